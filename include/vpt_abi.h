@@ -1,0 +1,326 @@
+/*
+ * vpt_abi.h -- C ABI of libvpt_hip.so, the MI355X (gfx950) replacement for the one
+ * device entry point of sergeneren/Volumetric-Path-Tracer: `volume_rt_kernel`
+ * (reference source/render_kernel.cu:2216) together with the scene handles that
+ * kernel dereferences (dense VDB textures, the instance octree, the look-up
+ * textures).  Plain C: POD structs, raw pointers, sizes.  No C++ / torch types.
+ *
+ * Every struct below mirrors a reference POD field-for-field (same names, same
+ * units).  Two deliberate differences, both forced by the platform:
+ *   - `cudaTextureObject_t` handles become `vpt_texture_t` handles created with
+ *     vpt_texture_create() (CDNA4 has no texture-filter path; filtering is ALU);
+ *   - reference classes with a vptr (`point_light`, `sphere`) are restated as PODs
+ *     without one -- the kernel never virtual-calls through them.
+ *
+ * Threading: one vpt_ctx per GPU, re-entrant per ctx, all work is enqueued on the
+ * HIP stream the caller passes (NULL = the ctx's own stream).  Errors: every entry
+ * point returns 0 or a negative VPT_E_* code and never exits the process
+ * (reference: check_success() -> exit(EXIT_FAILURE), source/main.cpp:136-142).
+ */
+#ifndef VPT_ABI_H_
+#define VPT_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPT_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------- */
+#define VPT_OK              0
+#define VPT_E_INVALID      -1   /* bad argument / NULL pointer / inconsistent sizes    */
+#define VPT_E_NO_DEVICE    -2   /* no usable gfx950 device                             */
+#define VPT_E_HIP          -3   /* a HIP runtime call failed (see vpt_last_error)       */
+#define VPT_E_NOMEM        -4
+#define VPT_E_NOT_READY    -5   /* scene / octree / look-up tables not bound yet        */
+#define VPT_E_UNSUPPORTED  -6
+#define VPT_E_IO           -7   /* host-side loader could not read / parse a file       */
+
+/* ---- small vector PODs (layout = CUDA float3/float4/int3/uint2) ------------------ */
+typedef struct vpt_float2 { float x, y; } vpt_float2;
+typedef struct vpt_float3 { float x, y, z; } vpt_float3;
+typedef struct vpt_float4 { float x, y, z, w; } vpt_float4;
+typedef struct vpt_int3   { int x, y, z; } vpt_int3;
+typedef struct vpt_uint2  { unsigned int x, y; } vpt_uint2;
+
+/* replaces cudaTextureObject_t (an opaque 64-bit handle in the reference too) */
+typedef unsigned long long vpt_texture_t;
+
+/* ---- camera : reference source/gpu_vdb/camera.h:94-148 --------------------------- */
+typedef struct vpt_camera {
+    float      time1, time0;          /* camera.h:139 (note the order: time1 first)   */
+    vpt_float3 origin;
+    float      focus_dist;
+    vpt_float3 lower_left_corner;
+    vpt_float3 horizontal;
+    vpt_float3 vertical;
+    vpt_float3 u, v, w;
+    float      lens_radius;
+    unsigned char viz_dof;            /* bool                                         */
+} vpt_camera;
+
+/* ---- lights : reference source/light.h:70-121,156-169 ---------------------------- */
+typedef struct vpt_point_light {
+    vpt_float3 pos;
+    vpt_float3 dir;
+    float      power;
+    vpt_float3 color;
+} vpt_point_light;
+
+typedef struct vpt_light_list {
+    unsigned int           num_lights;
+    const vpt_point_light *light_ptr;  /* HOST pointer; copied by vpt_render (the
+                                          reference used cudaMallocManaged,
+                                          source/main.cpp:1000)                       */
+} vpt_light_list;
+
+/* ---- reference sphere : source/geometry/geometry.h:80-171 ------------------------ */
+typedef struct vpt_sphere {
+    vpt_float3 center;
+    float      radius;
+    vpt_float3 color;
+    float      roughness;
+} vpt_sphere;
+
+/* ---- VDB_INFO / GPU_VDB : reference source/gpu_vdb/gpu_vdb.h:59-76,148-152 -------- */
+typedef struct vpt_vdb_info {
+    float      voxelsize;
+    vpt_int3   dim;
+    vpt_float3 bmin;
+    vpt_float3 bmax;
+    float      max_density;
+    float      min_density;
+    unsigned char has_color;
+    unsigned char has_emission;
+    unsigned char matte;
+    vpt_texture_t density_texture;    /* 3-D f32, normalised coords, linear, clamp    */
+    vpt_texture_t emission_texture;   /* 3-D f32                                      */
+    vpt_texture_t color_texture;      /* 3-D float4                                   */
+} vpt_vdb_info;
+
+typedef struct vpt_gpu_vdb {
+    vpt_vdb_info vdb_info;
+    float        xform[4][4];         /* mat4::m[col][row], matrix_math.h:49-70: the
+                                         OpenVDB index->world matrix in row-vector
+                                         convention (gpu_vdb.cpp:81-92)               */
+} vpt_gpu_vdb;
+
+/* ---- atmosphere : reference source/atmosphere/definitions.h:35-99 ----------------- */
+typedef struct vpt_density_profile_layer {
+    float width, exp_term, exp_scale, linear_term, const_term;
+} vpt_density_profile_layer;
+
+typedef struct vpt_density_profile { vpt_density_profile_layer layers[2]; } vpt_density_profile;
+
+typedef struct vpt_atmosphere_parameters {
+    vpt_float3 sky_spectral_radiance_to_luminance;
+    vpt_float3 sun_spectral_radiance_to_luminance;
+    vpt_float3 solar_irradiance;
+    float      angle;
+    float      bottom_radius;
+    float      top_radius;
+    int        use_luminance;
+    vpt_density_profile rayleigh_density;
+    vpt_float3 rayleigh_scattering;
+    vpt_density_profile mie_density;
+    vpt_float3 mie_scattering;
+    vpt_float3 mie_extinction;
+    float      mie_phase_function_g;
+    vpt_density_profile absorption_density;
+    vpt_float3 absorption_extinction;
+    vpt_float3 ground_albedo;
+    float      sun_angular_radius;
+    float      mu_s_min;
+    float      exposure;
+    vpt_float3 white_point;
+    /* precompute scratch (device pointers; only used by vpt_atmosphere_precompute) */
+    vpt_float4 *delta_irradience_buffer;
+    vpt_float4 *delta_rayleigh_scattering_buffer;
+    vpt_float4 *delta_mie_scattering_buffer;
+    vpt_float4 *delta_scattering_density_buffer;
+    vpt_float4 *delta_multiple_scattering_buffer;
+    vpt_float4 *transmittance_buffer;
+    vpt_float4 *irradiance_buffer;
+    vpt_float4 *scattering_buffer;
+    vpt_float4 *optional_mie_single_scattering_buffer;
+    /* render-time look-up tables */
+    vpt_texture_t transmittance_texture;          /* 2-D 256x64 float4, linear         */
+    vpt_texture_t scattering_texture;             /* 3-D 256x128x32 float4, linear     */
+    vpt_texture_t irradiance_texture;             /* 2-D 256x64 float4, linear         */
+    vpt_texture_t single_mie_scattering_texture;  /* 3-D 256x128x32 float4, linear     */
+} vpt_atmosphere_parameters;
+
+/* LUT dimensions, reference source/atmosphere/constants.h:50-62 */
+#define VPT_TRANSMITTANCE_W 256
+#define VPT_TRANSMITTANCE_H 64
+#define VPT_SCATTERING_R    32
+#define VPT_SCATTERING_MU   128
+#define VPT_SCATTERING_MU_S 32
+#define VPT_SCATTERING_NU   8
+#define VPT_IRRADIANCE_W    256
+#define VPT_IRRADIANCE_H    64
+
+/* ---- Kernel_params : reference source/kernel_params.h:39-109 ---------------------- */
+/* Buffer pointers are DEVICE pointers owned by the caller, exactly as in the
+ * reference (source/main.cpp:596-637 allocates them with cudaMalloc). */
+typedef struct vpt_kernel_params {
+    unsigned char render;             /* bool */
+    unsigned char debug;              /* bool */
+    vpt_uint2     resolution;
+    float         exposure_scale;
+    unsigned int *display_buffer;     /* W*H 0xffRRGGBB                                */
+    vpt_float4   *raw_buffer;         /* W*H tonemapped rgb + alpha                    */
+    vpt_float3   *blue_noise_buffer;  /* 256*256, advanced in place every iteration    */
+    vpt_float3   *emission_texture;   /* 256-entry blackbody LUT                       */
+    float         emission_scale;
+    float         emission_pivot;
+    vpt_float3   *density_color_texture; /* 256-entry LUT                              */
+    unsigned int  iteration;
+    vpt_float3   *accum_buffer;       /* W*H running mean                              */
+    float        *depth_buffer;       /* W*H running mean of first-hit distance        */
+    unsigned int  max_interactions;
+    int           ray_depth;
+    int           volume_depth;
+    float         min_extinction;
+    float         phase_g1, phase_g2, phase_f;
+    vpt_float3    albedo;
+    vpt_float3    extinction;
+    vpt_float3    transmittance;
+    float         tr_depth;
+    float         density_mult;
+    unsigned int  environment_type;   /* 0 procedural sky, 1 HDRI                      */
+    float         azimuth;            /* degrees                                       */
+    float         elevation;          /* degrees                                       */
+    vpt_float3    sun_color;
+    vpt_float3    sky_color;
+    float         sun_mult;
+    float         sky_mult;
+    double        energy_inject;
+    vpt_texture_t env_tex;            /* 2-D float4 lat-long, linear, wrap/clamp       */
+    int           env_sample_tex_res;
+    vpt_texture_t sky_tex;
+    vpt_texture_t env_func_tex;           /* 2-D f32, unnormalised, point, wrap/clamp  */
+    vpt_texture_t env_cdf_tex;
+    vpt_texture_t env_marginal_func_tex;  /* 1-D f32, unnormalised, point, wrap        */
+    vpt_texture_t env_marginal_cdf_tex;
+    float         env_marginal_int;
+    vpt_float3   *debug_buffer;
+    vpt_float3   *cost_buffer;        /* W*H running mean (always BLACK, :2249,:2280)  */
+    int           integrator;         /* 0 direct_integrator, !=0 vol_integrator       */
+} vpt_kernel_params;
+
+/* ---- textures : replaces cudaMalloc(3D)Array + cudaCreateTextureObject ------------
+ * call sites: source/gpu_vdb/gpu_vdb.cpp:214-248,293-327,373-407,
+ * source/main.cpp:775-867,957-976, source/atmosphere/atmosphere.cpp:503-675        */
+#define VPT_ADDR_WRAP   0
+#define VPT_ADDR_CLAMP  1
+#define VPT_FILTER_POINT  0
+#define VPT_FILTER_LINEAR 1
+
+typedef struct vpt_texture_desc {
+    int width, height, depth;     /* height = depth = 1 for 1-D, depth = 1 for 2-D     */
+    int channels;                 /* 1 (f32) or 4 (float4)                             */
+    int normalized_coords;        /* cudaTextureDesc::normalizedCoords                 */
+    int filter_mode;              /* VPT_FILTER_*                                      */
+    int address_mode[3];          /* VPT_ADDR_* per axis                               */
+} vpt_texture_desc;
+
+typedef struct vpt_ctx vpt_ctx;
+
+/* ---- context ----------------------------------------------------------------------- */
+/* replaces init_cuda()/cuModuleLoadData/cuModuleGetFunction, source/main.cpp:343-355,
+ * 1221-1244.  `device` is a HIP device ordinal. */
+int  vpt_create(int device, vpt_ctx **out_ctx);
+void vpt_destroy(vpt_ctx *ctx);
+const char *vpt_last_error(const vpt_ctx *ctx);   /* ctx may be NULL: last global error */
+int  vpt_abi_version(void);
+/* returns the HIP stream (hipStream_t) owned by the ctx */
+void *vpt_stream(vpt_ctx *ctx);
+int  vpt_sync(vpt_ctx *ctx);                      /* cudaDeviceSynchronize, main.cpp:1829 */
+
+/* ---- textures ---------------------------------------------------------------------- */
+/* `data` is a HOST pointer to width*height*depth*channels floats, x fastest
+ * (LayoutXYZ, gpu_vdb.cpp:179-212); it is copied to HBM. */
+int  vpt_texture_create(vpt_ctx *ctx, const vpt_texture_desc *desc, const float *data,
+                        vpt_texture_t *out_tex);
+/* same, but `device_data` already lives in HBM and is adopted without a copy
+ * (caller keeps ownership and must keep it alive) */
+int  vpt_texture_create_device(vpt_ctx *ctx, const vpt_texture_desc *desc,
+                               const float *device_data, vpt_texture_t *out_tex);
+int  vpt_texture_destroy(vpt_ctx *ctx, vpt_texture_t tex);
+
+/* ---- scene: instances + octree ---------------------------------------------------------
+ * replaces: cuMemAlloc+HtoD of instances[] (source/main.cpp:1301-1303) and
+ * BVH_Builder::build_bvh -> build_octree<<<1,1>>> (source/bvh/bvh_builder.cpp:46-105,
+ * source/bvh/bvh_kernels.cu:204-246,455,582).  Builds the fixed 3-level octree over
+ * the instance bounds on the host and uploads it with the instance table.  The LBVH
+ * is not built: volume_rt_kernel never traverses it (render_kernel.cu:2222). */
+int  vpt_scene_set_volumes(vpt_ctx *ctx, const vpt_gpu_vdb *volumes, int num_volumes);
+/* read back the root node facts the reference keeps on the host */
+int  vpt_scene_get_root(vpt_ctx *ctx, vpt_float3 *pmin, vpt_float3 *pmax,
+                        float *max_extinction, float *min_extinction);
+/* number of octree nodes with num_volumes>0 per level (root excluded): out[3] */
+int  vpt_scene_get_octree_stats(vpt_ctx *ctx, int out_nonempty[3]);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * vpt_render: ONE launch of volume_rt_kernel = one sample per pixel at
+ * kernel_params->iteration (drop-in for cuLaunchKernel at source/main.cpp:1822-1829,
+ * params[] = {cam, lights, volumes, sphere, geo_list, bvh, octree, atmosphere, kp};
+ * volumes/octree come from vpt_scene_set_volumes, geo_list/bvh are unused by the
+ * kernel).  Asynchronous on `stream` (hipStream_t, NULL = ctx stream). */
+int  vpt_render(vpt_ctx *ctx, const vpt_camera *cam, const vpt_light_list *lights,
+                const vpt_sphere *ref_sphere, const vpt_atmosphere_parameters *atmosphere,
+                const vpt_kernel_params *kernel_params, void *stream);
+
+/* vpt_render_batch: iterations kp->iteration + k*iter_stride, k = 0..iter_count-1, in
+ * one call (what the reference's main loop does with iter_count launches).  Buffers
+ * end in exactly the state iter_count successive launches would leave them in,
+ * except display/raw which are tonemapped once at the end (they are overwritten
+ * every launch in the reference, render_kernel.cu:2303-2316).  iter_stride > 1 is
+ * the multi-GPU iteration striping: the running means then weight the samples of
+ * this rank only (local index k), and blue noise advances iter_stride steps per k. */
+int  vpt_render_batch(vpt_ctx *ctx, const vpt_camera *cam, const vpt_light_list *lights,
+                      const vpt_sphere *ref_sphere, const vpt_atmosphere_parameters *atmosphere,
+                      const vpt_kernel_params *kernel_params, unsigned int iter_count,
+                      unsigned int iter_stride, void *stream);
+
+/* advance a 256x256 float3 blue-noise buffer by `steps` golden-ratio increments
+ * (render_kernel.cu:2320-2325), e.g. to position rank g of a striped render */
+int  vpt_blue_noise_advance(vpt_ctx *ctx, vpt_float3 *blue_noise_buffer, unsigned int steps,
+                            void *stream);
+
+/* per-launch statistics of the last render call (device counters, read back after a
+ * sync): look-up counts feeding the algorithmic-bytes roofline */
+typedef struct vpt_render_stats {
+    unsigned long long samples;           /* pixel-samples traced                      */
+    unsigned long long density_lookups;   /* N_d                                       */
+    unsigned long long color_lookups;     /* N_c                                       */
+    unsigned long long emission_lookups;  /* N_e                                       */
+    unsigned long long tracking_steps;    /* RNG-consuming steps of sample/Tr/emission */
+    unsigned long long skip_steps;        /* empty-node pushes                         */
+    float              trace_ms;          /* HIP-event time of the trace kernel(s)     */
+    float              resolve_ms;        /* HIP-event time of the resolve kernel(s)   */
+} vpt_render_stats;
+/* enable/disable look-up counting (off by default: counting costs atomics) */
+int  vpt_set_counting(vpt_ctx *ctx, int enable);
+int  vpt_get_stats(vpt_ctx *ctx, vpt_render_stats *out);
+
+/* ---- host-side helpers restating reference host code the path depends on --------------- */
+/* camera::update_camera, source/gpu_vdb/camera.h:110-129 */
+void vpt_camera_update(vpt_camera *cam, vpt_float3 lookfrom, vpt_float3 lookat, vpt_float3 vup,
+                       float vfov, float aspect, float aperture);
+/* camera() default ctor, camera.h:97-106 */
+void vpt_camera_default(vpt_camera *cam);
+/* GPU_VDB::Bounds, source/gpu_vdb/gpu_vdb.h:131-146 */
+void vpt_gpu_vdb_bounds(const vpt_gpu_vdb *vdb, vpt_float3 *pmin, vpt_float3 *pmax);
+/* Kernel_params defaults of source/main.cpp:1350-1376 (+ the per-frame overrides at
+ * :1533-1546: azimuth 120, elevation 30, energy_inject 1.0) */
+void vpt_kernel_params_default(vpt_kernel_params *kp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPT_ABI_H_ */

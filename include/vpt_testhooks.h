@@ -1,0 +1,26 @@
+/* vpt_testhooks.h -- NOT part of the drop-in boundary.  Small probes the test-suite uses to
+ * pin the product's fixed-sequence arithmetic (csrc/vpt_math.h) against the oracle's,
+ * on the host and on the device.  Exported by libvpt_hip.so next to the vpt_abi.h symbols. */
+#ifndef VPT_TESTHOOKS_H_
+#define VPT_TESTHOOKS_H_
+#include "vpt_abi.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define VPT_OP_LOG 0
+#define VPT_OP_SIN 1
+#define VPT_OP_COS 2
+#define VPT_OP_UNIFORM 3   /* in[i] reinterpreted as uint32 -> curand_uniform mapping */
+#define VPT_OP_RCP 4       /* 1.0f / x  */
+#define VPT_OP_SQRT 5
+/* evaluate op element-wise with the HOST build of csrc/vpt_math.h */
+int vpt_test_host_math(int op, const float *in, float *out, int n);
+/* evaluate op element-wise in a gfx950 kernel (in/out are HOST arrays) */
+int vpt_test_device_math(vpt_ctx *ctx, int op, const float *in, float *out, int n);
+/* n raw Philox draws of rocRAND's philox4x32_10 from rocrand_init(seed, 0, offset), mapped
+ * with the curand_uniform formula -- the stream the trace kernel consumes */
+int vpt_test_device_uniform_stream(vpt_ctx *ctx, unsigned long long seed, unsigned long long offset, int n, float *out);
+#ifdef __cplusplus
+}
+#endif
+#endif

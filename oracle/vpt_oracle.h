@@ -1,0 +1,88 @@
+/* vpt_oracle.h -- TEST INFRASTRUCTURE: C API of the CPU oracle (liborc.so).
+ *
+ * The oracle is a single-threaded-by-default CPU restatement of the reference's
+ * `volume_rt_kernel` (source/render_kernel.cu:2216) and everything it calls.  It is
+ * the checker for the HIP path and the "CPU ray-marching baseline" of bench.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden images or known answers for
+ * this path and cannot be built here (CUDA/OpenVDB/Windows deps).
+ * What is pinned: Philox4x32-10 against the Random123 known-answer vector, the
+ * dragon.vdb asset facts (voxel count, bbox, value range), and closed-form
+ * properties (homogeneous-slab transmittance, trilinear exactness on linear fields).
+ *
+ * It re-uses the POD structs of include/vpt_abi.h (they restate the reference's PODs).
+ * Texture handles inside those PODs are oracle handles made by orc_texture_create;
+ * buffer pointers inside vpt_kernel_params are HOST pointers here.
+ */
+#ifndef VPT_ORACLE_H_
+#define VPT_ORACLE_H_
+
+#include "../include/vpt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* look-up counters feeding SURVEY 8(d)'s algorithmic-bytes formula */
+typedef struct orc_stats {
+    unsigned long long samples;
+    unsigned long long density_lookups;   /* N_d */
+    unsigned long long color_lookups;     /* N_c */
+    unsigned long long emission_lookups;  /* N_e */
+    unsigned long long tracking_steps;
+    unsigned long long skip_steps;
+    unsigned long long rng_draws;
+    unsigned long long max_draws_per_sample;
+} orc_stats;
+
+/* host texture with CUDA sampler semantics; data is NOT copied */
+vpt_texture_t orc_texture_create(const vpt_texture_desc *desc, const float *data);
+void orc_texture_destroy(vpt_texture_t tex);
+/* sample a texture directly (unit tests of the sampler restatement) */
+void orc_texture_sample(vpt_texture_t tex, float u, float v, float w, float out[4]);
+
+/* Philox4x32-10 block function + cuRAND stream semantics (unit tests) */
+void orc_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4]);
+/* n draws of curand_uniform from curand_init(seed, 0, offset) */
+void orc_curand_uniform_stream(unsigned long long seed, unsigned long long offset, int n, float *out);
+
+/* deterministic elementary functions (unit tests) */
+float orc_det_logf(float x);
+float orc_det_sinf(float x);
+float orc_det_cosf(float x);
+
+/* octree facts (unit tests / cross-check of the product's host builder) */
+typedef struct orc_octree_info {
+    vpt_float3 root_pmin, root_pmax;
+    float max_extinction, min_extinction;
+    int nonempty[3];          /* nodes with num_volumes>0 at levels 1..3 */
+    int total_nodes;
+} orc_octree_info;
+int orc_octree_info_get(const vpt_gpu_vdb *volumes, int num_volumes, orc_octree_info *out);
+/* point location: returns leaf path i*64+x*8+y (or -1) and whether the leaf is empty */
+int orc_octree_locate(const vpt_gpu_vdb *volumes, int num_volumes, vpt_float3 p, int *num_volumes_in_leaf);
+
+/* sum_density at a world position over all volumes (brute force, no octree) */
+float orc_density_at(const vpt_gpu_vdb *volumes, int num_volumes, vpt_float3 p);
+
+/* Render iterations kp->iteration + k*iter_stride, k=0..iter_count-1, exactly as
+ * iter_count successive launches of volume_rt_kernel would (display/raw tonemapped
+ * after every iteration like the reference).  nthreads<=1: single thread. */
+int orc_render(const vpt_camera *cam, const vpt_light_list *lights,
+               const vpt_gpu_vdb *volumes, int num_volumes,
+               const vpt_sphere *ref_sphere, const vpt_atmosphere_parameters *atmosphere,
+               const vpt_kernel_params *kp, unsigned int iter_count, unsigned int iter_stride,
+               int nthreads, orc_stats *stats);
+
+/* one pixel-sample, returning the integrator's value before accumulation (debugging
+ * and per-sample parity tests): out = {L.x, L.y, L.z, tr, depth} */
+int orc_sample_pixel(const vpt_camera *cam, const vpt_light_list *lights,
+                     const vpt_gpu_vdb *volumes, int num_volumes,
+                     const vpt_sphere *ref_sphere, const vpt_atmosphere_parameters *atmosphere,
+                     const vpt_kernel_params *kp, int x, int y, float out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

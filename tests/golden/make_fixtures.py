@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the reference's shipped assets.
+
+Run in the build container (needs /root/reference, which does NOT exist on the GPU
+box; the fixtures it writes do travel):
+
+    python tests/golden/make_fixtures.py
+
+Outputs (tests/golden/):
+  dragon_dense.npz   dense LayoutXYZ copy of assets/dragon.vdb's `density` grid over its
+                     active-voxel bbox + VDB_INFO facts + index->world matrix -- what
+                     GPU_VDB::loadVDB builds (reference source/gpu_vdb/gpu_vdb.cpp:171-250,
+                     413-471)
+  dragon_xform_dense.npz   same for assets/dragon_with_xform.vdb (AffineMap, active tiles)
+  bn0.npz            assets/BN0.bmp as the float3 blue-noise buffer of
+                     load_texture_bmp_gpu (source/util/fileIO.cpp:460-495: x=R, y=B, z=G)
+  luts.npz           blackbody_texture.exr and density_color_texture2.exr as float3[256]
+                     (load_texture_exr_gpu, source/util/fileIO.cpp:356-390)
+Known answers pinned here: dragon.vdb has 131 leaves, 19 660 active
+voxels, bbox (16,1,35)-(85,49,65), active max 1.0, min 2.8933e-05; the file's own
+`file_voxel_count` / `file_bbox_*` metadata must agree with the parse.
+"""
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import vdb_reader_py  # noqa: E402
+
+ASSETS = "/root/reference/assets"
+
+
+def read_bmp24(path):
+    """24-bit uncompressed BMP -> uint8 [H, W, 3] RGB, top-down (bitmap_image.h:1603-1609)."""
+    with open(path, "rb") as f:
+        b = f.read()
+    assert b[:2] == b"BM"
+    off = struct.unpack_from("<I", b, 10)[0]
+    w, h = struct.unpack_from("<ii", b, 18)
+    bpp = struct.unpack_from("<H", b, 28)[0]
+    comp = struct.unpack_from("<I", b, 30)[0]
+    assert bpp == 24 and comp == 0
+    stride = (w * 3 + 3) & ~3
+    bottom_up = h > 0
+    h = abs(h)
+    img = np.zeros((h, w, 3), np.uint8)
+    for row in range(h):
+        src = off + row * stride
+        line = np.frombuffer(b, np.uint8, w * 3, src).reshape(w, 3)[:, ::-1]   # BGR -> RGB
+        img[h - 1 - row if bottom_up else row] = line
+    return img
+
+
+def read_exr_half_rgba_uncompressed(path):
+    """OpenEXR v2 single-part scanline, uncompressed, all-HALF channels -> dict name -> f32[H, W]."""
+    with open(path, "rb") as f:
+        b = f.read()
+    assert b[:4] == bytes([0x76, 0x2F, 0x31, 0x01])
+    p = 8
+    attrs = {}
+
+    def cstr(p):
+        e = b.index(b"\0", p)
+        return b[p:e].decode(), e + 1
+
+    while b[p] != 0:
+        name, p = cstr(p)
+        typ, p = cstr(p)
+        size = struct.unpack_from("<I", b, p)[0]
+        p += 4
+        attrs[name] = (typ, b[p:p + size])
+        p += size
+    p += 1
+    assert attrs["compression"][1][0] == 0, "only uncompressed EXR supported"
+    xmin, ymin, xmax, ymax = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = xmax - xmin + 1, ymax - ymin + 1
+    chans = []
+    cb = attrs["channels"][1]
+    q = 0
+    while cb[q] != 0:
+        e = cb.index(b"\0", q)
+        cname = cb[q:e].decode()
+        q = e + 1
+        ptype = struct.unpack_from("<i", cb, q)[0]
+        q += 16
+        assert ptype == 1, "HALF channels only"
+        chans.append(cname)
+    offsets = struct.unpack_from("<%dQ" % h, b, p)
+    out = {c: np.zeros((h, w), np.float32) for c in chans}
+    for row in range(h):
+        o = offsets[row]
+        y, size = struct.unpack_from("<iI", b, o)
+        o += 8
+        for c in chans:          # channels are stored alphabetically per scanline
+            out[c][y - ymin] = np.frombuffer(b, "<f2", w, o).astype(np.float32)
+            o += 2 * w
+    return out
+
+
+def vdb_fixture(path, out_path):
+    grids = vdb_reader_py.read_vdb(path)
+    g = grids["density"]
+    dense, lo, hi = g.to_dense()
+    dense = dense[..., 0]
+    dim = hi - lo + 1
+    active_vals = np.concatenate([v[m, 0] for _, v, m in g.leaves if m.any()] + [np.repeat(val[0], (1 << lg) ** 3) for _, lg, val in g.tiles])
+    info = dict(
+        density=dense.astype(np.float32),                        # [z, y, x], x fastest
+        bbox_min=lo.astype(np.int32), bbox_max=hi.astype(np.int32), dim=dim.astype(np.int32),
+        matrix=np.asarray(g.matrix, np.float64),                 # OpenVDB Mat4d, row-vector convention
+        voxel_size=np.float64(g.voxel_size),
+        leaf_count=np.int64(len(g.leaves)), tile_count=np.int64(len(g.tiles)),
+        active_voxel_count=np.int64(g.active_voxel_count()),
+        active_max=np.float32(active_vals.max()), active_min=np.float32(active_vals.min()),
+        file_voxel_count=np.int64(g.meta["file_voxel_count"]),
+        file_bbox_min=np.asarray(g.meta["file_bbox_min"], np.int32),
+        file_bbox_max=np.asarray(g.meta["file_bbox_max"], np.int32),
+    )
+    assert info["active_voxel_count"] == info["file_voxel_count"]
+    assert (info["file_bbox_min"] == lo).all() and (info["file_bbox_max"] == hi).all()
+    np.savez_compressed(out_path, **info)
+    print(out_path, dense.shape, "leaves", len(g.leaves), "tiles", len(g.tiles), "active", g.active_voxel_count(),
+          "max", active_vals.max(), "min", active_vals.min())
+    return info
+
+
+def main():
+    d = vdb_fixture(os.path.join(ASSETS, "dragon.vdb"), os.path.join(HERE, "dragon_dense.npz"))
+    assert int(d["leaf_count"]) == 131 and int(d["active_voxel_count"]) == 19660
+    assert tuple(d["bbox_min"]) == (16, 1, 35) and tuple(d["bbox_max"]) == (85, 49, 65)
+    vdb_fixture(os.path.join(ASSETS, "dragon_with_xform.vdb"), os.path.join(HERE, "dragon_xform_dense.npz"))
+
+    img = read_bmp24(os.path.join(ASSETS, "BN0.bmp"))
+    assert img.shape == (256, 256, 3)
+    np.savez_compressed(os.path.join(HERE, "bn0.npz"), rgb=img)
+    print("bn0", img.shape, img.mean())
+
+    luts = {}
+    for name, key in (("blackbody_texture.exr", "blackbody"), ("density_color_texture2.exr", "density_color")):
+        ch = read_exr_half_rgba_uncompressed(os.path.join(ASSETS, name))
+        rgb = np.stack([ch["R"][0], ch["G"][0], ch["B"][0]], axis=-1).astype(np.float32)
+        assert rgb.shape == (256, 3)
+        luts[key] = rgb
+        print(name, rgb[0], rgb[-1])
+    assert (luts["density_color"] == 1.0).all()
+    np.savez_compressed(os.path.join(HERE, "luts.npz"), **luts)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""The C-ABI library loads, exports every symbol include/vpt_abi.h declares, and the ctypes
+mirrors have the C layouts (no compute calls: runs without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    hdr = open(os.path.join(ROOT, "include", "vpt_abi.h")).read()
+    declared = set(re.findall(r"\b(vpt_[a-z_0-9]+)\s*\(", hdr)) - {"vpt_texture_create_device_"}
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(pkg.ABI_SYMBOLS), (declared ^ set(pkg.ABI_SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vpt_abi_version() == 1
+
+
+def test_struct_layouts_match_the_c_compiler(pkg, tmp_path):
+    abi = pkg.abi
+    pairs = [("vpt_camera", abi.Camera), ("vpt_point_light", abi.PointLight), ("vpt_light_list", abi.LightList),
+             ("vpt_sphere", abi.Sphere), ("vpt_vdb_info", abi.VdbInfo), ("vpt_gpu_vdb", abi.GpuVdb),
+             ("vpt_density_profile", abi.DensityProfile), ("vpt_atmosphere_parameters", abi.AtmosphereParameters),
+             ("vpt_kernel_params", abi.KernelParams), ("vpt_texture_desc", abi.TextureDesc), ("vpt_render_stats", abi.RenderStats)]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "vpt_abi.h"), "int main(){"]
+    expect = []
+    for cname, cls in pairs:
+        src.append('printf("%%zu\\n", sizeof(%s));' % cname)
+        expect.append(C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            src.append('printf("%%zu\\n", offsetof(%s, %s));' % (cname, fname))
+            expect.append(getattr(cls, fname).offset)
+    src.append("return 0;}")
+    cfile = tmp_path / "lay.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", str(cfile), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == expect
+    # the reference's own sizes for the PODs that cross its launch boundary
+    assert C.sizeof(abi.Camera) == 104
+    assert C.sizeof(abi.GpuVdb) == 144 and C.sizeof(abi.VdbInfo) == 80
+
+
+def test_defaults_match_reference_main(pkg):
+    """Kernel_params defaults of main.cpp:1350-1376 plus the per-frame overrides :1533-1546."""
+    lib = pkg.load_library()
+    kp = pkg.abi.KernelParams()
+    lib.vpt_kernel_params_default(C.byref(kp))
+    assert (kp.render, kp.max_interactions, kp.ray_depth, kp.volume_depth) == (1, 100, 50, 1)
+    assert (kp.phase_g1, kp.tr_depth, kp.density_mult, kp.exposure_scale) == (0.0, 1.0, 1.0, 1.0)
+    assert (kp.azimuth, kp.elevation, kp.sun_mult, kp.sky_mult, kp.energy_inject) == (120.0, 30.0, 1.0, 1.0, 1.0)
+    assert kp.albedo.tuple() == (1, 1, 1) and kp.extinction.tuple() == (1, 1, 1)
+    assert (kp.integrator, kp.environment_type, kp.emission_scale, kp.emission_pivot) == (0, 0, 0.0, 1.0)
+    cam = pkg.abi.Camera()
+    lib.vpt_camera_default(C.byref(cam))
+    assert (cam.time0, cam.time1, cam.lens_radius) == (0.0, 1.0, 25.0)
+
+
+def test_camera_update_against_float64_formula(pkg):
+    """camera::update_camera (camera.h:110-129) checked against an independent numpy evaluation."""
+    import numpy as np
+    lib = pkg.load_library()
+    F3 = pkg.abi.Float3
+    cam = pkg.abi.Camera()
+    lf, la, up = np.array([10.0, 7.0, -3.0]), np.array([1.0, 2.0, 0.5]), np.array([0.0, 1.0, 0.0])
+    lib.vpt_camera_update(C.byref(cam), F3(*lf), F3(*la), F3(*up), 30.0, 16.0 / 9.0, 2.0)
+    fd = np.linalg.norm(lf - la)
+    hh = np.tan(np.radians(30.0) / 2)
+    hw = hh * 16.0 / 9.0
+    w = (lf - la) / fd
+    u = np.cross(up, w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    assert abs(cam.focus_dist - fd) < 1e-5 and cam.lens_radius == 1.0
+    np.testing.assert_allclose(cam.u.tuple(), u, atol=1e-6)
+    np.testing.assert_allclose(cam.v.tuple(), v, atol=1e-6)
+    np.testing.assert_allclose(cam.lower_left_corner.tuple(), lf - hw * fd * u - hh * fd * v - fd * w, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cam.horizontal.tuple(), 2 * hw * fd * u, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cam.vertical.tuple(), 2 * hh * fd * v, rtol=1e-5, atol=1e-5)
+
+
+def test_render_fails_loudly_without_gpu(pkg):
+    """No CPU fallback: without a gfx950 device the product refuses to create a context."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.VptError):
+        pkg.Context(0)

@@ -1,0 +1,150 @@
+// vpt_device.h -- device-side views of the scene and the per-launch parameter blocks.
+//
+// HBM layout (DESIGN.md, section Data layout):
+//   * density / emission grids: dense f32, x fastest (LayoutXYZ of the reference's
+//     copyToDense, gpu_vdb.cpp:179-212); colour grids: dense float4;
+//   * the 3-level instance octree is stored as three occupancy bit-sets (8 + 64 + 512
+//     bits) plus a CSR list of instance indices per leaf -- child boxes are re-derived
+//     arithmetically by halving the parent box (bvh_kernels.cu:150-202 divide_bbox), which
+//     reproduces the reference's node boxes bit-for-bit without the 2.5 KB OCTNode;
+//   * path records: one 64-byte line per pixel-sample, written once by the trace
+//     kernel, read once by the resolve kernel.
+#pragma once
+
+#include "vpt_math.h"
+
+namespace vpt {
+
+struct DVolume {
+    const float* density;
+    const float* emission;
+    const f4* color;
+    float m[12];   // world->index rows: q.x = m[0]*x + m[1]*y + m[2]*z + m[3], ...
+    float bmin[3];
+    float fdim[3];
+    int dim[3];
+    int has_color;
+    int has_emission;
+    int pad_;
+};
+
+struct DTexture {          // CUDA sampler state restated
+    const float* data;
+    int width, height, depth, channels;
+    int normalized, linear;
+    int addr[3];
+};
+
+// 64-byte path record: trace -> resolve
+struct __attribute__((aligned(16))) Record {
+    float L[3];
+    float tr;
+    float beta[3];
+    float depth;
+    float env_pos[3];
+    uint32_t flags;        // bit0: sample was traced (render && iteration < max_interactions)
+    float dir[3];
+    float pad_;
+};
+static_assert(sizeof(Record) == 64, "Record must be one 64-byte line");
+
+struct DPointLight {       // vpt_point_light
+    float pos[3];
+    float dir[3];
+    float power;
+    float color[3];
+};
+
+struct DCamera {           // vpt_camera, same field order
+    float time1, time0;
+    float origin[3];
+    float focus_dist;
+    float llc[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+    unsigned char viz_dof;
+};
+
+struct Counters {
+    unsigned long long samples;
+    unsigned long long density_lookups;
+    unsigned long long color_lookups;
+    unsigned long long emission_lookups;
+    unsigned long long tracking_steps;
+    unsigned long long skip_steps;
+};
+
+struct TraceParams {
+    // work distribution
+    uint32_t width, height, n_pixels;
+    uint32_t iter_begin, iter_stride, iter_count;
+    uint32_t max_interactions;
+    int render;
+    uint32_t* work_counter;          // next sample id (0 .. n_pixels*iter_count)
+    Record* records;                 // [iter_count][n_pixels]
+    const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
+    Counters* counters;              // may be NULL
+    // camera
+    DCamera cam;
+    // octree / scene
+    float root_pmin[3], root_pmax[3];
+    float max_ext, min_ext;
+    uint32_t occ[19];                // [0]: level-1, [1..2]: level-2, [3..18]: level-3 occupancy
+    const uint32_t* leaf_offsets;    // 513 CSR offsets (multi-volume scenes)
+    const uint32_t* leaf_indices;
+    const DVolume* volumes;
+    int num_volumes;
+    DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs
+    // reference sphere
+    float sph_center[3];
+    float sph_radius;
+    float sph_color[3];
+    float sph_roughness;
+    // lights
+    const DPointLight* lights;
+    int num_lights;
+    // Kernel_params subset
+    int ray_depth, volume_depth;
+    float phase_g1;
+    float albedo[3], extinction[3];
+    float tr_depth, density_mult;
+    float emission_scale, emission_pivot;
+    float sun_color[3];
+    float sun_mult;
+    float sun_dir[3];                // degree_to_cartesian(azimuth, elevation), host-evaluated
+    float energy_inject;             // float(kernel_params.energy_inject)
+    const float* emission_lut;       // float3[256]
+    const float* density_color_lut;  // float3[256]
+    unsigned int environment_type;
+};
+
+struct ResolveParams {
+    uint32_t width, height, n_pixels;
+    uint32_t iter_begin, iter_stride, iter_count;
+    uint32_t max_interactions;
+    const Record* records;
+    float* accum;          // float3[n_pixels]
+    float* cost;           // float3[n_pixels] or NULL
+    float* depth;          // float[n_pixels] or NULL
+    uint32_t* display;     // or NULL
+    float* raw;            // float4[n_pixels] or NULL
+    float exposure_scale;
+    // camera bits for viz_dof
+    float lens_radius, focus_dist;
+    int viz_dof;
+    // environment
+    unsigned int environment_type;
+    int integrator;
+    float sky_mult;
+    float sky_color[3];
+    float sun_dir[3];
+    DTexture env_tex;
+    // atmosphere
+    int has_atmosphere;
+    float atm_f[64];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
+    DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
+};
+
+}  // namespace vpt

@@ -1,0 +1,771 @@
+// vpt_host.hip -- C-ABI implementation (include/vpt_abi.h) and the host-side restatement of
+// the reference host code the hot path depends on: texture creation (gpu_vdb.cpp:214-248),
+// instance upload + octree build (bvh_builder.cpp:46-105, bvh_kernels.cu:150-246),
+// camera::update_camera (camera.h:110-129), GPU_VDB::Bounds (gpu_vdb.h:131-146), the
+// Kernel_params defaults (main.cpp:1350-1376,1533-1546) and the per-frame launch
+// (main.cpp:1822-1829).
+//
+// No CPU fallback exists: every render entry point needs a gfx950 device and fails with
+// VPT_E_NO_DEVICE / VPT_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vpt_abi.h"
+#include "vpt_device.h"
+
+namespace vpt {
+hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
+hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
+hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream);
+}  // namespace vpt
+
+using namespace vpt;
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_last_error;
+
+struct TexEntry {
+    DTexture t;
+    void* owned;     // device allocation owned by the ctx (NULL when adopted)
+    bool live;
+};
+
+struct Box { f3 lo, hi; };
+
+}  // namespace
+
+struct vpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int blocks_per_cu = 4;
+    std::string last_error;
+    std::vector<TexEntry> textures;
+    // scene
+    std::vector<vpt_gpu_vdb> host_volumes;
+    std::vector<DVolume> host_dvolumes;
+    DVolume* d_volumes = nullptr;
+    uint32_t* d_leaf_offsets = nullptr;
+    uint32_t* d_leaf_indices = nullptr;
+    uint32_t occ[19] = {0};
+    Box root = {{0, 0, 0}, {0, 0, 0}};
+    float max_ext = 0.0f, min_ext = 0.0f;
+    int nonempty[3] = {0, 0, 0};
+    bool scene_ready = false;
+    bool any_color = false, any_emission = false;
+    // scratch
+    Record* d_records = nullptr;
+    size_t records_capacity = 0;           // in records
+    float2* d_bn_table = nullptr;
+    size_t bn_capacity = 0;                // in iterations
+    uint32_t* d_work_counter = nullptr;
+    Counters* d_counters = nullptr;
+    DPointLight* d_lights = nullptr;
+    size_t lights_capacity = 0;
+    std::vector<DPointLight> lights_cache;
+    // stats
+    bool counting = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int e0, e1; int kind; };
+    std::vector<Span> spans;
+    int ev_used = 0;
+    unsigned long long last_samples = 0;
+};
+
+namespace {
+
+void set_error(vpt_ctx* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    std::lock_guard<std::mutex> g(g_err_mutex);
+    g_last_error = buf;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            set_error(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VPT_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+inline f3 v3(vpt_float3 v) { return mk3(v.x, v.y, v.z); }
+inline vpt_float3 tov(f3 v) { vpt_float3 r = {v.x, v.y, v.z}; return r; }
+inline void st3(float* d, f3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline void st3(float* d, vpt_float3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+mat4 load_xform(const vpt_gpu_vdb& v) {
+    mat4 m;
+    std::memcpy(m.m, v.xform, sizeof(m.m));
+    return m;
+}
+
+// GPU_VDB::Bounds, gpu_vdb.h:131-146
+Box vdb_bounds(const vpt_gpu_vdb& v) {
+    f3 bmin = v3(v.vdb_info.bmin), bmax = v3(v.vdb_info.bmax);
+    f3 center = (bmax + bmin) * 0.5f;
+    f3 extent = (bmax - bmin) * 0.5f;
+    mat4 x = load_xform(v);
+    f3 nc = mat4_transform_point(mat4_transpose(x), center);
+    f3 ne = mat4_transform_vector(mat4_transpose(mat4_abs(x)), extent);
+    Box b = {nc - ne, nc + ne};
+    return b;
+}
+
+bool overlaps(const Box& a, const Box& b) {                  // AABB.h:134-139
+    bool x = (a.hi.x >= b.lo.x) && (a.lo.x <= b.hi.x);
+    bool y = (a.hi.y >= b.lo.y) && (a.lo.y <= b.hi.y);
+    bool z = (a.hi.z >= b.lo.z) && (a.lo.z <= b.hi.z);
+    return (x && y && z);
+}
+
+// child i of a node box, divide_bbox (bvh_kernels.cu:150-202); same halving arithmetic as
+// the device-side point location in vpt_trace.hip
+Box child_box(const Box& p, int i) {
+    const float hx = (p.lo.x + p.hi.x) * 0.5f, hy = (p.lo.y + p.hi.y) * 0.5f, hz = (p.lo.z + p.hi.z) * 0.5f;
+    const bool xh = (i & 1) != 0, yh = (i & 2) == 0, zh = (i & 4) != 0;
+    Box c;
+    c.lo = mk3(xh ? hx : p.lo.x, yh ? hy : p.lo.y, zh ? hz : p.lo.z);
+    c.hi = mk3(xh ? p.hi.x : hx, yh ? p.hi.y : hy, zh ? p.hi.z : hz);
+    return c;
+}
+
+// degree_to_cartesian, render_kernel.cu:126-142 (evaluated once on the host with the same
+// fixed-sequence sin/cos the device would use)
+f3 degree_to_cartesian(float azimuth, float elevation) {
+    float az = clampf(azimuth, .0f, 360.0f);
+    float el = clampf(elevation, -90.0f, 90.0f);
+    az = az * VPT_PI / 180.0f;
+    el = (90.0f - el) * VPT_PI / 180.0f;
+    float x = det_sinf(el) * det_cosf(az);
+    float y = det_cosf(el);
+    float z = det_sinf(el) * det_sinf(az);
+    return normalize(mk3(x, y, z));
+}
+
+int resolve_tex(vpt_ctx* ctx, vpt_texture_t h, DTexture* out) {
+    if (h == 0 || h > ctx->textures.size() || !ctx->textures[h - 1].live) return VPT_E_INVALID;
+    *out = ctx->textures[h - 1].t;
+    return 0;
+}
+
+int get_events(vpt_ctx* ctx, int* e0, int* e1) {
+    while ((int)ctx->ev_pool.size() < ctx->ev_used + 2) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *e0 = ctx->ev_used++;
+    *e1 = ctx->ev_used++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpt_abi_version(void) { return VPT_ABI_VERSION; }
+
+const char* vpt_last_error(const vpt_ctx* ctx) {
+    if (ctx) return ctx->last_error.c_str();
+    std::lock_guard<std::mutex> g(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_last_error;
+    return copy.c_str();
+}
+
+int vpt_create(int device, vpt_ctx** out_ctx) {
+    if (!out_ctx) return VPT_E_INVALID;
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error(nullptr, "vpt_create: no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return VPT_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error(nullptr, "vpt_create: device %d out of range (0..%d)", device, count - 1);
+        return VPT_E_INVALID;
+    }
+    vpt_ctx* ctx = new vpt_ctx();
+    ctx->device = device;
+    HIPCHK(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(nullptr, "vpt_create: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+        delete ctx;
+        return VPT_E_NO_DEVICE;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    const char* bpc = std::getenv("VPT_BLOCKS_PER_CU");
+    if (bpc && std::atoi(bpc) > 0) ctx->blocks_per_cu = std::atoi(bpc);
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
+    HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
+    *out_ctx = ctx;
+    return VPT_OK;
+}
+
+void vpt_destroy(vpt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& t : ctx->textures)
+        if (t.live && t.owned) (void)hipFree(t.owned);
+    (void)hipFree(ctx->d_volumes);
+    (void)hipFree(ctx->d_leaf_offsets);
+    (void)hipFree(ctx->d_leaf_indices);
+    (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_bn_table);
+    (void)hipFree(ctx->d_work_counter);
+    (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_lights);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int vpt_sync(vpt_ctx* ctx) {
+    if (!ctx) return VPT_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return VPT_OK;
+}
+
+// ---- textures ---------------------------------------------------------------------------------
+static int texture_add(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* host, const float* dev, vpt_texture_t* out) {
+    if (!ctx || !desc || !out || (!host && !dev)) return VPT_E_INVALID;
+    if (desc->width <= 0 || (desc->channels != 1 && desc->channels != 4)) {
+        set_error(ctx, "vpt_texture_create: bad descriptor (width %d, channels %d)", desc->width, desc->channels);
+        return VPT_E_INVALID;
+    }
+    TexEntry te;
+    te.t.width = desc->width;
+    te.t.height = desc->height > 0 ? desc->height : 1;
+    te.t.depth = desc->depth > 0 ? desc->depth : 1;
+    te.t.channels = desc->channels;
+    te.t.normalized = desc->normalized_coords;
+    te.t.linear = desc->filter_mode == VPT_FILTER_LINEAR;
+    for (int i = 0; i < 3; ++i) te.t.addr[i] = desc->address_mode[i];
+    te.owned = nullptr;
+    te.live = true;
+    const size_t n = (size_t)te.t.width * te.t.height * te.t.depth * te.t.channels;
+    if (n > ((size_t)1 << 32)) {
+        set_error(ctx, "vpt_texture_create: %zu elements exceeds the 32-bit texel index of this build", n);
+        return VPT_E_UNSUPPORTED;
+    }
+    if (host) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, n * sizeof(float));
+        if (e != hipSuccess) {
+            set_error(ctx, "vpt_texture_create: hipMalloc(%zu bytes) failed: %s", n * sizeof(float), hipGetErrorString(e));
+            return VPT_E_NOMEM;
+        }
+        HIPCHK(ctx, hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+        te.owned = d;
+        te.t.data = (const float*)d;
+    } else {
+        te.t.data = dev;
+    }
+    ctx->textures.push_back(te);
+    *out = (vpt_texture_t)ctx->textures.size();
+    return VPT_OK;
+}
+
+int vpt_texture_create(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* data, vpt_texture_t* out_tex) {
+    return texture_add(ctx, desc, data, nullptr, out_tex);
+}
+int vpt_texture_create_device(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* device_data, vpt_texture_t* out_tex) {
+    return texture_add(ctx, desc, nullptr, device_data, out_tex);
+}
+int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
+    if (!ctx || tex == 0 || tex > ctx->textures.size() || !ctx->textures[tex - 1].live) return VPT_E_INVALID;
+    TexEntry& t = ctx->textures[tex - 1];
+    if (t.owned) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(t.owned));
+    }
+    t.live = false;
+    t.owned = nullptr;
+    return VPT_OK;
+}
+
+// ---- scene ------------------------------------------------------------------------------------
+int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volumes) {
+    if (!ctx || !volumes || num_volumes <= 0) return VPT_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<DVolume> dv(num_volumes);
+    std::vector<Box> bounds(num_volumes);
+    ctx->any_color = ctx->any_emission = false;
+    for (int i = 0; i < num_volumes; ++i) {
+        const vpt_vdb_info& vi = volumes[i].vdb_info;
+        DVolume& d = dv[i];
+        std::memset(&d, 0, sizeof(d));
+        DTexture t;
+        if (resolve_tex(ctx, vi.density_texture, &t) != 0 || t.channels != 1) {
+            set_error(ctx, "vpt_scene_set_volumes: volume %d has no valid f32 density texture", i);
+            return VPT_E_INVALID;
+        }
+        if (t.width != vi.dim.x || t.height != vi.dim.y || t.depth != vi.dim.z) {
+            set_error(ctx, "vpt_scene_set_volumes: volume %d density texture is %dx%dx%d but vdb_info.dim is %dx%dx%d", i,
+                      t.width, t.height, t.depth, vi.dim.x, vi.dim.y, vi.dim.z);
+            return VPT_E_INVALID;
+        }
+        d.density = t.data;
+        if (vi.has_emission) {
+            if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1 || t.width != vi.dim.x || t.height != vi.dim.y || t.depth != vi.dim.z) {
+                set_error(ctx, "vpt_scene_set_volumes: volume %d has_emission but no matching f32 emission texture", i);
+                return VPT_E_INVALID;
+            }
+            d.emission = t.data;
+            d.has_emission = 1;
+            ctx->any_emission = true;
+        }
+        if (vi.has_color) {
+            if (resolve_tex(ctx, vi.color_texture, &t) != 0 || t.channels != 4 || t.width != vi.dim.x || t.height != vi.dim.y || t.depth != vi.dim.z) {
+                set_error(ctx, "vpt_scene_set_volumes: volume %d has_color but no matching float4 colour texture", i);
+                return VPT_E_INVALID;
+            }
+            d.color = reinterpret_cast<const f4*>(t.data);
+            d.has_color = 1;
+            ctx->any_color = true;
+        }
+        // xform.transpose().inverse(), evaluated once with the operand order of
+        // matrix_math.h:214-253 so it carries the bits of the per-lookup inverse (:987)
+        const mat4 w2i = mat4_inverse(mat4_transpose(load_xform(volumes[i])));
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) d.m[r * 4 + c] = w2i.m[c][r];
+        st3(d.bmin, vi.bmin);
+        d.fdim[0] = (float)vi.dim.x; d.fdim[1] = (float)vi.dim.y; d.fdim[2] = (float)vi.dim.z;
+        d.dim[0] = vi.dim.x; d.dim[1] = vi.dim.y; d.dim[2] = vi.dim.z;
+        bounds[i] = vdb_bounds(volumes[i]);
+    }
+    // root node, bvh_builder.cpp:61-78
+    Box root = {mk3(VPT_M_INF), mk3(-VPT_M_INF)};
+    float max_ext = .0f, min_ext = VPT_M_INF;
+    for (int i = 0; i < num_volumes; ++i) {
+        root.hi = fmax3(root.hi, bounds[i].hi);
+        root.lo = fmin3(root.lo, bounds[i].lo);
+        max_ext = fmax_(max_ext, volumes[i].vdb_info.max_density);
+        min_ext = fmin_(min_ext, volumes[i].vdb_info.min_density);
+    }
+    root.hi += mk3(1.0f);
+    root.lo -= mk3(1.0f);
+    // three levels of children, build_octree_recursive (bvh_kernels.cu:204-246)
+    uint32_t occ[19] = {0};
+    int nonempty[3] = {0, 0, 0};
+    std::vector<uint32_t> offsets(513, 0), indices;
+    for (int a = 0; a < 8; ++a) {
+        const Box b1 = child_box(root, a);
+        bool any1 = false;
+        for (int v = 0; v < num_volumes; ++v) any1 |= overlaps(b1, bounds[v]);
+        if (!any1) continue;
+        occ[0] |= 1u << a;
+        nonempty[0]++;
+        for (int b = 0; b < 8; ++b) {
+            const Box b2 = child_box(b1, b);
+            bool any2 = false;
+            for (int v = 0; v < num_volumes; ++v) any2 |= overlaps(b2, bounds[v]);
+            if (!any2) continue;
+            const int p2 = a * 8 + b;
+            occ[1 + (p2 >> 5)] |= 1u << (p2 & 31);
+            nonempty[1]++;
+            for (int c = 0; c < 8; ++c) {
+                const Box b3 = child_box(b2, c);
+                const int p3 = p2 * 8 + c;
+                int cnt = 0;
+                for (int v = 0; v < num_volumes; ++v)
+                    if (overlaps(b3, bounds[v])) cnt++;
+                offsets[p3 + 1] = (uint32_t)cnt;          // temporarily a count
+                if (cnt == 0) continue;
+                occ[3 + (p3 >> 5)] |= 1u << (p3 & 31);
+                nonempty[2]++;
+            }
+        }
+    }
+    for (int i = 0; i < 512; ++i) offsets[i + 1] += offsets[i];
+    indices.resize(offsets[512] ? offsets[512] : 1);
+    for (int p3 = 0; p3 < 512; ++p3) {
+        if (offsets[p3 + 1] == offsets[p3]) continue;
+        const Box b3 = child_box(child_box(child_box(root, p3 >> 6), (p3 >> 3) & 7), p3 & 7);
+        uint32_t q = offsets[p3];
+        for (int v = 0; v < num_volumes; ++v)
+            if (overlaps(b3, bounds[v])) indices[q++] = (uint32_t)v;
+    }
+    // upload
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_volumes); ctx->d_volumes = nullptr;
+    (void)hipFree(ctx->d_leaf_offsets); ctx->d_leaf_offsets = nullptr;
+    (void)hipFree(ctx->d_leaf_indices); ctx->d_leaf_indices = nullptr;
+    HIPCHK(ctx, hipMalloc(&ctx->d_volumes, sizeof(DVolume) * num_volumes));
+    HIPCHK(ctx, hipMemcpy(ctx->d_volumes, dv.data(), sizeof(DVolume) * num_volumes, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_leaf_offsets, sizeof(uint32_t) * 513));
+    HIPCHK(ctx, hipMemcpy(ctx->d_leaf_offsets, offsets.data(), sizeof(uint32_t) * 513, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_leaf_indices, sizeof(uint32_t) * indices.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_leaf_indices, indices.data(), sizeof(uint32_t) * indices.size(), hipMemcpyHostToDevice));
+    ctx->host_volumes.assign(volumes, volumes + num_volumes);
+    ctx->host_dvolumes = dv;
+    std::memcpy(ctx->occ, occ, sizeof(occ));
+    std::memcpy(ctx->nonempty, nonempty, sizeof(nonempty));
+    ctx->root = root;
+    ctx->max_ext = max_ext;
+    ctx->min_ext = min_ext;
+    ctx->scene_ready = true;
+    return VPT_OK;
+}
+
+int vpt_scene_get_root(vpt_ctx* ctx, vpt_float3* pmin, vpt_float3* pmax, float* max_extinction, float* min_extinction) {
+    if (!ctx) return VPT_E_INVALID;
+    if (!ctx->scene_ready) return VPT_E_NOT_READY;
+    if (pmin) *pmin = tov(ctx->root.lo);
+    if (pmax) *pmax = tov(ctx->root.hi);
+    if (max_extinction) *max_extinction = ctx->max_ext;
+    if (min_extinction) *min_extinction = ctx->min_ext;
+    return VPT_OK;
+}
+
+int vpt_scene_get_octree_stats(vpt_ctx* ctx, int out_nonempty[3]) {
+    if (!ctx || !out_nonempty) return VPT_E_INVALID;
+    if (!ctx->scene_ready) return VPT_E_NOT_READY;
+    for (int i = 0; i < 3; ++i) out_nonempty[i] = ctx->nonempty[i];
+    return VPT_OK;
+}
+
+int vpt_set_counting(vpt_ctx* ctx, int enable) {
+    if (!ctx) return VPT_E_INVALID;
+    ctx->counting = enable != 0;
+    return VPT_OK;
+}
+
+int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof(*out));
+    for (auto& s : ctx->spans) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[s.e1]));
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[s.e0], ctx->ev_pool[s.e1]));
+        if (s.kind == 0) out->trace_ms += ms;
+        else out->resolve_ms += ms;
+    }
+    out->samples = ctx->last_samples;
+    if (ctx->counting) {
+        Counters c;
+        HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        out->samples = c.samples;
+        out->density_lookups = c.density_lookups;
+        out->color_lookups = c.color_lookups;
+        out->emission_lookups = c.emission_lookups;
+        out->tracking_steps = c.tracking_steps;
+        out->skip_steps = c.skip_steps;
+    }
+    return VPT_OK;
+}
+
+// ---- atmosphere packing (indices: enum AF_* in vpt_resolve.hip) -------------------------------------
+static void pack_atmosphere(const vpt_atmosphere_parameters* a, float* f) {
+    std::memset(f, 0, sizeof(float) * 64);
+    f[0] = a->bottom_radius; f[1] = a->top_radius; f[2] = (float)a->use_luminance; f[3] = a->mie_phase_function_g;
+    f[4] = a->sun_angular_radius; f[5] = a->mu_s_min; f[6] = a->exposure;
+    st3(f + 8, a->sky_spectral_radiance_to_luminance);
+    st3(f + 11, a->sun_spectral_radiance_to_luminance);
+    st3(f + 14, a->solar_irradiance);
+    st3(f + 17, a->ground_albedo);
+    st3(f + 20, a->white_point);
+}
+
+// ---- the hot path ---------------------------------------------------------------------------------
+int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* lights, const vpt_sphere* ref_sphere,
+                     const vpt_atmosphere_parameters* atmosphere, const vpt_kernel_params* kp, unsigned int iter_count,
+                     unsigned int iter_stride, void* stream_v) {
+    if (!ctx || !cam || !lights || !ref_sphere || !kp) return VPT_E_INVALID;
+    if (!ctx->scene_ready) {
+        set_error(ctx, "vpt_render: call vpt_scene_set_volumes first");
+        return VPT_E_NOT_READY;
+    }
+    if (iter_stride == 0) iter_stride = 1;
+    if (iter_count == 0) return VPT_OK;
+    const uint32_t W = kp->resolution.x, H = kp->resolution.y;
+    if (W == 0 || H == 0 || !kp->accum_buffer || !kp->blue_noise_buffer || !kp->density_color_texture) {
+        set_error(ctx, "vpt_render: resolution / accum_buffer / blue_noise_buffer / density_color_texture must be set");
+        return VPT_E_INVALID;
+    }
+    if ((unsigned long long)W * H > 0x7fffffffull / 64) {
+        set_error(ctx, "vpt_render: %ux%u exceeds the 32-bit sample index of this build", W, H);
+        return VPT_E_UNSUPPORTED;
+    }
+    if (kp->integrator != 0) {
+        set_error(ctx, "vpt_render: integrator=%d (vol_integrator, render_kernel.cu:1712) is not implemented yet", kp->integrator);
+        return VPT_E_UNSUPPORTED;
+    }
+    if (lights->num_lights > 0 && !lights->light_ptr) return VPT_E_INVALID;
+    if (ctx->any_emission && kp->emission_scale > 0 && !kp->emission_texture) {
+        set_error(ctx, "vpt_render: emission_scale > 0 needs kernel_params.emission_texture");
+        return VPT_E_INVALID;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const uint32_t n_pixels = W * H;
+
+    // ---- resolve-side parameters
+    ResolveParams R;
+    std::memset(&R, 0, sizeof(R));
+    R.width = W; R.height = H; R.n_pixels = n_pixels;
+    R.iter_stride = iter_stride;
+    R.max_interactions = kp->max_interactions;
+    R.accum = reinterpret_cast<float*>(kp->accum_buffer);
+    R.cost = reinterpret_cast<float*>(kp->cost_buffer);
+    R.depth = kp->depth_buffer;
+    R.exposure_scale = kp->exposure_scale;
+    R.lens_radius = cam->lens_radius; R.focus_dist = cam->focus_dist; R.viz_dof = cam->viz_dof;
+    R.environment_type = kp->environment_type;
+    R.integrator = kp->integrator;
+    R.sky_mult = kp->sky_mult;
+    st3(R.sky_color, kp->sky_color);
+    const f3 sun_dir = degree_to_cartesian(kp->azimuth, kp->elevation);
+    st3(R.sun_dir, sun_dir);
+    if (kp->environment_type == 0) {
+        const bool have_luts = atmosphere && atmosphere->transmittance_texture && atmosphere->scattering_texture &&
+                               atmosphere->irradiance_texture && atmosphere->single_mie_scattering_texture;
+        if (have_luts) {
+            if (resolve_tex(ctx, atmosphere->transmittance_texture, &R.transmittance_tex) || resolve_tex(ctx, atmosphere->scattering_texture, &R.scattering_tex) ||
+                resolve_tex(ctx, atmosphere->irradiance_texture, &R.irradiance_tex) || resolve_tex(ctx, atmosphere->single_mie_scattering_texture, &R.single_mie_tex)) {
+                set_error(ctx, "vpt_render: invalid atmosphere texture handle");
+                return VPT_E_INVALID;
+            }
+            if (R.transmittance_tex.channels != 4 || R.scattering_tex.channels != 4 || R.irradiance_tex.channels != 4 || R.single_mie_tex.channels != 4) {
+                set_error(ctx, "vpt_render: atmosphere look-up tables must be float4");
+                return VPT_E_INVALID;
+            }
+            R.has_atmosphere = 1;
+            pack_atmosphere(atmosphere, R.atm_f);
+        } else if (kp->sky_mult != 0.0f) {
+            set_error(ctx, "vpt_render: environment_type=0 with sky_mult != 0 needs the four atmosphere look-up textures");
+            return VPT_E_NOT_READY;
+        }
+    } else {
+        if (resolve_tex(ctx, kp->env_tex, &R.env_tex) || R.env_tex.channels != 4) {
+            set_error(ctx, "vpt_render: environment_type=1 needs a float4 env_tex");
+            return VPT_E_INVALID;
+        }
+    }
+
+    // ---- trace-side parameters
+    TraceParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.width = W; P.height = H; P.n_pixels = n_pixels;
+    P.iter_stride = iter_stride;
+    P.max_interactions = kp->max_interactions;
+    P.render = kp->render ? 1 : 0;
+    P.work_counter = ctx->d_work_counter;
+    P.counters = ctx->counting ? ctx->d_counters : nullptr;
+    static_assert(sizeof(DCamera) == sizeof(vpt_camera), "camera layout");
+    std::memcpy(&P.cam, cam, sizeof(DCamera));
+    st3(P.root_pmin, ctx->root.lo); st3(P.root_pmax, ctx->root.hi);
+    P.max_ext = ctx->max_ext; P.min_ext = ctx->min_ext;
+    std::memcpy(P.occ, ctx->occ, sizeof(P.occ));
+    P.leaf_offsets = ctx->d_leaf_offsets; P.leaf_indices = ctx->d_leaf_indices;
+    P.volumes = ctx->d_volumes; P.num_volumes = (int)ctx->host_dvolumes.size();
+    P.vol0 = ctx->host_dvolumes[0];
+    st3(P.sph_center, ref_sphere->center); P.sph_radius = ref_sphere->radius;
+    st3(P.sph_color, ref_sphere->color); P.sph_roughness = ref_sphere->roughness;
+    P.num_lights = (int)lights->num_lights;
+    P.ray_depth = kp->ray_depth; P.volume_depth = kp->volume_depth;
+    P.phase_g1 = kp->phase_g1;
+    st3(P.albedo, kp->albedo); st3(P.extinction, kp->extinction);
+    P.tr_depth = kp->tr_depth; P.density_mult = kp->density_mult;
+    P.emission_scale = kp->emission_scale; P.emission_pivot = kp->emission_pivot;
+    st3(P.sun_color, kp->sun_color); P.sun_mult = kp->sun_mult;
+    st3(P.sun_dir, sun_dir);
+    P.energy_inject = (float)kp->energy_inject;
+    P.emission_lut = reinterpret_cast<const float*>(kp->emission_texture);
+    P.density_color_lut = reinterpret_cast<const float*>(kp->density_color_texture);
+    P.environment_type = kp->environment_type;
+
+    // lights: the reference keeps them in managed memory (main.cpp:1000); we mirror the
+    // host array into HBM whenever it changes
+    if (lights->num_lights > 0) {
+        static_assert(sizeof(DPointLight) == sizeof(vpt_point_light), "light layout");
+        const size_t n = lights->num_lights;
+        bool changed = ctx->lights_cache.size() != n ||
+                       std::memcmp(ctx->lights_cache.data(), lights->light_ptr, n * sizeof(DPointLight)) != 0;
+        if (changed) {
+            if (ctx->lights_capacity < n) {
+                HIPCHK(ctx, hipStreamSynchronize(stream));
+                (void)hipFree(ctx->d_lights);
+                HIPCHK(ctx, hipMalloc(&ctx->d_lights, n * sizeof(DPointLight)));
+                ctx->lights_capacity = n;
+            }
+            ctx->lights_cache.resize(n);
+            std::memcpy(ctx->lights_cache.data(), lights->light_ptr, n * sizeof(DPointLight));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_lights, ctx->lights_cache.data(), n * sizeof(DPointLight), hipMemcpyHostToDevice, stream));
+        }
+        P.lights = ctx->d_lights;
+    }
+
+    // ---- batch chunking: records for `chunk` iterations stay below ~2 GiB
+    const size_t per_iter = (size_t)n_pixels;
+    size_t chunk = ((size_t)2 << 30) / (per_iter * sizeof(Record));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 64) chunk = 64;
+    if (chunk > iter_count) chunk = iter_count;
+    const char* env_chunk = std::getenv("VPT_BATCH_ITERS");
+    if (env_chunk && std::atoi(env_chunk) > 0) chunk = std::min<size_t>((size_t)std::atoi(env_chunk), iter_count);
+    if (ctx->records_capacity < chunk * per_iter) {
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+        (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
+        hipError_t e = hipMalloc(&ctx->d_records, chunk * per_iter * sizeof(Record));
+        if (e != hipSuccess) {
+            set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", chunk * per_iter * sizeof(Record), hipGetErrorString(e));
+            return VPT_E_NOMEM;
+        }
+        ctx->records_capacity = chunk * per_iter;
+    }
+    if (ctx->bn_capacity < chunk) {
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+        (void)hipFree(ctx->d_bn_table); ctx->d_bn_table = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, chunk * 65536 * sizeof(float2)));
+        ctx->bn_capacity = chunk;
+    }
+    P.records = ctx->d_records;
+    P.blue_noise = ctx->d_bn_table;
+    R.records = ctx->d_records;
+
+    ctx->spans.clear();
+    ctx->ev_used = 0;
+    ctx->last_samples = 0;
+    if (ctx->counting) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), stream));
+
+    const bool multi = P.num_volumes > 1;
+    const bool color = ctx->any_color;
+    const bool emit = ctx->any_emission && kp->emission_scale > 0;
+    const int max_blocks = ctx->num_cus * ctx->blocks_per_cu;
+
+    for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {
+        const unsigned int n = (unsigned int)std::min<size_t>(chunk, iter_count - done);
+        const unsigned int it0 = kp->iteration + done * iter_stride;
+        const bool last = done + n >= iter_count;
+        P.iter_begin = it0; P.iter_count = n;
+        R.iter_begin = it0; R.iter_count = n;
+        R.display = last ? kp->display_buffer : nullptr;
+        R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), stream));
+        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride, stream));
+        const unsigned long long total = (unsigned long long)n_pixels * n;
+        int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
+        if (blocks < 1) blocks = 1;
+        int e0, e1, rc;
+        if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
+        ctx->spans.push_back({e0, e1, 0});
+        if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        HIPCHK(ctx, launch_resolve(R, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
+        ctx->spans.push_back({e0, e1, 1});
+        ctx->last_samples += total;
+    }
+    return VPT_OK;
+}
+
+int vpt_render(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* lights, const vpt_sphere* ref_sphere,
+               const vpt_atmosphere_parameters* atmosphere, const vpt_kernel_params* kernel_params, void* stream) {
+    return vpt_render_batch(ctx, cam, lights, ref_sphere, atmosphere, kernel_params, 1, 1, stream);
+}
+
+int vpt_blue_noise_advance(vpt_ctx* ctx, vpt_float3* blue_noise_buffer, unsigned int steps, void* stream_v) {
+    if (!ctx || !blue_noise_buffer) return VPT_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    if (steps == 0) return VPT_OK;
+    HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(blue_noise_buffer), nullptr, 1, steps, stream));
+    return VPT_OK;
+}
+
+// ---- host-side helpers -----------------------------------------------------------------------------
+void vpt_camera_default(vpt_camera* cam) {            // camera.h:97-106
+    if (!cam) return;
+    std::memset(cam, 0, sizeof(*cam));
+    cam->time0 = .0f; cam->time1 = 1.0f;
+    cam->horizontal.x = -1.0f;
+    cam->vertical.y = 1.0f;
+    cam->u.x = 1.0f; cam->v.y = 1.0f; cam->w.z = 1.0f;
+    cam->lens_radius = 25.0f;
+}
+
+void vpt_camera_update(vpt_camera* cam, vpt_float3 lookfrom_, vpt_float3 lookat_, vpt_float3 vup_, float vfov, float aspect, float aperture) {
+    if (!cam) return;                                 // camera.h:110-129
+    const f3 lookfrom = v3(lookfrom_), lookat = v3(lookat_), vup = v3(vup_);
+    cam->focus_dist = length(lookfrom - lookat);
+    cam->lens_radius = aperture / 2.0f;
+    float theta = vfov * VPT_PI / 180.0f;
+    float half_height = std::tan(theta / 2.0f);                     // tan(float): the float overload
+    float half_width = aspect * half_height;
+    cam->origin = tov(lookfrom);
+    const f3 w = normalize(lookfrom - lookat);
+    const f3 u = normalize(cross(vup, w));
+    const f3 v = cross(w, u);
+    cam->w = tov(w); cam->u = tov(u); cam->v = tov(v);
+    const float fd = cam->focus_dist;
+    cam->lower_left_corner = tov(lookfrom - half_width * fd * u - half_height * fd * v - fd * w);
+    cam->horizontal = tov(2.0f * half_width * fd * u);
+    cam->vertical = tov(2.0f * half_height * fd * v);
+}
+
+void vpt_gpu_vdb_bounds(const vpt_gpu_vdb* vdb, vpt_float3* pmin, vpt_float3* pmax) {
+    if (!vdb) return;
+    Box b = vdb_bounds(*vdb);
+    if (pmin) *pmin = tov(b.lo);
+    if (pmax) *pmax = tov(b.hi);
+}
+
+void vpt_kernel_params_default(vpt_kernel_params* kp) {   // main.cpp:1350-1376 + :1533-1546
+    if (!kp) return;
+    std::memset(kp, 0, sizeof(*kp));
+    kp->render = 1;
+    kp->iteration = 0;
+    kp->max_interactions = 100;
+    kp->exposure_scale = 1.0f;
+    kp->environment_type = 0;
+    kp->ray_depth = 50;
+    kp->volume_depth = 1;
+    kp->phase_g1 = 0.0f; kp->phase_g2 = 0.0f; kp->phase_f = 1.0f;
+    kp->tr_depth = 1.0f;
+    kp->density_mult = 1.0f;
+    kp->albedo = {1.0f, 1.0f, 1.0f};
+    kp->extinction = {1.0f, 1.0f, 1.0f};
+    kp->azimuth = 120.0f;           // GUI value overwrites the struct's 150 every frame (:1420,:1538)
+    kp->elevation = 30.0f;
+    kp->sun_color = {1.0f, 1.0f, 1.0f};
+    kp->sun_mult = 1.0f;
+    kp->energy_inject = 1.0;        // :1543
+    kp->sky_color = {1.0f, 1.0f, 1.0f};
+    kp->sky_mult = 1.0f;
+    kp->env_sample_tex_res = 360;
+    kp->integrator = 0;
+    kp->emission_scale = 0.0f;
+    kp->emission_pivot = 1.0f;
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// vpt_resolve.hip -- second stage of the hot path: per pixel, in iteration order,
+//   environment tail of direct_integrator (render_kernel.cu:1838-1850: Bruneton sky
+//   `sample_atmosphere` :839-895 or lat-long HDRI), NaN/Inf guard (:2263-2264), viz_dof
+//   tint (:2266-2274), running-mean accumulation (:2278-2287) and -- once per batch --
+//   ACES tonemap + gamma + 8-bit pack + raw buffer (:2292-2316).
+// Plus the blue-noise table kernel (golden-ratio advance, :2320-2325).
+//
+// One thread = one pixel; records are 64-byte lines, so a wave reads 4 KiB contiguous
+// per iteration.  Everything here is value-only arithmetic (nothing branches on it that
+// feeds the random walk), so the fast device libm is used.
+#include <hip/hip_runtime.h>
+
+#include "vpt_device.h"
+
+namespace vpt {
+
+// ---- generic sampler (CUDA texture addressing) -----------------------
+VPT_D int tex_addr(int i, int n, int mode, int normalized) {
+    if (mode == 0 && normalized) {            // wrap (only honoured for normalised coordinates)
+        int r = i % n;
+        return r < 0 ? r + n : r;
+    }
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+struct AxisTap { int i0, i1; float a; };
+VPT_D AxisTap axis_tap(float u, int n, int mode, int normalized, int linear) {
+    AxisTap r;
+    float x = normalized ? u * (float)n : u;
+    if (linear) {
+        float xb = x - 0.5f;
+        float fl = floorf(xb);
+        r.a = xb - fl;
+        int i = (int)fl;
+        r.i0 = tex_addr(i, n, mode, normalized);
+        r.i1 = tex_addr(i + 1, n, mode, normalized);
+    } else {
+        int i = (int)floorf(x);
+        r.a = 0.0f;
+        r.i0 = r.i1 = tex_addr(i, n, mode, normalized);
+    }
+    return r;
+}
+VPT_D f4 texel4(const DTexture& t, int x, int y, int z) {
+    size_t idx = ((size_t)z * t.height + y) * t.width + x;
+    if (t.channels == 1) return mk4(t.data[idx], 0.0f, 0.0f, 0.0f);
+    const float4 v = reinterpret_cast<const float4*>(t.data)[idx];
+    return mk4(v.x, v.y, v.z, v.w);
+}
+VPT_D f4 lerp4r(f4 a, f4 b, float t) { return a + (b - a) * t; }
+VPT_D f4 tex2d(const DTexture& t, float u, float v) {
+    AxisTap ax = axis_tap(u, t.width, t.addr[0], t.normalized, t.linear);
+    AxisTap ay = axis_tap(v, t.height, t.addr[1], t.normalized, t.linear);
+    if (!t.linear) return texel4(t, ax.i0, ay.i0, 0);
+    f4 c0 = lerp4r(texel4(t, ax.i0, ay.i0, 0), texel4(t, ax.i1, ay.i0, 0), ax.a);
+    f4 c1 = lerp4r(texel4(t, ax.i0, ay.i1, 0), texel4(t, ax.i1, ay.i1, 0), ax.a);
+    return lerp4r(c0, c1, ay.a);
+}
+VPT_D f4 tex3d(const DTexture& t, float u, float v, float w) {
+    AxisTap ax = axis_tap(u, t.width, t.addr[0], t.normalized, t.linear);
+    AxisTap ay = axis_tap(v, t.height, t.addr[1], t.normalized, t.linear);
+    AxisTap az = axis_tap(w, t.depth, t.addr[2], t.normalized, t.linear);
+    if (!t.linear) return texel4(t, ax.i0, ay.i0, az.i0);
+    f4 c00 = lerp4r(texel4(t, ax.i0, ay.i0, az.i0), texel4(t, ax.i1, ay.i0, az.i0), ax.a);
+    f4 c10 = lerp4r(texel4(t, ax.i0, ay.i1, az.i0), texel4(t, ax.i1, ay.i1, az.i0), ax.a);
+    f4 c01 = lerp4r(texel4(t, ax.i0, ay.i0, az.i1), texel4(t, ax.i1, ay.i0, az.i1), ax.a);
+    f4 c11 = lerp4r(texel4(t, ax.i0, ay.i1, az.i1), texel4(t, ax.i1, ay.i1, az.i1), ax.a);
+    return lerp4r(lerp4r(c00, c10, ay.a), lerp4r(c01, c11, ay.a), az.a);
+}
+
+// ---- Bruneton precomputed atmospheric scattering, look-up side ------------------------------
+// (render_kernel.cu:369-895; published algorithm: E. Bruneton, "Precomputed Atmospheric
+// Scattering", EGSR 2008 + 2017 reference implementation `functions.glsl`.)
+// atm_f[] packing is defined in vpt_host.cpp (pack_atmosphere).
+enum {
+    AF_BOTTOM = 0, AF_TOP = 1, AF_USE_LUM = 2, AF_MIE_G = 3, AF_SUN_ANG = 4, AF_MU_S_MIN = 5, AF_EXPOSURE = 6,
+    AF_SKY_K = 8, AF_SUN_K = 11, AF_SOLAR = 14, AF_GROUND = 17, AF_WHITE = 20,
+};
+struct Sky {
+    const ResolveParams& R;
+    VPT_D float f(int i) const { return R.atm_f[i]; }
+    VPT_D f3 v(int i) const { return mk3(R.atm_f[i], R.atm_f[i + 1], R.atm_f[i + 2]); }
+    VPT_D float bottom() const { return f(AF_BOTTOM); }
+    VPT_D float top() const { return f(AF_TOP); }
+    VPT_D bool lum() const { return f(AF_USE_LUM) != 0.0f; }
+
+    VPT_D static float ClampCosine(float mu) { return clampf(mu, -1.0f, 1.0f); }
+    VPT_D float ClampRadius(float r) const { return clampf(r, bottom(), top()); }
+    VPT_D static float SafeSqrt(float a) { return sqrtf(fmax_(a, 0.0f)); }
+    VPT_D float DistanceToTop(float r, float mu) const {                              // :389
+        float disc = (float)((double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(top() * top()));
+        return fmax_(-r * mu + SafeSqrt(disc), 0.0f);
+    }
+    VPT_D bool HitsGround(float r, float mu) const {                                  // :401
+        return mu < 0.0f && (double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(bottom() * bottom()) >= 0.0;
+    }
+    VPT_D static float UnitToTex(float x, int n) {                                    // :419
+        return (float)(0.5 / (double)n + (double)x * (1.0 - 1.0 / (double)n));
+    }
+    VPT_D f3 TransmittanceToTop(float r, float mu) const {                            // :429-470
+        float H = sqrtf(top() * top() - bottom() * bottom());
+        float rho = SafeSqrt(r * r - bottom() * bottom());
+        float d = DistanceToTop(r, mu);
+        float d_min = top() - r;
+        float d_max = rho + H;
+        float x_mu = (d - d_min) / (d_max - d_min);
+        float x_r = rho / H;
+        return xyz(tex2d(R.transmittance_tex, UnitToTex(x_mu, 256), UnitToTex(x_r, 64)));
+    }
+    VPT_D f3 Transmittance(float r, float mu, float d, bool ground) const {           // :472
+        float r_d = ClampRadius((float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r)));
+        float mu_d = ClampCosine((r * mu + d) / r_d);
+        if (ground) return fmin3(TransmittanceToTop(r_d, -mu_d) / TransmittanceToTop(r, -mu), mk3(1.0f));
+        return fmin3(TransmittanceToTop(r, mu) / TransmittanceToTop(r_d, mu_d), mk3(1.0f));
+    }
+    VPT_D f3 TransmittanceToSun(float r, float mu_s) const {                          // :486
+        float sin_theta_h = bottom() / r;
+        float cos_theta_h = -sqrtf(fmax_(1.0f - sin_theta_h * sin_theta_h, 0.0f));
+        float sa = f(AF_SUN_ANG);
+        return TransmittanceToTop(r, mu_s) * smoothstep(-sin_theta_h * sa, sin_theta_h * sa, mu_s - cos_theta_h);
+    }
+    VPT_D static float RayleighPhase(float nu) {                                      // :508
+        float k = 3.0f / (16.0f * VPT_PI);
+        return k * (1.0f + nu * nu);
+    }
+    VPT_D static float MiePhase(float g, float nu) {                                  // :514
+        float k = 3.0f / (8.0f * VPT_PI) * (1.0f - g * g) / (2.0f + g * g);
+        return k * (1.0f + nu * nu) / powf(1.0f + g * g - 2.0f * g * nu, 1.5f);
+    }
+    VPT_D f4 ScatteringUvwz(float r, float mu, float mu_s, float nu, bool ground) const {   // :520-569
+        float H = sqrtf(top() * top() - bottom() * bottom());
+        float rho = SafeSqrt(r * r - bottom() * bottom());
+        float u_r = UnitToTex(rho / H, 32);
+        float r_mu = r * mu;
+        float disc = r_mu * r_mu - r * r + bottom() * bottom();
+        float u_mu;
+        if (ground) {
+            float d = -r_mu - SafeSqrt(disc);
+            float d_min = r - bottom();
+            float d_max = rho;
+            u_mu = 0.5f - 0.5f * UnitToTex(d_max == d_min ? 0.0f : (d - d_min) / (d_max - d_min), 64);
+        } else {
+            float d = -r_mu + SafeSqrt(disc + H * H);
+            float d_min = top() - r;
+            float d_max = rho + H;
+            u_mu = 0.5f + 0.5f * UnitToTex((d - d_min) / (d_max - d_min), 64);
+        }
+        float d = DistanceToTop(bottom(), mu_s);
+        float d_min = top() - bottom();
+        float d_max = H;
+        float a = (d - d_min) / (d_max - d_min);
+        float A = -2.0f * f(AF_MU_S_MIN) * bottom() / (d_max - d_min);
+        float u_mu_s = UnitToTex(fmax_(1.0f - a / A, 0.0f) / (1.0f + a), 32);
+        float u_nu = (nu + 1.0f) / 2.0f;
+        return mk4(u_nu, u_mu_s, u_mu, u_r);
+    }
+    VPT_D f3 CombinedScattering(float r, float mu, float mu_s, float nu, bool ground, f3& single_mie) const {  // :672
+        f4 uvwz = ScatteringUvwz(r, mu, mu_s, nu, ground);
+        float tex_coord_x = uvwz.x * 7.0f;
+        float tex_x = floorf(tex_coord_x);
+        float lerp = tex_coord_x - tex_x;
+        float u0 = (tex_x + uvwz.y) / 8.0f;
+        float u1 = (tex_x + 1.0f + uvwz.y) / 8.0f;
+        float l0 = 1.0f - lerp;
+        f3 scattering = xyz(tex3d(R.scattering_tex, u0, uvwz.z, uvwz.w) * l0 + tex3d(R.scattering_tex, u1, uvwz.z, uvwz.w) * lerp);
+        single_mie = xyz(tex3d(R.single_mie_tex, u0, uvwz.z, uvwz.w) * l0 + tex3d(R.single_mie_tex, u1, uvwz.z, uvwz.w) * lerp);
+        return scattering;
+    }
+    VPT_D f3 Irradiance(float r, float mu_s) const {                                  // :633-654
+        float x_r = (r - bottom()) / (top() - bottom());
+        float x_mu_s = mu_s * 0.5f + 0.5f;
+        return xyz(tex2d(R.irradiance_tex, UnitToTex(x_mu_s, 256), UnitToTex(x_r, 64)));
+    }
+    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance) const {   // :694 (shadow_length = 0)
+        float r = length(camera);
+        float rmu = dot(camera, view_ray);
+        float dtop = -rmu - sqrtf(rmu * rmu - r * r + top() * top());
+        if (dtop > 0.0f) {
+            camera = camera + view_ray * dtop;
+            r = top();
+            rmu += dtop;
+        } else if (r > top()) {
+            transmittance = mk3(1.0f);
+            return mk3(0.0f);
+        }
+        float mu = rmu / r;
+        float mu_s = dot(camera, sun_direction) / r;
+        float nu = dot(view_ray, sun_direction);
+        bool ground = HitsGround(r, mu);
+        transmittance = ground ? mk3(0.0f) : TransmittanceToTop(r, mu);
+        f3 single_mie;
+        f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        f3 sky = scattering * RayleighPhase(nu) + single_mie * MiePhase(f(AF_MIE_G), nu);
+        if (lum()) sky *= v(AF_SKY_K);
+        return sky;
+    }
+    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance) const {   // :749 (shadow_length = 0)
+        f3 view_ray = normalize(point - camera);
+        float r = length(camera);
+        float rmu = dot(camera, view_ray);
+        float dtop = -rmu - sqrtf(rmu * rmu - r * r + top() * top());
+        if (dtop > 0.0f) {
+            camera = camera + view_ray * dtop;
+            r = top();
+            rmu += dtop;
+        }
+        float mu = rmu / r;
+        float mu_s = dot(camera, sun_direction) / r;
+        float nu = dot(view_ray, sun_direction);
+        float d = length(point - camera);
+        bool ground = HitsGround(r, mu);
+        transmittance = Transmittance(r, mu, d, ground);
+        f3 single_mie;
+        f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        d = fmax_(d, 0.0f);
+        float r_p = ClampRadius((float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r)));
+        float mu_p = (r * mu + d) / r_p;
+        float mu_s_p = (r * mu_s + d * nu) / r_p;
+        f3 single_mie_p;
+        f3 scattering_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, ground, single_mie_p);
+        f3 shadow_t = transmittance;
+        scattering = scattering - shadow_t * scattering_p;
+        single_mie = single_mie - shadow_t * single_mie_p;
+        single_mie = single_mie * smoothstep(0.0f, 0.01f, mu_s);
+        f3 sky = scattering * RayleighPhase(nu) + single_mie * MiePhase(f(AF_MIE_G), nu);
+        if (lum()) sky *= v(AF_SKY_K);
+        return sky;
+    }
+    // sample_atmosphere :839-895
+    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction) const {
+        f3 earth_center = mk3(.0f, -bottom(), .0f);
+        f3 p = ray_pos - earth_center;
+        float p_dot_v = dot(p, ray_dir);
+        float p_dot_p = dot(p, p);
+        float d2 = p_dot_p - p_dot_v * p_dot_v;
+        float dist = -p_dot_v - sqrtf(earth_center.y * earth_center.y - d2);
+        float ground_alpha = 0.0f;
+        f3 ground_radiance = mk3(0.0f);
+        if (dist > 0.0f) {
+            f3 point = ray_pos + ray_dir * dist;
+            f3 normal = normalize(point - earth_center);
+            f3 pt = point - earth_center;
+            float r = length(pt);
+            float mu_s = dot(pt, sun_direction) / r;
+            f3 sky_irr = Irradiance(r, mu_s) * ((1.0f + dot(normal, pt) / r) * 0.5f);     // :818
+            f3 sun_irr = v(AF_SOLAR) * TransmittanceToSun(r, mu_s) * fmax_(dot(normal, sun_direction), 0.0f);
+            if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
+            ground_radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
+            f3 tr;
+            f3 in_scatter = SkyRadianceToPoint(ray_pos - earth_center, pt, sun_direction, tr);
+            ground_radiance = ground_radiance * tr + in_scatter;
+            ground_alpha = 1.0f;
+        }
+        f3 tr_sky;
+        f3 radiance_sky = SkyRadiance(ray_pos - earth_center, ray_dir, sun_direction, tr_sky);
+        float sa = f(AF_SUN_ANG);
+        if (dot(ray_dir, sun_direction) > cosf(sa)) {
+            f3 solar = v(AF_SOLAR) / (VPT_PI * sa * sa);
+            if (lum()) solar *= v(AF_SUN_K);
+            radiance_sky = radiance_sky + tr_sky * solar;
+        }
+        ground_radiance = lerp3(radiance_sky, ground_radiance, ground_alpha);
+        f3 exposure = lum() ? mk3(f(AF_EXPOSURE)) * 1e-5f : mk3(f(AF_EXPOSURE));
+        f3 e = -ground_radiance / v(AF_WHITE) * exposure;
+        f3 om = mk3(1.0f) - mk3(expf(e.x), expf(e.y), expf(e.z));
+        const float g = (float)(1.0 / 2.2);
+        return mk3(powf(om.x, g), powf(om.y, g), powf(om.z, g));
+    }
+};
+
+VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
+    f3 a = v * (v + 0.0245786f) - 0.000090537f;
+    f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return a / b;
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveParams R) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R.n_pixels) return;
+    f3 acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
+    f3 cst = R.cost ? mk3(R.cost[3 * idx], R.cost[3 * idx + 1], R.cost[3 * idx + 2]) : mk3(0.0f);
+    float dep = R.depth ? R.depth[idx] : 0.0f;
+    float tr_last = 0.0f;
+    const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
+    const Sky sky = {R};
+
+    for (uint32_t k = 0; k < R.iter_count; ++k) {
+        const uint32_t iteration = R.iter_begin + k * R.iter_stride;
+        const uint32_t local_it = iteration / R.iter_stride;
+        const float4* src = reinterpret_cast<const float4*>(R.records + ((size_t)k * R.n_pixels + idx));
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        f3 L = mk3(q0.x, q0.y, q0.z);
+        float tr = q0.w;
+        const f3 beta = mk3(q1.x, q1.y, q1.z);
+        float depth = q1.w;
+        const f3 env_pos = mk3(q2.x, q2.y, q2.z);
+        const uint32_t flags = __float_as_uint(q2.w);
+        const f3 dir = mk3(q3.x, q3.y, q3.z);
+        f3 value = L;
+        if (flags & 1u) {
+            if (R.environment_type == 0) {                                              // :1838-1842
+                if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
+            } else {                                                                     // :1843-1850
+                f4 t = tex2d(R.env_tex, atan2f(dir.z, dir.x) * (float)(0.5 / (double)VPT_PI) + 0.5f,
+                             acosf(fmax_(fmin_(dir.y, 1.0f), -1.0f)) * (float)(1.0 / (double)VPT_PI));
+                value += xyz(t) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
+            }
+        }
+        // :2263-2264
+        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
+        if (isnan(tr) || isinf(tr)) tr = 1.0f;
+        // :2266-2274
+        if (R.viz_dof) {
+            float aof = clampf(1 / R.lens_radius, .0f, 3.402823466e+38F);
+            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
+            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
+            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
+        }
+        // :2278-2287 (cost is always BLACK, :2249)
+        if (local_it == 0) {
+            acc = value;
+            cst = mk3(0.0f);
+            dep = depth;
+        } else if (iteration < R.max_interactions) {
+            const float n = (float)(local_it + 1);
+            acc = acc + (value - acc) / n;
+            cst = cst + (mk3(0.0f) - cst) / n;
+            dep = dep + (depth - dep) / n;
+        }
+        tr_last = tr;
+    }
+    R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;
+    if (R.cost) { R.cost[3 * idx] = cst.x; R.cost[3 * idx + 1] = cst.y; R.cost[3 * idx + 2] = cst.z; }
+    if (R.depth) R.depth[idx] = dep;
+
+    if (R.display || R.raw) {
+        // :2292-2316
+        f3 val = mk3(0.59719f * acc.x + 0.35458f * acc.y + 0.04823f * acc.z,
+                     0.07600f * acc.x + 0.90834f * acc.y + 0.01566f * acc.z,
+                     0.02840f * acc.x + 0.13383f * acc.y + 0.83777f * acc.z);
+        val = rtt_and_odt_fit(val);
+        val = mk3(1.60475f * val.x + -0.53108f * val.y + -0.07367f * val.z,
+                  -0.10208f * val.x + 1.10813f * val.y + -0.00605f * val.z,
+                  -0.00327f * val.x + -0.07276f * val.y + 1.07602f * val.z) * R.exposure_scale;
+        const float ig = (float)(1.0 / 2.2);
+        const unsigned int r = (unsigned int)(255.0f * fmin_(powf(fmax_(val.x, 0.0f), ig), 1.0f));
+        const unsigned int g = (unsigned int)(255.0f * fmin_(powf(fmax_(val.y, 0.0f), ig), 1.0f));
+        const unsigned int b = (unsigned int)(255.0f * fmin_(powf(fmax_(val.z, 0.0f), ig), 1.0f));
+        if (R.display) R.display[idx] = 0xff000000u | (r << 16) | (g << 8) | b;
+        if (R.raw) reinterpret_cast<float4*>(R.raw)[idx] = make_float4(val.x, val.y, val.z, tr_last);
+    }
+}
+
+// Blue-noise tables: entry i of iteration k = the caller's buffer advanced k*stride golden-ratio
+// steps (render_kernel.cu:2320-2325, applied between launches; the reference's in-launch
+// read/write race is resolved as "a launch reads the pre-update values").  Also leaves
+// the caller's buffer advanced by count*stride steps, as `count` launches would.
+__global__ __launch_bounds__(256) void blue_noise_kernel(float* bn /* float3[65536] */, float2* table, uint32_t count, uint32_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536u) return;
+    float x = bn[3 * i], y = bn[3 * i + 1], z = bn[3 * i + 2];
+    const float phi = (1.0f + sqrtf(5.0f)) / 2.0f;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (table) table[(size_t)k * 65536u + i] = make_float2(x, y);
+        for (uint32_t s = 0; s < stride; ++s) {
+            x = fmodf(x + phi, 1.0f);
+            y = fmodf(y + phi, 1.0f);
+            z = fmodf(z + phi, 1.0f);
+        }
+    }
+    bn[3 * i] = x; bn[3 * i + 1] = y; bn[3 * i + 2] = z;
+}
+
+hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream) {
+    const int blocks = (int)((R.n_pixels + 255u) / 256u);
+    hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, R);
+    return hipGetLastError();
+}
+hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream) {
+    hipLaunchKernelGGL(blue_noise_kernel, dim3(256), dim3(256), 0, stream, bn, table, count, stride);
+    return hipGetLastError();
+}
+
+}  // namespace vpt

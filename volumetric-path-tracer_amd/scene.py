@@ -1,0 +1,226 @@
+"""Scene assembly above the C ABI: the host-side steps the reference performs between
+loading a grid and launching the kernel, restated so that tests / bench / smoke build the
+exact POD inputs `volume_rt_kernel` receives.
+
+  make_vdb_info       GPU_VDB::loadVDB's info block      (gpu_vdb.cpp:171-212, 413-471)
+  frame_camera        the "F key" framing                (main.cpp:525-543)
+  default_sphere      the reference sphere               (main.cpp:1480-1488)
+  SceneDesc           backend-neutral bundle (numpy + PODs) consumed by HipBinding
+                      (this file) and by tests/oracle_binding.py
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import (AtmosphereParameters, Camera, Float3, GpuVdb, Int3, KernelParams, LightList, PointLight, Sphere)
+from .host import Context, load_library
+
+FLT_EPSILON = np.float32(1.1920929e-07)
+FLT_MAX = np.float32(3.4028235e38)
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def f3(v):
+    return Float3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def make_gpu_vdb(density, bbox_min, bbox_max, matrix, voxel_size, emission=None, color=None):
+    """VDB_INFO + xform exactly as GPU_VDB::loadVDB fills them (texture handles left 0).
+
+    density: float32 [z, y, x] dense copy over the active bbox.  matrix: OpenVDB Mat4d
+    (row-vector convention).  xform[i][j] = matrix(j, i) (gpu_vdb.cpp:81-92).
+    """
+    d = np.ascontiguousarray(density, dtype=np.float32)
+    v = GpuVdb()
+    vi = v.vdb_info
+    vi.voxelsize = float(np.float32(voxel_size))
+    vi.dim = Int3(int(d.shape[2]), int(d.shape[1]), int(d.shape[0]))
+    vi.bmin = f3(np.asarray(bbox_min, dtype=np.float32))
+    vi.bmax = f3(np.asarray(bbox_max, dtype=np.float32))
+    vi.max_density = float(max(np.float32(0.0), d.max()))                       # gpu_vdb.cpp:206
+    vi.min_density = float(min(FLT_MAX, np.maximum(FLT_EPSILON, d).min()))      # gpu_vdb.cpp:207
+    vi.has_color = 1 if color is not None else 0
+    vi.has_emission = 1 if emission is not None else 0
+    m = np.asarray(matrix, dtype=np.float64).astype(np.float32)
+    for i in range(4):
+        for j in range(4):
+            v.xform[i][j] = float(m[j, i])
+    return v
+
+
+def frame_camera(lib, volumes, width, height, fov=30.0, aperture=0.0):
+    """main.cpp:525-543: bbox (seeded with the origin!) of the transformed bmin/bmax corners,
+    lookat = centre, lookfrom = centre + |diag| * (1,1,1)."""
+    bmin = np.zeros(3, np.float32)
+    bmax = np.zeros(3, np.float32)
+    for v in volumes:
+        xf = np.array([[v.xform[c][r] for c in range(4)] for r in range(4)], dtype=np.float32)   # M[r][c] = m[c][r]
+        xt = xf.T                                                                               # xform.transpose()
+        def tp(p):
+            p4 = np.array([p.x, p.y, p.z, 1.0], np.float32)
+            return (xt @ p4)[:3].astype(np.float32)
+        bmin = np.minimum(bmin, tp(v.vdb_info.bmin))
+        bmax = np.maximum(bmax, tp(v.vdb_info.bmax))
+    center = ((bmax + bmin) / np.float32(2)).astype(np.float32)
+    dist = np.float32(np.sqrt(np.sum((bmax - bmin).astype(np.float32) ** 2, dtype=np.float32)))
+    lookfrom = (center + dist).astype(np.float32)
+    cam = Camera()
+    lib.vpt_camera_default(C.byref(cam))
+    lib.vpt_camera_update(C.byref(cam), f3(lookfrom), f3(center), Float3(0, 1, 0), float(fov), float(width) / float(height), float(aperture))
+    return cam, center, dist
+
+
+def default_sphere():
+    s = Sphere()                                  # main.cpp:1480-1488
+    s.center = Float3(0, 1000, 0)
+    s.radius = 1.0
+    s.color = Float3(10.0, 0, 0)
+    s.roughness = 1.0
+    return s
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def blue_noise_from_rgb(rgb):
+    """load_texture_bmp_gpu (fileIO.cpp:460-495): x = R/255, y = B/255, z = G/255."""
+    rgb = rgb.astype(np.float32)
+    out = np.empty((256 * 256, 3), np.float32)
+    flat = rgb.reshape(-1, 3)
+    out[:, 0] = flat[:, 0] / np.float32(255.0)
+    out[:, 1] = flat[:, 2] / np.float32(255.0)
+    out[:, 2] = flat[:, 1] / np.float32(255.0)
+    return out
+
+
+class SceneDesc:
+    """Backend-neutral scene: numpy grids + PODs without texture handles / buffer pointers."""
+
+    def __init__(self):
+        self.volumes = []          # list of (GpuVdb, density[z,y,x], emission or None, color[z,y,x,4] or None)
+        self.camera = None
+        self.lights = []           # list of PointLight
+        self.sphere = default_sphere()
+        self.kp = KernelParams()
+        self.atmosphere = AtmosphereParameters()
+        self.atm_luts = None       # dict transmittance/irradiance/scattering/single_mie numpy float4 arrays
+        self.env_map = None        # numpy [h, w, 4]
+        self.blue_noise = None     # numpy [65536, 3]
+        self.emission_lut = None   # numpy [256, 3]
+        self.density_color_lut = None
+        self.width = 0
+        self.height = 0
+
+
+def dragon_scene(width, height, config="c1", lib=None):
+    """The BASELINE.md configs on assets/dragon.vdb (via the committed golden fixture).
+
+    c1: one point light above the bbox, sun_mult = sky_mult = 0        
+    c2: procedural sun + sky (needs atmosphere LUTs bound by the caller) (row 2)
+    sun: c2 without the sky term (sun NEE only, sky_mult = 0) -- no LUTs needed
+    """
+    lib = lib or load_library()
+    g = load_golden("dragon_dense.npz")
+    luts = load_golden("luts.npz")
+    bn = load_golden("bn0.npz")
+    sd = SceneDesc()
+    sd.width, sd.height = int(width), int(height)
+    vdb = make_gpu_vdb(g["density"], g["bbox_min"], g["bbox_max"], g["matrix"], g["voxel_size"])
+    sd.volumes.append((vdb, np.ascontiguousarray(g["density"], np.float32), None, None))
+    cam, center, dist = frame_camera(lib, [vdb], width, height)
+    sd.camera = cam
+    kp = KernelParams()
+    lib.vpt_kernel_params_default(C.byref(kp))
+    kp.resolution = abi.UInt2(int(width), int(height))
+    kp.max_interactions = 1 << 30
+    if config == "c1":
+        kp.sun_mult = 0.0
+        kp.sky_mult = 0.0
+        pl = PointLight()
+        pl.pos = f3(center + np.array([0, dist, 0], np.float32))
+        pl.color = Float3(1, 1, 1)
+        pl.power = float(np.float32(dist) * np.float32(dist))
+        sd.lights.append(pl)
+    elif config == "sun":
+        kp.sky_mult = 0.0
+    elif config == "c2":
+        pass
+    else:
+        raise ValueError(config)
+    sd.kp = kp
+    sd.blue_noise = blue_noise_from_rgb(bn["rgb"])
+    sd.emission_lut = np.ascontiguousarray(luts["blackbody"], np.float32)
+    sd.density_color_lut = np.ascontiguousarray(luts["density_color"], np.float32)
+    return sd
+
+
+class HipBinding:
+    """Uploads a SceneDesc through the C ABI and owns the torch HBM buffers the reference's
+    main loop would own (accum/raw/cost/depth/display, main.cpp:596-637)."""
+
+    def __init__(self, sd, device=0, ctx=None):
+        import torch
+        self.torch = torch
+        self.sd = sd
+        self.ctx = ctx or Context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        ctx = self.ctx
+        vols = []
+        for vdb, dens, emis, col in sd.volumes:
+            v = GpuVdb.from_buffer_copy(vdb)
+            v.vdb_info.density_texture = ctx.texture(dens, 1)
+            if emis is not None:
+                v.vdb_info.emission_texture = ctx.texture(emis, 1)
+            if col is not None:
+                v.vdb_info.color_texture = ctx.texture(col, 4)
+            vols.append(v)
+        self.volumes = vols
+        ctx.set_volumes(vols)
+        n = sd.width * sd.height
+        t = torch
+        self.accum = t.zeros(n, 3, dtype=t.float32, device=self.dev)
+        self.cost = t.zeros(n, 3, dtype=t.float32, device=self.dev)
+        self.depth = t.zeros(n, dtype=t.float32, device=self.dev)
+        self.raw = t.zeros(n, 4, dtype=t.float32, device=self.dev)
+        self.display = t.zeros(n, dtype=t.int32, device=self.dev)
+        self.blue_noise = t.from_numpy(sd.blue_noise.copy()).to(self.dev)
+        self.emission_lut = t.from_numpy(sd.emission_lut.copy()).to(self.dev)
+        self.density_color_lut = t.from_numpy(sd.density_color_lut.copy()).to(self.dev)
+        kp = KernelParams.from_buffer_copy(sd.kp)
+        kp.accum_buffer = self.accum.data_ptr()
+        kp.cost_buffer = self.cost.data_ptr()
+        kp.depth_buffer = self.depth.data_ptr()
+        kp.raw_buffer = self.raw.data_ptr()
+        kp.display_buffer = self.display.data_ptr()
+        kp.blue_noise_buffer = self.blue_noise.data_ptr()
+        kp.emission_texture = self.emission_lut.data_ptr()
+        kp.density_color_texture = self.density_color_lut.data_ptr()
+        self.kp = kp
+        self.atmosphere = AtmosphereParameters.from_buffer_copy(sd.atmosphere)
+        if sd.atm_luts is not None:
+            L = sd.atm_luts
+            wc = (abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_CLAMP)
+            self.atmosphere.transmittance_texture = ctx.texture(L["transmittance"], 4, address=wc)
+            self.atmosphere.irradiance_texture = ctx.texture(L["irradiance"], 4, address=wc)
+            self.atmosphere.scattering_texture = ctx.texture(L["scattering"], 4)
+            self.atmosphere.single_mie_scattering_texture = ctx.texture(L["single_mie"], 4)
+        if sd.env_map is not None:
+            kp.env_tex = ctx.texture(sd.env_map, 4, address=(abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_CLAMP))
+        self._lights_arr = (PointLight * max(1, len(sd.lights)))(*sd.lights)
+        self.lights = LightList(len(sd.lights), C.cast(self._lights_arr, C.POINTER(PointLight)))
+        # buffers were filled on torch's stream; the ctx renders on its own stream
+        torch.cuda.synchronize(self.dev)
+
+    def render(self, iter_count, iter_stride=1, iteration=None, stream=None):
+        if iteration is not None:
+            self.kp.iteration = int(iteration)
+        self.ctx.render_batch(self.sd.camera, self.lights, self.sd.sphere, self.atmosphere, self.kp, iter_count, iter_stride, stream)
+        self.kp.iteration += int(iter_count) * int(iter_stride)
+
+    def sync(self):
+        self.ctx.sync()
