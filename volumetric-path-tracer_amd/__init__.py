@@ -8,3 +8,4 @@ The directory name contains a hyphen, so it is imported through `__graft_entry__
 from . import abi  # noqa: F401
 from .host import ABI_SYMBOLS, LIB_PATH, Context, VptError, load_library  # noqa: F401
 from . import scene  # noqa: F401
+from . import dist  # noqa: F401
