@@ -308,6 +308,20 @@ typedef struct vpt_render_stats {
 int  vpt_set_counting(vpt_ctx *ctx, int enable);
 int  vpt_get_stats(vpt_ctx *ctx, vpt_render_stats *out);
 
+/* ---- atmosphere (prerequisite of the procedural sky) -----------------------------
+ * vpt_atmosphere_default_model: the scalars atmosphere::atmosphere() + init() + update_model() leave in
+ * atmosphere_parameters with the reference's defaults (constant solar spectrum, ozone on, white
+ * balance on, lambdas 680/550/440 nm, use_luminance NONE) -- source/atmosphere/atmosphere.cpp:698-784,
+ * 1177-1230.  Buffers / texture handles are zeroed.
+ * vpt_atmosphere_precompute: atmosphere::precompute (atmosphere.cpp:888-1116; kernels
+ * atmosphere_kernels.cu:621-752) followed by copy_*_texture (:503-675): allocates any of the nine
+ * scratch buffers that are NULL, fills them, and creates the four look-up textures.
+ * vpt_atmosphere_read_lut: device->host copy of one table (0 transmittance 256x64, 1 irradiance
+ * 256x64, 2 scattering 256x128x32, 3 single Mie 256x128x32; float4 texels). */
+int  vpt_atmosphere_default_model(vpt_atmosphere_parameters *atm);
+int  vpt_atmosphere_precompute(vpt_ctx *ctx, vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
+int  vpt_atmosphere_read_lut(vpt_ctx *ctx, const vpt_atmosphere_parameters *atm, int which, float *host_out, size_t n_floats);
+
 /* ---- host-side helpers restating reference host code the path depends on --------------- */
 /* camera::update_camera, source/gpu_vdb/camera.h:110-129 */
 void vpt_camera_update(vpt_camera *cam, vpt_float3 lookfrom, vpt_float3 lookat, vpt_float3 vup,

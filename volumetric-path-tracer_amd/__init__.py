@@ -9,3 +9,4 @@ from . import abi  # noqa: F401
 from .host import ABI_SYMBOLS, LIB_PATH, Context, VptError, load_library  # noqa: F401
 from . import scene  # noqa: F401
 from . import dist  # noqa: F401
+from . import atmosphere  # noqa: F401

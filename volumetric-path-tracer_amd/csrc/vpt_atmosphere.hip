@@ -1,0 +1,497 @@
+// vpt_atmosphere.hip -- prerequisite of BASELINE config 2: the reference's
+// default sky model and the one-off precomputation of its four look-up tables.
+//
+//   vpt_atmosphere_default_model  = atmosphere::atmosphere() + init() + update_model()
+//                                   (source/atmosphere/atmosphere.cpp:698-784, 1177-1230, 1340-1370)
+//   vpt_atmosphere_precompute     = atmosphere::precompute() + copy_*_texture()
+//                                   (atmosphere.cpp:888-1116, 503-675) driving restatements of the six
+//                                   kernels of source/atmosphere/atmosphere_kernels.cu:621-752
+//
+// Published algorithm: E. Bruneton, F. Neyret, "Precomputed Atmospheric Scattering" (EGSR 2008) and
+// Bruneton's 2017 reference implementation.  The reference's port deviates from it in ways that
+// change the tables, and those are kept because the tables are INPUTS of the hot path:
+//   D1  look-ups during precomputation are nearest-texel reads of the linear buffers
+//       (atmosphere_kernels.cu:157-169, 375-395, 604-616), not filtered fetches;
+//   D2  orders >= 3 of the scattering density read `scattering_buffer` (the previous order's
+//       result already divided by the Rayleigh phase) instead of the delta-multiple-scattering
+//       buffer (:398-408), and GetIrradiance reads `irradiance_buffer` (:604-616);
+//   D3  calculate_indirect_irradiance / calculate_multiple_scattering declare `const int blend` but
+//       the host passes a float4 whose first lane is 0.0f (atmosphere.cpp:1052-1083), so nothing
+//       accumulates: every order OVERWRITES irradiance/scattering.  The final scattering table is
+//       the 4th order alone; single Mie lives in its own table;
+//   D4  mie_extinction is interpolated from the Mie *scattering* spectrum (atmosphere.cpp:728-730).
+// Not timed, not on the parity-critical decision path: plain fp32/fp64 device math.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/vpt_abi.h"
+#include "vpt_math.h"
+
+using namespace vpt;
+
+namespace {
+
+constexpr int TW = VPT_TRANSMITTANCE_W, TH = VPT_TRANSMITTANCE_H;
+constexpr int IW = VPT_IRRADIANCE_W, IH = VPT_IRRADIANCE_H;
+constexpr int S_R = VPT_SCATTERING_R, S_MU = VPT_SCATTERING_MU, S_MU_S = VPT_SCATTERING_MU_S, S_NU = VPT_SCATTERING_NU;
+constexpr int SW = S_NU * S_MU_S, SH = S_MU, SD = S_R;
+
+struct AtmoD {                       // device copy of the scalars + scratch buffers
+    float bottom, top;
+    float sun_angular_radius, mu_s_min, mie_g;
+    f3 solar_irradiance, rayleigh_scattering, mie_scattering, mie_extinction, absorption_extinction, ground_albedo;
+    vpt_density_profile rayleigh_density, mie_density, absorption_density;
+    float4 *delta_irradiance, *delta_rayleigh, *delta_mie, *delta_density, *delta_multiple;
+    float4 *transmittance, *irradiance, *scattering, *single_mie;
+};
+
+VPT_D float ClampCosine(float mu) { return clampf(mu, -1.0f, 1.0f); }
+VPT_D float ClampDistance(float d) { return fmax_(d, 0.0f); }
+VPT_D float ClampRadius(const AtmoD& a, float r) { return clampf(r, a.bottom, a.top); }
+VPT_D float SafeSqrt(float x) { return sqrtf(fmax_(x, 0.0f)); }
+VPT_D float DistTop(const AtmoD& a, float r, float mu) {
+    float disc = (float)((double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(a.top * a.top));
+    return ClampDistance(-r * mu + SafeSqrt(disc));
+}
+VPT_D float DistBottom(const AtmoD& a, float r, float mu) {
+    float disc = (float)((double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(a.bottom * a.bottom));
+    return ClampDistance(-r * mu - SafeSqrt(disc));
+}
+VPT_D bool HitsGround(const AtmoD& a, float r, float mu) {
+    return mu < 0.0f && (double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(a.bottom * a.bottom) >= 0.0;
+}
+VPT_D float LayerDensity(const vpt_density_profile_layer& l, float h) {
+    float d = (float)((double)l.exp_term * exp((double)(l.exp_scale * h))) + l.linear_term * h + l.const_term;
+    return clampf(d, 0.0f, 1.0f);
+}
+VPT_D float ProfileDensity(const vpt_density_profile& p, float h) {
+    return h < p.layers[0].width ? LayerDensity(p.layers[0], h) : LayerDensity(p.layers[1], h);
+}
+VPT_D float UnitToTex(float x, int n) { return (float)(0.5 / (double)n + (double)x * (1.0 - 1.0 / (double)n)); }
+VPT_D float TexToUnit(float u, int n) { return (float)(((double)u - 0.5 / (double)n) / (1.0 - 1.0 / (double)n)); }
+VPT_D float dsqrt3(float d, float r, float mu) {     // sqrt(d*d + 2.0*r*mu*d + r*r) with the reference's promotions
+    return (float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r));
+}
+
+// ---- transmittance (atmosphere_kernels.cu:67-113, 621-632) ------------------------------------
+VPT_D float OpticalLength(const AtmoD& a, const vpt_density_profile& p, float r, float mu) {
+    const int N = 500;
+    float dx = DistTop(a, r, mu) / (float)N;
+    float result = 0.0f;
+    for (int i = 0; i <= N; ++i) {
+        float d_i = (float)i * dx;
+        float r_i = dsqrt3(d_i, r, mu);
+        float y_i = ProfileDensity(p, r_i - a.bottom);
+        float w = (i == 0 || i == N) ? 0.5f : 1.0f;
+        result += y_i * w * dx;
+    }
+    return result;
+}
+VPT_D f3 exp3(f3 v) { return mk3(expf(v.x), expf(v.y), expf(v.z)); }
+VPT_D f3 ComputeTransmittanceToTop(const AtmoD& a, float r, float mu) {
+    return exp3(-(a.rayleigh_scattering * OpticalLength(a, a.rayleigh_density, r, mu) +
+                  a.mie_extinction * OpticalLength(a, a.mie_density, r, mu) +
+                  a.absorption_extinction * OpticalLength(a, a.absorption_density, r, mu)));
+}
+struct uv2 { float x, y; };
+VPT_D uv2 TransmittanceUv(const AtmoD& a, float r, float mu) {
+    float H = sqrtf(a.top * a.top - a.bottom * a.bottom);
+    float rho = SafeSqrt(r * r - a.bottom * a.bottom);
+    float d = DistTop(a, r, mu);
+    float d_min = a.top - r, d_max = rho + H;
+    uv2 o = {UnitToTex((d - d_min) / (d_max - d_min), TW), UnitToTex(rho / H, TH)};
+    return o;
+}
+VPT_D f3 ld4(const float4* b, int i) { float4 v = b[i]; return mk3(v.x, v.y, v.z); }
+// nearest-texel read (D1), :157-169
+VPT_D f3 TransmittanceToTop(const AtmoD& a, float r, float mu) {
+    uv2 uv = TransmittanceUv(a, r, mu);
+    int x = (int)floorf(uv.x * TW), y = (int)floorf(uv.y * TH);
+    int idx = min(max(y * TW + x, 0), TW * TH - 1);
+    return ld4(a.transmittance, idx);
+}
+VPT_D f3 Transmittance(const AtmoD& a, float r, float mu, float d, bool ground) {
+    float r_d = ClampRadius(a, dsqrt3(d, r, mu));
+    float mu_d = ClampCosine((r * mu + d) / r_d);
+    if (ground) return fmin3(TransmittanceToTop(a, r_d, -mu_d) / TransmittanceToTop(a, r, -mu), mk3(1.0f));
+    return fmin3(TransmittanceToTop(a, r, mu) / TransmittanceToTop(a, r_d, mu_d), mk3(1.0f));
+}
+VPT_D f3 TransmittanceToSun(const AtmoD& a, float r, float mu_s) {
+    float sh = a.bottom / r;
+    float ch = -sqrtf(fmax_(1.0f - sh * sh, 0.0f));
+    return TransmittanceToTop(a, r, mu_s) * smoothstep(-sh * a.sun_angular_radius, sh * a.sun_angular_radius, mu_s - ch);
+}
+
+__global__ void k_transmittance(AtmoD a) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= TW || y >= TH) return;
+    float u = ((float)x + 0.5f) / (float)TW, v = ((float)y + 0.5f) / (float)TH;
+    // GetRMuFromTransmittanceTextureUv :124-140
+    float x_mu = TexToUnit(u, TW), x_r = TexToUnit(v, TH);
+    float H = sqrtf(a.top * a.top - a.bottom * a.bottom);
+    float rho = H * x_r;
+    float r = sqrtf(rho * rho + a.bottom * a.bottom);
+    float d_min = a.top - r, d_max = rho + H;
+    float d = d_min + x_mu * (d_max - d_min);
+    float mu = d == 0.0f ? 1.0f : (float)(((double)(H * H) - (double)(rho * rho) - (double)(d * d)) / (2.0 * (double)r * (double)d));
+    mu = ClampCosine(mu);
+    f3 t = ComputeTransmittanceToTop(a, r, mu);
+    a.transmittance[y * TW + x] = make_float4(t.x, t.y, t.z, 0.0f);
+}
+
+// ---- irradiance --------------------------------------------------------------------------------
+VPT_D void IrradianceRMuS(const AtmoD& a, int x, int y, float& r, float& mu_s) {     // :588-594
+    float u = ((float)x + 0.5f) / (float)IW, v = ((float)y + 0.5f) / (float)IH;
+    float x_mu_s = TexToUnit(u, IW), x_r = TexToUnit(v, IH);
+    r = a.bottom + x_r * (a.top - a.bottom);
+    mu_s = ClampCosine(2.0f * x_mu_s - 1.0f);
+}
+VPT_D f3 GetIrradiance(const AtmoD& a, float r, float mu_s) {                         // :604-616 (D1, D2)
+    float x_r = (r - a.bottom) / (a.top - a.bottom);
+    float x_mu_s = mu_s * 0.5f + 0.5f;
+    float u = UnitToTex(x_mu_s, IW), v = UnitToTex(x_r, IH);
+    int x = (int)floorf(u * IW), y = (int)floorf(v * IH);
+    int idx = min(max(y * IW + x, 0), IW * IH - 1);
+    return ld4(a.irradiance, idx);
+}
+__global__ void k_direct_irradiance(AtmoD a, int blend) {                              // :634-652
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= IW || y >= IH) return;
+    const int idx = y * IW + x;
+    float r, mu_s;
+    IrradianceRMuS(a, x, y, r, mu_s);
+    if (!blend) a.irradiance[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 tmp = a.irradiance[idx];
+    // ComputeDirectIrradiance :561-570
+    float alpha_s = a.sun_angular_radius;
+    float avg = mu_s < -alpha_s ? 0.0f : (mu_s > alpha_s ? mu_s : (mu_s + alpha_s) * (mu_s + alpha_s) / (4.0f * alpha_s));
+    f3 e = a.solar_irradiance * TransmittanceToTop(a, r, mu_s) * avg;
+    a.delta_irradiance[idx] = make_float4(e.x, e.y, e.z, 0.0f);
+    if (blend) {
+        float4 c = a.irradiance[idx];
+        a.irradiance[idx] = make_float4(c.x + tmp.x, c.y + tmp.y, c.z + tmp.z, c.w + tmp.w);
+    }
+}
+
+// ---- scattering --------------------------------------------------------------------------------
+VPT_D float RayleighPhase(float nu) { float k = 3.0f / (16.0f * VPT_PI); return k * (1.0f + nu * nu); }
+VPT_D float MiePhase(float g, float nu) {
+    float k = 3.0f / (8.0f * VPT_PI) * (1.0f - g * g) / (2.0f + g * g);
+    return k * (1.0f + nu * nu) / powf(1.0f + g * g - 2.0f * g * nu, 1.5f);
+}
+// GetScatteringTextureUvwzFromRMuMuSNu :255-304
+VPT_D f4 ScatteringUvwz(const AtmoD& a, float r, float mu, float mu_s, float nu, bool ground) {
+    float H = sqrtf(a.top * a.top - a.bottom * a.bottom);
+    float rho = SafeSqrt(r * r - a.bottom * a.bottom);
+    float u_r = UnitToTex(rho / H, S_R);
+    float r_mu = r * mu;
+    float disc = r_mu * r_mu - r * r + a.bottom * a.bottom;
+    float u_mu;
+    if (ground) {
+        float d = -r_mu - SafeSqrt(disc);
+        float d_min = r - a.bottom, d_max = rho;
+        u_mu = 0.5f - 0.5f * UnitToTex(d_max == d_min ? 0.0f : (d - d_min) / (d_max - d_min), S_MU / 2);
+    } else {
+        float d = -r_mu + SafeSqrt(disc + H * H);
+        float d_min = a.top - r, d_max = rho + H;
+        u_mu = 0.5f + 0.5f * UnitToTex((d - d_min) / (d_max - d_min), S_MU / 2);
+    }
+    float d = DistTop(a, a.bottom, mu_s);
+    float d_min = a.top - a.bottom, d_max = H;
+    float aa = (d - d_min) / (d_max - d_min);
+    float A = -2.0f * a.mu_s_min * a.bottom / (d_max - d_min);
+    float u_mu_s = UnitToTex(fmax_(1.0f - aa / A, 0.0f) / (1.0f + aa), S_MU_S);
+    float u_nu = (nu + 1.0f) / 2.0f;
+    return mk4(u_nu, u_mu_s, u_mu, u_r);
+}
+// GetRMuMuSNuFromScatteringTextureFragCoord :306-354
+VPT_D void ScatteringParams(const AtmoD& a, int x, int y, int z, float& r, float& mu, float& mu_s, float& nu, bool& ground) {
+    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f, fz = (float)z + 0.5f;
+    float frag_nu = floorf(fx / (float)S_MU_S);
+    float frag_mu_s = fmodf(fx, (float)S_MU_S);
+    const float u_nu = frag_nu / (float)(S_NU - 1), u_mu_s = frag_mu_s / (float)S_MU_S, u_mu = fy / (float)S_MU, u_r = fz / (float)S_R;
+    float H = sqrtf(a.top * a.top - a.bottom * a.bottom);
+    float rho = H * TexToUnit(u_r, S_R);
+    r = sqrtf(rho * rho + a.bottom * a.bottom);
+    if (u_mu < 0.5f) {
+        float d_min = r - a.bottom, d_max = rho;
+        float d = d_min + (d_max - d_min) * TexToUnit(1.0f - 2.0f * u_mu, S_MU / 2);
+        mu = d == 0.0f ? -1.0f : ClampCosine((float)(-((double)(rho * rho) + (double)(d * d)) / (2.0 * (double)r * (double)d)));
+        ground = true;
+    } else {
+        float d_min = a.top - r, d_max = rho + H;
+        float d = d_min + (d_max - d_min) * TexToUnit(2.0f * u_mu - 1.0f, S_MU / 2);
+        mu = d == 0.0f ? 1.0f : ClampCosine((float)(((double)(H * H) - (double)(rho * rho) - (double)(d * d)) / (2.0 * (double)r * (double)d)));
+        ground = false;
+    }
+    float x_mu_s = TexToUnit(u_mu_s, S_MU_S);
+    float d_min = a.top - a.bottom, d_max = H;
+    float A = -2.0f * a.mu_s_min * a.bottom / (d_max - d_min);
+    float aa = (A - x_mu_s * A) / (1.0f + x_mu_s * A);
+    float d = d_min + fmin_(aa, A) * (d_max - d_min);
+    mu_s = d == 0.0f ? 1.0f : ClampCosine((float)(((double)(H * H) - (double)(d * d)) / (2.0 * (double)a.bottom * (double)d)));
+    nu = ClampCosine(u_nu * 2.0f - 1.0f);
+    float s = sqrtf((1.0f - mu * mu) * (1.0f - mu_s * mu_s));
+    nu = clampf(nu, mu * mu_s - s, mu * mu_s + s);
+}
+// GetScattering(buffer) :375-395 -- truncating nearest-texel reads of two nu slices (D1)
+VPT_D f3 GetScatteringBuf(const AtmoD& a, const float4* buf, float r, float mu, float mu_s, float nu, bool ground) {
+    f4 uvwz = ScatteringUvwz(a, r, mu, mu_s, nu, ground);
+    float tcx = uvwz.x * (float)(S_NU - 1);
+    float tx = floorf(tcx);
+    float lerp = tcx - tx;
+    float u0 = (tx + uvwz.y) / (float)S_NU, u1 = (tx + 1.0f + uvwz.y) / (float)S_NU;
+    int x0 = (int)(u0 * SW), x1 = (int)(u1 * SW), yy = (int)(uvwz.z * SH), zz = (int)(uvwz.w * SD);
+    const int n = SW * SH * SD;
+    int i0 = min(max(x0 + SW * (yy + SH * zz), 0), n - 1);
+    int i1 = min(max(x1 + SW * (yy + SH * zz), 0), n - 1);     // x1 may step past the row when nu == 1 (weight 0 then)
+    return ld4(buf, i0) * (1.0f - lerp) + ld4(buf, i1) * lerp;
+}
+VPT_D f3 GetScatteringOrder(const AtmoD& a, float r, float mu, float mu_s, float nu, bool ground, int order) {   // :398-408 (D2)
+    if (order == 1) {
+        f3 ray = GetScatteringBuf(a, a.delta_rayleigh, r, mu, mu_s, nu, ground);
+        f3 mie = GetScatteringBuf(a, a.delta_mie, r, mu, mu_s, nu, ground);
+        return ray * RayleighPhase(nu) + mie * MiePhase(a.mie_g, nu);
+    }
+    return GetScatteringBuf(a, a.scattering, r, mu, mu_s, nu, ground);
+}
+
+__global__ void k_single_scattering(AtmoD a) {                                        // :172-243, 719-752 (blend = 0)
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z * blockDim.z + threadIdx.z;
+    if (x >= SW || y >= SH || z >= SD) return;
+    const int idx = x + SW * (y + SH * z);
+    float r, mu, mu_s, nu;
+    bool ground;
+    ScatteringParams(a, x, y, z, r, mu, mu_s, nu, ground);
+    const int N = 50;
+    float dx = (ground ? DistBottom(a, r, mu) : DistTop(a, r, mu)) / (float)N;
+    f3 ray_sum = mk3(0.0f), mie_sum = mk3(0.0f);
+    for (int i = 0; i <= N; ++i) {
+        float d_i = (float)i * dx;
+        float r_d = ClampRadius(a, dsqrt3(d_i, r, mu));
+        float mu_s_d = ClampCosine((r * mu_s + d_i * nu) / r_d);
+        f3 tr = Transmittance(a, r, mu, d_i, ground) * TransmittanceToSun(a, r_d, mu_s_d);
+        float w = (i == 0 || i == N) ? 0.5f : 1.0f;
+        ray_sum += tr * ProfileDensity(a.rayleigh_density, r_d - a.bottom) * w;
+        mie_sum += tr * ProfileDensity(a.mie_density, r_d - a.bottom) * w;
+    }
+    f3 ray = ray_sum * dx * a.solar_irradiance * a.rayleigh_scattering;
+    f3 mie = mie_sum * dx * a.solar_irradiance * a.mie_scattering;
+    a.delta_rayleigh[idx] = make_float4(ray.x, ray.y, ray.z, 1.0f);
+    a.delta_mie[idx] = make_float4(mie.x, mie.y, mie.z, 1.0f);
+    a.scattering[idx] = make_float4(ray.x, ray.y, ray.z, mie.x);          // luminance_from_radiance = identity
+    a.single_mie[idx] = make_float4(mie.x, mie.y, mie.z, 1.0f);
+}
+
+__global__ void k_scattering_density(AtmoD a, int order) {                            // :412-480, 702-717
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z * blockDim.z + threadIdx.z;
+    if (x >= SW || y >= SH || z >= SD) return;
+    const int idx = x + SW * (y + SH * z);
+    float r, mu, mu_s, nu;
+    bool ground_unused;
+    ScatteringParams(a, x, y, z, r, mu, mu_s, nu, ground_unused);
+    const f3 zenith = mk3(0.0f, 0.0f, 1.0f);
+    const f3 omega = mk3(sqrtf(1.0f - mu * mu), 0.0f, mu);
+    const float sun_x = omega.x == 0.0f ? 0.0f : (nu - mu * mu_s) / omega.x;
+    const float sun_y = sqrtf(fmax_(1.0f - sun_x * sun_x - mu_s * mu_s, 0.0f));
+    const f3 omega_s = mk3(sun_x, sun_y, mu_s);
+    const int N = 16;
+    const float dphi = VPT_PI / (float)N, dtheta = VPT_PI / (float)N;
+    const float ray_dens = ProfileDensity(a.rayleigh_density, r - a.bottom);
+    const float mie_dens = ProfileDensity(a.mie_density, r - a.bottom);
+    f3 acc = mk3(0.0f);
+    for (int l = 0; l < N; ++l) {
+        float theta = ((float)l + 0.5f) * dtheta;
+        float ct = cosf(theta), st = sinf(theta);
+        bool g = HitsGround(a, r, ct);
+        float dist_ground = 0.0f;
+        f3 tr_ground = mk3(0.0f), albedo = mk3(0.0f);
+        if (g) {
+            dist_ground = DistBottom(a, r, ct);
+            tr_ground = Transmittance(a, r, ct, dist_ground, true);
+            albedo = a.ground_albedo;
+        }
+        for (int m = 0; m < 2 * N; ++m) {
+            float phi = ((float)m + 0.5f) * dphi;
+            f3 wi = mk3(cosf(phi) * st, sinf(phi) * st, ct);
+            float dw = dtheta * dphi * sinf(theta);
+            float nu1 = dot(omega_s, wi);
+            f3 incident = GetScatteringOrder(a, r, wi.z, mu_s, nu1, g, order - 1);
+            f3 gn = normalize(zenith * r + wi * dist_ground);
+            f3 girr = GetIrradiance(a, a.bottom, dot(gn, omega_s));
+            incident += tr_ground * albedo * (1.0f / VPT_PI) * girr;
+            float nu2 = dot(omega, wi);
+            acc += incident * (a.rayleigh_scattering * ray_dens * RayleighPhase(nu2) + a.mie_scattering * mie_dens * MiePhase(a.mie_g, nu2)) * dw;
+        }
+    }
+    a.delta_density[idx] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+}
+
+__global__ void k_indirect_irradiance(AtmoD a, int order) {                           // :572-586, 654-674 (blend = 0, D3)
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= IW || y >= IH) return;
+    const int idx = y * IW + x;
+    float r, mu_s;
+    IrradianceRMuS(a, x, y, r, mu_s);
+    const int N = 32;
+    const float dphi = VPT_PI / (float)N, dtheta = VPT_PI / (float)N;
+    f3 result = mk3(0.0f);
+    const f3 omega_s = mk3(sqrtf(1.0f - mu_s * mu_s), 0.0f, mu_s);
+    for (int j = 0; j < N / 2; ++j) {
+        float theta = ((float)j + 0.5f) * dtheta;
+        for (int i = 0; i < 2 * N; ++i) {
+            float phi = ((float)i + 0.5f) * dphi;
+            f3 w = mk3(cosf(phi) * sinf(theta), sinf(phi) * sinf(theta), cosf(theta));
+            float dw = dtheta * dphi * sinf(theta);
+            float nu = dot(w, omega_s);
+            result += GetScatteringOrder(a, r, w.z, mu_s, nu, false, order - 1) * w.z * dw;
+        }
+    }
+    a.irradiance[idx] = make_float4(result.x, result.y, result.z, 0.0f);
+    a.delta_irradiance[idx] = a.irradiance[idx];
+}
+
+__global__ void k_multiple_scattering(AtmoD a) {                                      // :482-517, 676-700 (blend = 0, D3)
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z * blockDim.z + threadIdx.z;
+    if (x >= SW || y >= SH || z >= SD) return;
+    const int idx = x + SW * (y + SH * z);
+    float r, mu, mu_s, nu;
+    bool ground;
+    ScatteringParams(a, x, y, z, r, mu, mu_s, nu, ground);
+    const int N = 50;
+    float dx = (ground ? DistBottom(a, r, mu) : DistTop(a, r, mu)) / (float)N;
+    f3 sum = mk3(0.0f);
+    for (int i = 0; i <= N; ++i) {
+        float d_i = (float)i * dx;
+        float r_i = ClampRadius(a, dsqrt3(d_i, r, mu));
+        float mu_i = ClampCosine((r * mu + d_i) / r_i);
+        float mu_s_i = ClampCosine((r * mu_s + d_i * nu) / r_i);
+        f3 v = GetScatteringBuf(a, a.delta_density, r_i, mu_i, mu_s_i, nu, ground) * Transmittance(a, r, mu, d_i, ground) * dx;
+        float w = (i == 0 || i == N) ? 0.5f : 1.0f;
+        sum += v * w;
+    }
+    a.delta_multiple[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    f3 s = sum / RayleighPhase(nu);
+    a.scattering[idx] = make_float4(s.x, s.y, s.z, 0.0f);
+}
+
+}  // namespace
+
+extern "C" {
+
+// implemented in vpt_host.hip
+int vpt_texture_create_device(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* device_data, vpt_texture_t* out_tex);
+void* vpt_stream(vpt_ctx* ctx);
+
+int vpt_atmosphere_default_model(vpt_atmosphere_parameters* p) {
+    if (!p) return VPT_E_INVALID;
+    std::memset(p, 0, sizeof(*p));
+    const double lambdas[3] = {680.0, 550.0, 440.0};                 // kDefaultLambdas, atmosphere.h:97
+    // spectra are tabulated every 10 nm; the three wavelengths sit on table nodes, so
+    // interpolate() (atmosphere.cpp:170-186) returns the node values
+    const double kRayleigh = 1.24062e-6, kMieAngstromBeta = 5.328e-3, kMieScaleHeight = 1200.0, kMieAlbedo = 0.9;
+    const double mie = kMieAngstromBeta / kMieScaleHeight;           // Angstrom alpha = 0
+    float ray[3], mies[3];
+    for (int c = 0; c < 3; ++c) {
+        ray[c] = (float)(kRayleigh * std::pow(lambdas[c] * 1e-3, -4.0));
+        mies[c] = (float)(mie * kMieAlbedo);
+    }
+    // derived from the reference's data tables by tests/golden/make_atmosphere_defaults.py
+    p->sky_spectral_radiance_to_luminance = {105360.115f, 70390.3573f, 65952.7079f};
+    p->sun_spectral_radiance_to_luminance = {87936.9249f, 69212.9057f, 66345.1742f};
+    p->white_point = {1.18038779f, 0.929053056f, 0.890559155f};
+    p->absorption_extinction = {6.497166e-07f, 1.8809e-06f, 8.501668e-08f};
+    p->solar_irradiance = {1.5f, 1.5f, 1.5f};                        // kConstantSolarIrradiance
+    p->sun_angular_radius = (float)(0.00935 / 2.0);
+    p->bottom_radius = 6360000.0f;                                   // length unit = 1 m (atmosphere.cpp:1224-1228)
+    p->top_radius = 6420000.0f;
+    p->rayleigh_density.layers[1] = {0.0f, 1.0f, (float)(-1.0 / 8000.0), 0.0f, 0.0f};
+    p->rayleigh_scattering = {ray[0], ray[1], ray[2]};
+    p->mie_density.layers[1] = {0.0f, 1.0f, (float)(-1.0 / 1200.0), 0.0f, 0.0f};
+    p->mie_scattering = {mies[0], mies[1], mies[2]};
+    p->mie_extinction = {mies[0], mies[1], mies[2]};                 // D4: interpolated from m_mie_scattering
+    p->mie_phase_function_g = 0.8f;
+    p->absorption_density.layers[0] = {25000.0f, 0.0f, 0.0f, (float)(1.0 / 15000.0), (float)(-2.0 / 3.0)};
+    p->absorption_density.layers[1] = {0.0f, 0.0f, 0.0f, (float)(-1.0 / 15000.0), (float)(8.0 / 3.0)};
+    p->ground_albedo = {0.01f, 0.01f, 0.01f};
+    p->mu_s_min = (float)std::cos(120.0 / 180.0 * (double)VPT_PI);   // M_PI is the float macro in the reference
+    p->use_luminance = 0;
+    p->exposure = 1.0f;
+    p->angle = 0.0f;
+    return VPT_OK;
+}
+
+static int alloc4(float4** p, size_t n) {
+    if (*p) return 0;
+    return hipMalloc(p, n * sizeof(float4)) == hipSuccess ? 0 : -1;
+}
+
+int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int num_scattering_orders, void* stream_v) {
+    if (!ctx || !p) return VPT_E_INVALID;
+    if (num_scattering_orders < 1) num_scattering_orders = 4;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
+    const size_t n2t = (size_t)TW * TH, n2i = (size_t)IW * IH, n3 = (size_t)SW * SH * SD;
+    float4** bufs2t[] = {(float4**)&p->transmittance_buffer};
+    float4** bufs2i[] = {(float4**)&p->delta_irradience_buffer, (float4**)&p->irradiance_buffer};
+    float4** bufs3[] = {(float4**)&p->delta_rayleigh_scattering_buffer, (float4**)&p->delta_mie_scattering_buffer,
+                        (float4**)&p->delta_scattering_density_buffer, (float4**)&p->delta_multiple_scattering_buffer,
+                        (float4**)&p->scattering_buffer, (float4**)&p->optional_mie_single_scattering_buffer};
+    for (auto b : bufs2t) if (alloc4(b, n2t)) return VPT_E_NOMEM;
+    for (auto b : bufs2i) if (alloc4(b, n2i)) return VPT_E_NOMEM;
+    for (auto b : bufs3) if (alloc4(b, n3)) return VPT_E_NOMEM;
+    AtmoD a;
+    a.bottom = p->bottom_radius; a.top = p->top_radius;
+    a.sun_angular_radius = p->sun_angular_radius; a.mu_s_min = p->mu_s_min; a.mie_g = p->mie_phase_function_g;
+    auto v = [](vpt_float3 q) { return mk3(q.x, q.y, q.z); };
+    a.solar_irradiance = v(p->solar_irradiance); a.rayleigh_scattering = v(p->rayleigh_scattering);
+    a.mie_scattering = v(p->mie_scattering); a.mie_extinction = v(p->mie_extinction);
+    a.absorption_extinction = v(p->absorption_extinction); a.ground_albedo = v(p->ground_albedo);
+    a.rayleigh_density = p->rayleigh_density; a.mie_density = p->mie_density; a.absorption_density = p->absorption_density;
+    a.delta_irradiance = (float4*)p->delta_irradience_buffer; a.delta_rayleigh = (float4*)p->delta_rayleigh_scattering_buffer;
+    a.delta_mie = (float4*)p->delta_mie_scattering_buffer; a.delta_density = (float4*)p->delta_scattering_density_buffer;
+    a.delta_multiple = (float4*)p->delta_multiple_scattering_buffer; a.transmittance = (float4*)p->transmittance_buffer;
+    a.irradiance = (float4*)p->irradiance_buffer; a.scattering = (float4*)p->scattering_buffer;
+    a.single_mie = (float4*)p->optional_mie_single_scattering_buffer;
+
+    const dim3 b2(16, 16, 1), b3(32, 4, 2);
+    const dim3 gt((TW + 15) / 16, (TH + 15) / 16, 1), gi((IW + 15) / 16, (IH + 15) / 16, 1);
+    const dim3 gs((SW + 31) / 32, (SH + 3) / 4, (SD + 1) / 2);
+    hipLaunchKernelGGL(k_transmittance, gt, b2, 0, stream, a);
+    hipLaunchKernelGGL(k_direct_irradiance, gi, b2, 0, stream, a, 0);
+    hipLaunchKernelGGL(k_single_scattering, gs, b3, 0, stream, a);
+    for (int order = 2; order <= num_scattering_orders; ++order) {
+        hipLaunchKernelGGL(k_scattering_density, gs, b3, 0, stream, a, order);
+        hipLaunchKernelGGL(k_indirect_irradiance, gi, b2, 0, stream, a, order);
+        hipLaunchKernelGGL(k_multiple_scattering, gs, b3, 0, stream, a);
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VPT_E_HIP;
+    // copy_*_texture (atmosphere.cpp:503-675): float4, normalised, linear; 2-D wrap/clamp, 3-D clamp
+    vpt_texture_desc d2 = {TW, TH, 1, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_WRAP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
+    vpt_texture_desc d3 = {SW, SH, SD, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_CLAMP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
+    int rc;
+    if ((rc = vpt_texture_create_device(ctx, &d2, (const float*)p->transmittance_buffer, &p->transmittance_texture))) return rc;
+    d2.width = IW; d2.height = IH;
+    if ((rc = vpt_texture_create_device(ctx, &d2, (const float*)p->irradiance_buffer, &p->irradiance_texture))) return rc;
+    if ((rc = vpt_texture_create_device(ctx, &d3, (const float*)p->scattering_buffer, &p->scattering_texture))) return rc;
+    if ((rc = vpt_texture_create_device(ctx, &d3, (const float*)p->optional_mie_single_scattering_buffer, &p->single_mie_scattering_texture))) return rc;
+    return VPT_OK;
+}
+
+int vpt_atmosphere_read_lut(vpt_ctx* ctx, const vpt_atmosphere_parameters* p, int which, float* host_out, size_t n_floats) {
+    if (!ctx || !p || !host_out) return VPT_E_INVALID;
+    const void* src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: src = p->transmittance_buffer; n = (size_t)TW * TH * 4; break;
+        case 1: src = p->irradiance_buffer; n = (size_t)IW * IH * 4; break;
+        case 2: src = p->scattering_buffer; n = (size_t)SW * SH * SD * 4; break;
+        case 3: src = p->optional_mie_single_scattering_buffer; n = (size_t)SW * SH * SD * 4; break;
+        default: return VPT_E_INVALID;
+    }
+    if (!src || n_floats != n) return VPT_E_INVALID;
+    return hipMemcpy(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? VPT_OK : VPT_E_HIP;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "vpt_scene_set_volumes", "vpt_scene_get_root", "vpt_scene_get_octree_stats",
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
+    "vpt_atmosphere_default_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
     "vpt_camera_update", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_kernel_params_default",
 ]
 
@@ -76,6 +77,9 @@ def load_library(path=None):
     lib.vpt_gpu_vdb_bounds.restype = None
     lib.vpt_kernel_params_default.argtypes = [C.POINTER(KernelParams)]
     lib.vpt_kernel_params_default.restype = None
+    lib.vpt_atmosphere_default_model.argtypes = [C.POINTER(AtmosphereParameters)]
+    lib.vpt_atmosphere_precompute.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp]
+    lib.vpt_atmosphere_read_lut.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp, C.c_size_t]
     # test probes (include/vpt_testhooks.h)
     lib.vpt_test_host_math.argtypes = [C.c_int, vp, vp, C.c_int]
     lib.vpt_test_device_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
