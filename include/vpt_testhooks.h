@@ -20,6 +20,9 @@ int vpt_test_device_math(vpt_ctx *ctx, int op, const float *in, float *out, int 
 /* n raw Philox draws of rocRAND's philox4x32_10 from rocrand_init(seed, 0, offset), mapped
  * with the curand_uniform formula -- the stream the trace kernel consumes */
 int vpt_test_device_uniform_stream(vpt_ctx *ctx, unsigned long long seed, unsigned long long offset, int n, float *out);
+/* n draws of the product's own Philox stream (csrc/vpt_rng.h) for key = seed, offset, drawn
+ * through the trace kernel's refill-point protocol */
+int vpt_test_device_product_stream(vpt_ctx *ctx, unsigned int key, unsigned int offset, int n, float *out);
 #ifdef __cplusplus
 }
 #endif

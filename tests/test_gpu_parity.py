@@ -64,6 +64,10 @@ def test_device_math_and_rng_match_oracle_bitwise(pkg, orc):
         assert lib.vpt_test_device_uniform_stream(ctx.h, seed, off, 41, a.ctypes.data_as(C.c_void_p)) == 0
         orc.orc_curand_uniform_stream(seed, off, 41, b.ctypes.data_as(C.c_void_p))
         np.testing.assert_array_equal(a, b)
+        # the product's own Philox (csrc/vpt_rng.h) through its refill-point protocol
+        c = np.zeros(41, np.float32)
+        assert lib.vpt_test_device_product_stream(ctx.h, seed, off, 41, c.ctypes.data_as(C.c_void_p)) == 0
+        np.testing.assert_array_equal(c, b)
     ctx.close()
 
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvpt_hip.so")
 SOURCES = ["vpt_host.hip", "vpt_trace.hip", "vpt_resolve.hip", "vpt_atmosphere.hip", "vpt_testhooks.hip"]
-HEADERS = ["vpt_math.h", "vpt_device.h", os.path.join("..", "..", "include", "vpt_abi.h"),
+HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", os.path.join("..", "..", "include", "vpt_abi.h"),
            os.path.join("..", "..", "include", "vpt_testhooks.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -82,10 +82,16 @@ struct TraceParams {
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;
     int render;
-    uint32_t* work_counter;          // next sample id (0 .. n_pixels*iter_count)
+    uint32_t regen_min;              // refill when at least this many lanes of a wave are idle
+    uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
+    uint32_t* work_counter;          // next queue entry the tracer hands out
+    uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
+    uint32_t* queue_tail;            // raygen's append cursor
+    const uint32_t* queue_count;     // == queue_tail, read by the tracer
     Record* records;                 // [iter_count][n_pixels]
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
+    const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera
     DCamera cam;
     // octree / scene

@@ -22,6 +22,8 @@
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
+hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
+hipError_t launch_tail(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream);
 }  // namespace vpt
@@ -48,6 +50,8 @@ struct vpt_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu = 4;
+    uint32_t regen_min = 24;
+    uint32_t trans_min = 48;
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene
@@ -67,7 +71,9 @@ struct vpt_ctx {
     size_t records_capacity = 0;           // in records
     float2* d_bn_table = nullptr;
     size_t bn_capacity = 0;                // in iterations
-    uint32_t* d_work_counter = nullptr;
+    uint32_t* d_work_counter = nullptr;     // [0] tracer's dequeue cursor, [1] raygen's queue tail
+    uint32_t* d_queue = nullptr;
+    float* d_vdc = nullptr;
     Counters* d_counters = nullptr;
     DPointLight* d_lights = nullptr;
     size_t lights_capacity = 0;
@@ -157,6 +163,20 @@ f3 degree_to_cartesian(float azimuth, float elevation) {
     return normalize(mk3(x, y, z));
 }
 
+// vanDerCorput(n, base) for n = 0..100 with the float operations of camera.h:49-62
+void vdc_table(int base, float* out) {
+    for (int n0 = 0; n0 <= 100; ++n0) {
+        int n = n0;
+        float rand_int = 0, denom = 1, invBase = 1.f / base;
+        while (n) {
+            denom *= base;
+            rand_int += (n % base) / denom;
+            n = (int)(n * invBase);
+        }
+        out[n0] = rand_int;
+    }
+}
+
 int resolve_tex(vpt_ctx* ctx, vpt_texture_t h, DTexture* out) {
     if (h == 0 || h > ctx->textures.size() || !ctx->textures[h - 1].live) return VPT_E_INVALID;
     *out = ctx->textures[h - 1].t;
@@ -214,10 +234,21 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->num_cus = prop.multiProcessorCount;
     const char* bpc = std::getenv("VPT_BLOCKS_PER_CU");
     if (bpc && std::atoi(bpc) > 0) ctx->blocks_per_cu = std::atoi(bpc);
+    const char* rgm = std::getenv("VPT_REGEN_MIN");
+    if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = (uint32_t)std::atoi(rgm);
+    const char* trm = std::getenv("VPT_TRANS_MIN");
+    if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = (uint32_t)std::atoi(trm);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
     HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
+    {
+        float tab[2 * 101];
+        vdc_table(2, tab);
+        vdc_table(3, tab + 101);
+        HIPCHK(ctx, hipMalloc(&ctx->d_vdc, sizeof(tab)));
+        HIPCHK(ctx, hipMemcpy(ctx->d_vdc, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
     *out_ctx = ctx;
     return VPT_OK;
 }
@@ -232,6 +263,8 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
     (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);
     (void)hipFree(ctx->d_counters);
@@ -513,6 +546,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         set_error(ctx, "vpt_render: %ux%u exceeds the 32-bit sample index of this build", W, H);
         return VPT_E_UNSUPPORTED;
     }
+    if ((unsigned long long)kp->iteration + (unsigned long long)iter_count * iter_stride >= (1ull << 20)) {
+        set_error(ctx, "vpt_render: iteration index beyond 2^20 exceeds the 32-bit Philox counter word of this build");
+        return VPT_E_UNSUPPORTED;
+    }
     if (kp->integrator != 0) {
         set_error(ctx, "vpt_render: integrator=%d (vol_integrator, render_kernel.cu:1712) is not implemented yet", kp->integrator);
         return VPT_E_UNSUPPORTED;
@@ -552,8 +589,13 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 set_error(ctx, "vpt_render: invalid atmosphere texture handle");
                 return VPT_E_INVALID;
             }
-            if (R.transmittance_tex.channels != 4 || R.scattering_tex.channels != 4 || R.irradiance_tex.channels != 4 || R.single_mie_tex.channels != 4) {
-                set_error(ctx, "vpt_render: atmosphere look-up tables must be float4");
+            auto lut_ok = [](const DTexture& t, int w, int h, int d) {
+                return t.channels == 4 && t.width == w && t.height == h && t.depth == d && t.linear && t.normalized;
+            };
+            if (!lut_ok(R.transmittance_tex, VPT_TRANSMITTANCE_W, VPT_TRANSMITTANCE_H, 1) || !lut_ok(R.irradiance_tex, VPT_IRRADIANCE_W, VPT_IRRADIANCE_H, 1) ||
+                !lut_ok(R.scattering_tex, VPT_SCATTERING_NU * VPT_SCATTERING_MU_S, VPT_SCATTERING_MU, VPT_SCATTERING_R) ||
+                !lut_ok(R.single_mie_tex, VPT_SCATTERING_NU * VPT_SCATTERING_MU_S, VPT_SCATTERING_MU, VPT_SCATTERING_R)) {
+                set_error(ctx, "vpt_render: atmosphere look-up tables must be float4, linear, normalised, 256x64 / 256x64 / 256x128x32 / 256x128x32 (constants.h:50-62)");
                 return VPT_E_INVALID;
             }
             R.has_atmosphere = 1;
@@ -576,8 +618,11 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.iter_stride = iter_stride;
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;
+    P.regen_min = ctx->regen_min;
+    P.trans_min = ctx->trans_min;
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
+    P.vdc_tables = ctx->d_vdc;
     static_assert(sizeof(DCamera) == sizeof(vpt_camera), "camera layout");
     std::memcpy(&P.cam, cam, sizeof(DCamera));
     st3(P.root_pmin, ctx->root.lo); st3(P.root_pmax, ctx->root.hi);
@@ -633,7 +678,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (ctx->records_capacity < chunk * per_iter) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
+        (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
         hipError_t e = hipMalloc(&ctx->d_records, chunk * per_iter * sizeof(Record));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, chunk * per_iter * sizeof(uint32_t));
         if (e != hipSuccess) {
             set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", chunk * per_iter * sizeof(Record), hipGetErrorString(e));
             return VPT_E_NOMEM;
@@ -647,6 +694,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         ctx->bn_capacity = chunk;
     }
     P.records = ctx->d_records;
+    P.queue = ctx->d_queue;
+    P.queue_tail = ctx->d_work_counter + 1;
+    P.queue_count = ctx->d_work_counter + 1;
     P.blue_noise = ctx->d_bn_table;
     R.records = ctx->d_records;
 
@@ -668,7 +718,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         R.iter_begin = it0; R.iter_count = n;
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 2 * sizeof(uint32_t), stream));
         HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride, stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
@@ -676,11 +726,13 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         int e0, e1, rc;
         if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
         ctx->spans.push_back({e0, e1, 0});
         if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        HIPCHK(ctx, launch_tail(R, stream));
         HIPCHK(ctx, launch_resolve(R, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
         ctx->spans.push_back({e0, e1, 1});

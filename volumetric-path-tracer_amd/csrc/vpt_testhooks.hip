@@ -6,6 +6,7 @@
 
 #include "../../include/vpt_testhooks.h"
 #include "vpt_math.h"
+#include "vpt_rng.h"
 
 using namespace vpt;
 
@@ -31,9 +32,33 @@ __global__ void uniform_kernel(unsigned long long seed, unsigned long long offse
     rocrand_init(seed, 0, offset, &s);
     for (int i = 0; i < n; ++i) out[i] = (float)rocrand(&s) * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
 }
+// the product's own generator (csrc/vpt_rng.h), drawn through its refill-point protocol:
+// top_up, then at most two draws, as the trace kernel does
+__global__ void product_stream_kernel(unsigned int key, unsigned int offset, int n, float* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng g;
+    rng_init(g, key, offset);
+    unsigned int draws = 0;
+    int i = 0;
+    while (i < n) {
+        rng_top_up(g, key);
+        out[i++] = rnd(g, draws);
+        if (i < n && ((i * 2654435761u) >> 31)) out[i++] = rnd(g, draws);    // irregular 1-or-2 draw pattern
+    }
+}
 }  // namespace
 
 extern "C" {
+
+int vpt_test_device_product_stream(vpt_ctx* ctx, unsigned int key, unsigned int offset, int n, float* out) {
+    if (!ctx || !out || n <= 0) return VPT_E_INVALID;
+    float* d_out = nullptr;
+    if (hipMalloc(&d_out, sizeof(float) * n) != hipSuccess) return VPT_E_NOMEM;
+    hipLaunchKernelGGL(product_stream_kernel, dim3(1), dim3(64), 0, 0, key, offset, n, d_out);
+    hipError_t e = hipMemcpy(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost);
+    hipFree(d_out);
+    return e == hipSuccess ? VPT_OK : VPT_E_HIP;
+}
 
 int vpt_test_host_math(int op, const float* in, float* out, int n) {
     if (!in || !out || n < 0) return VPT_E_INVALID;

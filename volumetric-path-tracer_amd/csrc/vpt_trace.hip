@@ -11,60 +11,65 @@
 //
 // How it is organised (nothing like the reference's one-thread-per-pixel megakernel):
 //   * persistent waves; every lane runs a path STATE MACHINE whose heavy state is "do
-//     one tracking step".  All walk kinds (delta tracking for the depth pass and the
-//     integrator, ratio tracking for shadow rays, emission marching) share one step body
-//     (octree point location -> empty-node push | exponential step -> density look-up),
-//     so a wave executes the step body with lanes in different paths, bounces and walk
-//     kinds side by side -- divergence is confined to the short transition code;
-//   * lanes whose path ended are compacted with a wave ballot (v_mbcnt prefix) and
-//     refilled from a global sample counter with ONE atomic per wave; refill is batched
-//     (>= REGEN_MIN idle lanes) so ray generation runs with many lanes;
+//     one tracking step".  All walk kinds (delta tracking, ratio tracking for shadow rays,
+//     emission marching) share one step body (octree point location -> empty-node push |
+//     exponential step -> density look-up), so a wave executes the step body with lanes in
+//     different paths, bounces and walk kinds side by side -- divergence is confined to the
+//     short transition code, whose states are laid out in successor order so that a chain
+//     of transitions completes in one pass;
+//   * ray generation is its own kernel (raygen_kernel): one thread per pixel-sample at full
+//     lane utilisation; primary rays that miss both the volume box and the sphere are final
+//     there and never enter the tracer, the others are COMPACTED into a work queue with a wave
+//     ballot + one atomic per wave;
+//   * lanes whose path ended are refilled from that queue (popcount prefix over the idle
+//     ballot, ONE atomic per wave); a refill is a 64-byte record load, so it is cheap enough
+//     to run whenever >= regen_min lanes are idle;
+//   * the depth pass and the integrator's first delta-tracking walk replay the same Philox
+//     stream from the same ray (rng by value, :1860 vs :1761), so they are walked ONCE; the
+//     only state the replay would change, Alpha (:1670), is re-accumulated from a per-lane
+//     LDS history of the looked-up densities (exact; falls back to a real replay if the
+//     history overflows);
+//   * Philox4x32-10 blocks are generated at two fixed points per loop iteration (not at
+//     every draw site): each lane keeps one block plus one carried-over word, enough for
+//     the <= 2 draws any state consumes between refill points;
 //   * the Philox counter, not the schedule, defines a sample: results are bit-identical
-//     for any grid size / refill order.
+//     for any grid size / refill order;
 //   * octree occupancy bits sit in LDS; node boxes are re-derived by halving.
 #include <hip/hip_runtime.h>
-#include <rocrand/rocrand_philox4x32_10.h>
 
 #include "vpt_device.h"
+#include "vpt_rng.h"
 
 namespace vpt {
-
-#ifndef VPT_REGEN_MIN
-#define VPT_REGEN_MIN 16
-#endif
 
 enum : uint32_t {
     PH_IDLE = 0,
     // walking phases
-    PH_W_DEPTH = 1,   // delta tracking, depth pass
+    PH_W_FIRST = 1,   // delta tracking: depth pass + first integrator walk, fused
     PH_W_TRACK = 2,   // delta tracking, integrator
     PH_W_SUN = 3,     // ratio tracking towards the sun
     PH_W_PL = 4,      // ratio tracking towards a point light
     PH_W_SPH = 5,     // ratio tracking after the sphere bounce
     PH_W_EMIT = 6,    // emission march
     PH_W_LAST = 6,
-    // transition phases
+    // transition phases, in successor order
     PH_T_FIRST = 16,
-    PH_T_DEPTH_DONE = 16,
-    PH_T_OUTER_TOP = 17,
+    PH_T_FIRST_DONE = 16,
+    PH_T_REPLAY = 17,       // history overflow: restart the integrator from the primary ray
     PH_T_TRACK_DONE = 18,
     PH_T_SUN_DONE = 19,
-    PH_T_PL_NEXT = 20,
-    PH_T_PL_DONE = 21,
+    PH_T_PL_DONE = 20,
+    PH_T_PL_NEXT = 21,
     PH_T_EMIT_CHECK = 22,
     PH_T_EMIT_DONE = 23,
-    PH_T_OUTER_SECOND = 24,
-    PH_T_SPH_DONE = 25,
-    PH_T_FINISH = 26,
+    PH_T_SPH_DONE = 24,
+    PH_T_OUTER_SECOND = 25,
+    PH_T_OUTER_TOP = 26,
+    PH_T_FINISH = 27,
 };
 
-typedef rocrand_state_philox4x32_10 Rng;
-
-// curand_uniform: x * 2^-32 + 2^-33, (0, 1]   (camera.h:45-46)
-VPT_D float rnd(Rng& s, uint32_t& draws) {
-    ++draws;
-    return (float)rocrand(&s) * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
-}
+#define VPT_HIST_CAP 12
+#define VPT_CHUNK 256        // queue entries a wave claims per global atomic
 
 VPT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
@@ -283,7 +288,7 @@ VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want
     }
 }
 
-// coordinate_system :92-102, spherical_direction :104-115, sample_hg :306-325
+// coordinate_system :92-102, spherical_direction :104-115, sample_hg :306-325 (2 draws)
 VPT_D void sample_hg(f3& wo, Rng& rng, uint32_t& draws, float g) {
     float cos_theta;
     if (fabsf(g) < VPT_EPS) cos_theta = 1 - 2 * rnd(rng, draws);
@@ -308,25 +313,115 @@ VPT_D float henyey_greenstein(float cos_theta, float g) {   // light.h:55-64 (pi
     return VPT_PI_4 * (1 - g * g) / (denominator * sqrtf(denominator));
 }
 
-// vanDerCorput (camera.h:49-62)
-VPT_D float van_der_corput(Rng& rng, uint32_t& draws, int base) {
-    int n = (int)(rnd(rng, draws) * 100);
-    float rand_int = 0, denom = 1, invBase = 1.f / base;
-    while (n) {
-        denom *= base;
-        rand_int += (n % base) / denom;
-        n = (int)(n * invBase);
-    }
-    return rand_int;
+// vanDerCorput (camera.h:49-62): n = int(rand*100) is in [0, 100], so the radical inverse is read
+// from a 101-entry table that the host fills with the reference's own float loop (vdc_table in
+// vpt_host.hip) -- same bits, no data-dependent loop on the device.
+VPT_D float van_der_corput(const float* table, Rng& rng, uint32_t key, uint32_t& draws) {
+    int n = (int)(rnd_simple(rng, key, draws) * 100);
+    return table[n];
 }
 
+// ---- stage 0: ray generation + compaction ----------------------------------------------------------
+// volume_rt_kernel :2227-2251 for every pixel-sample of the batch, one thread each (full lanes).
+// Writes into records[slot] either
+//   * the FINAL path record, when the sample is not rendered (:2254) or its primary ray hits
+//     neither the volume box nor the sphere (get_closest_object == 0: every iteration of
+//     direct_integrator's loop is then a no-op and depth = 0), or
+//   * a 64-byte RAY record {org0, t_hit | dir0, obj | philox block | counter, word, depth} and the
+//     slot index into the work queue (wave-ballot compaction, one atomic per wave).
+#define VPT_RAYGEN_ROWS 64        // pixel rows per raygen block (block = 64 x 4 threads, 16 passes)
+template <bool COUNT>
+__global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
+    // grid: (ceil(W/64), ceil(H/64), iterations); a block sweeps a 64x64 pixel tile in 16 passes and
+    // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
+    __shared__ uint32_t s_q[64 * VPT_RAYGEN_ROWS];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0 && threadIdx.y == 0) s_n = 0;
+    __syncthreads();
+    const int x = (int)(blockIdx.x * 64u + threadIdx.x);
+    const uint32_t kiter = blockIdx.z;
+    const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+    const int lane = __lane_id();
+    const bool rendered = iteration < P.max_interactions && P.render;
+    uint32_t n_final = 0;
+    for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
+        const int y = (int)(blockIdx.y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
+        bool enqueue = false;
+        uint32_t s = 0;
+        if (x < (int)P.width && y < (int)P.height) {
+            const uint32_t pixel = (uint32_t)y * P.width + (uint32_t)x;
+            s = kiter * P.n_pixels + pixel;
+            Rng rng;
+            rng_init(rng, pixel, iteration * 4096u);
+            uint32_t draws = 0;
+            const float2 bn = P.blue_noise[(size_t)kiter * 65536 + (y % 256) * 256 + (x % 256)];
+            const float u = (float)(x + bn.x) / (float)P.width;
+            const float v = (float)(y + bn.y) / (float)P.height;
+            // camera::get_ray, camera.h:131-136
+            f3 pd;
+            do {
+                float a = van_der_corput(P.vdc_tables, rng, pixel, draws);
+                float b = van_der_corput(P.vdc_tables + 101, rng, pixel, draws);
+                pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
+            } while (dot(pd, pd) >= 1.0f);
+            const f3 rdk = P.cam.lens_radius * pd;
+            const f3 offset = ld3(P.cam.u) * rdk.x + ld3(P.cam.v) * rdk.y;
+            (void)rnd_simple(rng, pixel, draws);                          // the `time` draw
+            const f3 org0 = ld3(P.cam.origin) + offset;
+            const f3 B = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - ld3(P.cam.origin) - offset;
+            const f3 dir0 = normalize(B);
+            float4* dst = reinterpret_cast<float4*>(P.records + s);
+            int obj = 0;
+            float t_hit = 0.0f;
+            if (rendered) obj = closest_object(P, org0, dir0, rcp3(dir0), t_hit);
+            if (obj == 0) {
+                // final: L = 0 (or WHITE when not rendering, :2248), beta = 1 (0), tr = 0, depth = 0
+                const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
+                dst[0] = make_float4(l, l, l, 0.0f);
+                dst[1] = make_float4(b, b, b, 0.0f);
+                dst[2] = make_float4(org0.x, org0.y, org0.z, __uint_as_float(rendered ? 1u : 0u));
+                dst[3] = make_float4(dir0.x, dir0.y, dir0.z, 0.0f);
+                n_final++;
+            } else {
+                // :1883-1888: sphere first -> depth is the distance to it
+                const float depth = (obj == 2) ? length(org0 - (org0 + dir0 * t_hit)) : 0.0f;
+                dst[0] = make_float4(org0.x, org0.y, org0.z, t_hit);
+                dst[1] = make_float4(dir0.x, dir0.y, dir0.z, __uint_as_float((uint32_t)obj));
+                dst[2] = make_float4(__uint_as_float(rng.o0), __uint_as_float(rng.o1), __uint_as_float(rng.o2), __uint_as_float(rng.o3));
+                dst[3] = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), depth, 0.0f);
+                enqueue = true;
+            }
+        }
+        const unsigned long long m = __ballot(enqueue);
+        if (m != 0ull) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));      // LDS atomic
+            base = __shfl(base, leader);
+            if (enqueue) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = s;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    const uint32_t tid = threadIdx.y * 64u + threadIdx.x;
+    if (tid == 0 && n) s_base = atomicAdd(P.queue_tail, n);
+    __syncthreads();
+    const uint32_t gbase = s_base;
+    for (uint32_t i = tid; i < n; i += 256u) P.queue[gbase + i] = s_q[i];
+    if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
+}
+
+#ifndef VPT_TRACE_WAVES_PER_EU
+#define VPT_TRACE_WAVES_PER_EU 2
+#endif
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
+    __shared__ float s_hist[VPT_HIST_CAP * 256];      // [entry][thread]: densities seen by the fused first walk
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
 
-    const uint32_t total = P.n_pixels * P.iter_count;
+    const uint32_t total = *P.queue_count;          // rays that entered the volume box / hit the sphere
     const int lane = __lane_id();
     const f3 root_lo = ld3(P.root_pmin), root_hi = ld3(P.root_pmax);
     const f3 sun_dir = ld3(P.sun_dir);
@@ -334,12 +429,15 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
     const float inv_dm = 1.0f / P.density_mult;             // :1646
     const float sigma_c = P.min_ext;                        // :1164
     const float sigma_r_inv = 1.0f / (P.max_ext - sigma_c); // :1165
+    const uint32_t regen_min = P.regen_min;
+    const uint32_t trans_min = P.trans_min;
 
     // ---- lane state -------------------------------------------------------------------
     uint32_t phase = PH_IDLE;
     uint32_t pixel = 0, kiter = 0;
     Rng rng;
-    uint32_t draws = 0;            // draws since the last (re)init of rng
+    rng.c0 = rng.o0 = rng.o1 = rng.o2 = rng.o3 = rng.idx = rng.carry = rng.has_carry = 0u;
+    uint32_t draws = 0;            // draws since the stream origin of this sample (offset iteration*4096)
     uint32_t cam_draws = 0;        // draws consumed by camera::get_ray
     f3 pos = mk3(0.0f), dir = mk3(0.0f), inv = mk3(0.0f);      // current walk ray
     f3 ppos = mk3(0.0f), pdir = mk3(0.0f);                      // path ray parked during shadow / emission walks
@@ -352,82 +450,79 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
     float depth = 0.0f;
     f3 wgt = mk3(1.0f);            // return value of sample()
     int rd = 0, vd = 0, budget = 0, light_index = 0;
+    uint32_t n_hist = 0;
     bool mi = false, geo = false, obj2 = false;
+    int gco_obj = -1;              // cached get_closest_object result for the current (pos, dir), -1 = stale
+    float gco_t = 0.0f;
     float sph_factor = 0.0f;
     uint32_t n_d = 0, n_c = 0, n_e = 0, n_steps = 0, n_skips = 0;
     bool more = true;
+    uint32_t chunk_next = 0, chunk_end = 0;
 
     for (;;) {
-        // ==== refill idle lanes ============================================================
+        // ==== refill idle lanes from the compacted ray queue ===================================
+        // The wave owns a chunk [chunk_next, chunk_end) of queue entries at a time, so the global
+        // dequeue counter sees one atomic per VPT_CHUNK rays.
         const unsigned long long idle = __ballot(phase == PH_IDLE);
         if (idle != 0ull) {
             const unsigned long long active = __ballot(1);
-            const int n_idle = __popcll(idle);
-            if (!more && idle == active) break;
-            if (more && (n_idle >= VPT_REGEN_MIN || idle == active)) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
+                const int leader = __ffsll((long long)active) - 1;
                 uint32_t base = 0;
-                if (lane == __ffsll((long long)active) - 1) base = atomicAdd(P.work_counter, (uint32_t)n_idle);
-                base = __shfl(base, __ffsll((long long)active) - 1);
-                if (base + (uint32_t)n_idle >= total) more = false;
+                if (lane == leader) base = atomicAdd(P.work_counter, (uint32_t)VPT_CHUNK);
+                base = __shfl(base, leader);
+                chunk_next = min(base, total);
+                chunk_end = min(base + (uint32_t)VPT_CHUNK, total);
+                if (chunk_end == total) more = false;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            if (avail == 0u && !more && idle == active) break;
+            if (avail != 0u && (n_idle >= regen_min || idle == active)) {
+                const uint32_t first = chunk_next;
+                chunk_next += min(n_idle, avail);
                 if (phase == PH_IDLE) {
                     const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-                    const uint32_t s = base + rank;
-                    if (s < total) {
-                        // ---- ray generation, volume_rt_kernel :2227-2251 ------------------
-                        kiter = s / P.n_pixels;
-                        pixel = s - kiter * P.n_pixels;
+                    if (rank < avail) {
+                        const uint32_t slot = P.queue[first + rank];
+                        kiter = slot / P.n_pixels;
+                        pixel = slot - kiter * P.n_pixels;
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
-                        const int y = (int)(pixel / P.width);
-                        const int x = (int)(pixel - (uint32_t)y * P.width);
-                        rocrand_init(pixel, 0, (unsigned long long)iteration * 4096ull, &rng);
-                        draws = 0;
-                        const float2 bn = P.blue_noise[(size_t)kiter * 65536 + (y % 256) * 256 + (x % 256)];
-                        const float u = (float)(x + bn.x) / (float)P.width;
-                        const float v = (float)(y + bn.y) / (float)P.height;
-                        // camera::get_ray, camera.h:131-136
-                        f3 pd;
-                        do {
-                            float a = van_der_corput(rng, draws, 2);
-                            float b = van_der_corput(rng, draws, 3);
-                            pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
-                        } while (dot(pd, pd) >= 1.0f);
-                        const f3 rdk = P.cam.lens_radius * pd;
-                        const f3 offset = ld3(P.cam.u) * rdk.x + ld3(P.cam.v) * rdk.y;
-                        (void)rnd(rng, draws);                          // the `time` draw
+                        const float4* src = reinterpret_cast<const float4*>(P.records + slot);
+                        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                        org0 = mk3(q0.x, q0.y, q0.z);
+                        gco_t = q0.w;
+                        dir0 = mk3(q1.x, q1.y, q1.z);
+                        gco_obj = (int)__float_as_uint(q1.w);
+                        rng.o0 = __float_as_uint(q2.x); rng.o1 = __float_as_uint(q2.y);
+                        rng.o2 = __float_as_uint(q2.z); rng.o3 = __float_as_uint(q2.w);
+                        rng.c0 = __float_as_uint(q3.x);
+                        rng.idx = __float_as_uint(q3.y);
+                        rng.carry = 0u; rng.has_carry = 0u;
+                        depth = q3.z;
+                        draws = rng.c0 * 4u + rng.idx - iteration * 4096u;
                         cam_draws = draws;
-                        org0 = ld3(P.cam.origin) + offset;
-                        const f3 B = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - ld3(P.cam.origin) - offset;
-                        dir0 = normalize(B);
+                        // depth_calculator :1859-1889 and direct_integrator :1772-1785 start from the
+                        // same ray with the same rng copy
                         alpha = 0.0f;
-                        depth = 0.0f;
                         env_pos = org0;
-                        L = mk3(1.0f);           // value = WHITE when not rendering (:2248)
-                        beta = mk3(0.0f);
+                        pos = org0;
+                        dir = dir0;
+                        inv = rcp3(dir);
+                        L = mk3(0.0f);
+                        beta = mk3(1.0f);
+                        mi = false;
+                        rd = 1;
                         n_d = n_c = n_e = n_steps = n_skips = 0;
-                        if (iteration < P.max_interactions && P.render) {
-                            // ---- depth_calculator :1859-1889 (rng copy = same stream) ------
-                            pos = org0;
-                            dir = dir0;
-                            inv = rcp3(dir);
-                            float t_min;
-                            const int obj = closest_object(P, pos, dir, inv, t_min);
-                            mi = false;
-                            if (obj == 1) {
-                                pos += dir * (t_min + VPT_EPS);
-                                t = 0.0f; geo = false; obj2 = false;
-                                phase = PH_W_DEPTH;
-                            } else {
-                                // :1883-1888: sphere hit -> distance to it, nothing -> 0.  `mi` doubles
-                                // as "pos is the first hit" for the epilogue in PH_T_DEPTH_DONE.
-                                if (obj == 2) {
-                                    pos += dir * t_min;
-                                    mi = true;
-                                }
-                                phase = PH_T_DEPTH_DONE;
-                            }
+                        if (gco_obj == 1) {
+                            pos += dir * (gco_t + VPT_EPS);
+                            gco_obj = -1;
+                            vd = 1;
+                            t = 0.0f; geo = false; obj2 = false; wgt = mk3(1.0f);
+                            n_hist = 0;
+                            phase = PH_W_FIRST;
                         } else {
-                            phase = PH_T_FINISH;
-                            rd = -1;                                       // marks "not traced"
+                            phase = PH_T_OUTER_TOP;      // sphere first: cached result is reused there
                         }
                     }
                 }
@@ -435,7 +530,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
         }
 
         // ==== one tracking step for every walking lane =====================================
-        if (phase >= PH_W_DEPTH && phase <= PH_W_LAST) {
+        rng_top_up(rng, pixel);
+        if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const bool is_sample = phase <= PH_W_TRACK;
             const bool is_emit = EMIT && phase == PH_W_EMIT;
             f3 nmin, nmax;
@@ -491,6 +587,10 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                             int index = (int)floorf(fmin_(fmax_((density * inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
                             const float* dc = P.density_color_lut + 3 * index;
                             if (alpha < 1.0f) alpha += density;
+                            if (phase == PH_W_FIRST) {
+                                if (n_hist < VPT_HIST_CAP) s_hist[n_hist * 256 + threadIdx.x] = density;
+                                n_hist++;
+                            }
                             if (density * inv_max > rnd(rng, draws)) {
                                 mi = true;
                                 wgt = (ld3(P.albedo) * Cd * mk3(dc[0], dc[1], dc[2]) / ld3(P.extinction)) * P.energy_inject;
@@ -507,7 +607,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                 }
             }
             if (done) {
-                if (phase == PH_W_DEPTH) phase = PH_T_DEPTH_DONE;
+                if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;
                 else if (phase == PH_W_EMIT) phase = PH_T_EMIT_DONE;
                 else {
@@ -519,48 +619,52 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
         }
 
         // ==== transitions: integrator control flow between walks ===========================
-        while (__any(phase >= PH_T_FIRST)) {
-            // `start_tr` request: set by the states below, served once at the bottom
+        // States are visited in successor order, so e.g. TRACK_DONE -> OUTER_SECOND -> OUTER_TOP
+        // -> FINISH resolves in a single pass.  Each state draws at most 2 random numbers.
+        // Transition code runs with few lanes, so it is batched like the refill: entered only when
+        // >= trans_min lanes wait for it or nothing else can make progress.
+        const unsigned long long tmask = __ballot(phase >= PH_T_FIRST);
+        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
+        while (run_trans && __any(phase >= PH_T_FIRST)) {
+            rng_top_up(rng, pixel);
             bool start_tr = false;
             uint32_t tr_walk_phase = PH_IDLE, tr_done_phase = PH_IDLE;
             f3 tr_dir = mk3(0.0f);
 
-            if (phase == PH_T_DEPTH_DONE) {
-                // depth_calculator epilogue :1880-1888
+            if (phase == PH_T_FIRST_DONE) {
+                // the walk just finished IS depth_calculator's walk (:1879-1881) ...
                 depth = mi ? length(org0 - pos) : .0f;
-                // direct_integrator prologue :1772-1777: rng BY VALUE -> restart after get_ray
+                // ... and direct_integrator's first sample() call (:1789), which would add the same
+                // densities to Alpha a second time (:1670)
+                if (alpha < 1.0f) {
+                    if (n_hist > VPT_HIST_CAP) {
+                        phase = PH_T_REPLAY;
+                    } else {
+                        for (uint32_t i = 0; i < n_hist; ++i)
+                            if (alpha < 1.0f) alpha += s_hist[i * 256 + threadIdx.x];
+                    }
+                }
+                if (COUNT && phase == PH_T_FIRST_DONE) {
+                    // the reference walks this segment twice (depth pass + integrator): count it twice
+                    n_d += n_d; n_c += n_c; n_steps += n_steps; n_skips += n_skips;
+                }
+                if (phase == PH_T_FIRST_DONE) phase = PH_T_TRACK_DONE;
+            }
+            if (phase == PH_T_REPLAY) {
+                // history overflow (long walk through thin medium): replay the integrator's first walk
+                // for real, from the primary ray and the post-camera rng state
                 const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
-                rocrand_init(pixel, 0, (unsigned long long)iteration * 4096ull + cam_draws, &rng);
+                rng_init(rng, pixel, iteration * 4096u + cam_draws);
                 draws = cam_draws;
                 pos = org0;
                 dir = dir0;
                 inv = rcp3(dir);
-                L = mk3(0.0f);
-                beta = mk3(1.0f);
                 mi = false;
                 rd = 1;
+                gco_obj = -1;
                 phase = PH_T_OUTER_TOP;
-            } else if (phase == PH_T_OUTER_TOP) {
-                if (rd > P.ray_depth) {
-                    phase = PH_T_FINISH;
-                } else {
-                    float t_min;
-                    const int obj = closest_object(P, pos, dir, inv, t_min);      // :1782
-                    if (obj == 1) {
-                        pos += dir * (t_min + VPT_EPS);
-                        vd = 1;
-                        mi = false;
-                        t = 0.0f; geo = false; obj2 = false; wgt = mk3(1.0f);
-                        phase = PH_W_TRACK;
-                    } else if (obj == 0) {
-                        // nothing ahead: the second get_closest_object (:1806) sees the same
-                        // ray, so this and every later iteration is a no-op -> finish (exact)
-                        phase = PH_T_FINISH;
-                    } else {
-                        phase = PH_T_OUTER_SECOND;
-                    }
-                }
-            } else if (phase == PH_T_TRACK_DONE) {
+            }
+            if (phase == PH_T_TRACK_DONE) {
                 // :1789-1796
                 beta *= wgt;
                 const bool brk = is_black(beta) || obj2;
@@ -568,6 +672,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                     sample_hg(dir, rng, draws, P.phase_g1);
                     inv = rcp3(dir);
                 }
+                gco_obj = -1;
                 vd++;
                 if (!brk && vd <= P.volume_depth) {
                     mi = false;
@@ -593,12 +698,6 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                 } else {
                     phase = PH_T_EMIT_CHECK;
                 }
-            } else if (phase == PH_T_PL_NEXT) {
-                // estimate_point_light :1461-1466
-                light_index = (int)floorf(rnd(rng, draws) * P.num_lights);
-                if (light_index > P.num_lights - 1) light_index = P.num_lights - 1;  // rand()==1.0f guard
-                const DPointLight& lt = P.lights[light_index];
-                start_tr = true; tr_dir = normalize(ld3(lt.pos) - ppos); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
             } else if (phase == PH_T_PL_DONE) {
                 if (budget < P.num_lights) {
                     // point_light::Le, light.h:104-121
@@ -617,32 +716,37 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                     L += Ld * beta;                                                 // :1799
                     phase = PH_T_EMIT_CHECK;
                 }
-            } else if (phase == PH_T_EMIT_CHECK) {
-                if (EMIT && P.emission_scale > 0) {                                 // :1802 (mi is true here)
-                    pos = ppos;
-                    dir = pdir;
-                    inv = rcp3(dir);
-                    t = 0.0f;
-                    Ld = mk3(0.0f);
-                    phase = PH_W_EMIT;
-                } else {
-                    pos = ppos;
-                    dir = pdir;
-                    inv = rcp3(dir);
-                    phase = PH_T_OUTER_SECOND;
-                }
-            } else if (phase == PH_T_EMIT_DONE) {
-                L += Ld;                                                            // :1803
+            }
+            if (phase == PH_T_PL_NEXT) {
+                // estimate_point_light :1461-1466 (1 draw)
+                light_index = (int)floorf(rnd(rng, draws) * P.num_lights);
+                if (light_index > P.num_lights - 1) light_index = P.num_lights - 1;  // rand()==1.0f guard
+                const DPointLight& lt = P.lights[light_index];
+                start_tr = true; tr_dir = normalize(ld3(lt.pos) - ppos); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
+            } else if (phase == PH_T_EMIT_CHECK || phase == PH_T_EMIT_DONE || phase == PH_T_SPH_DONE) {
+                if (phase == PH_T_EMIT_DONE) L += Ld;                               // :1803
+                if (phase == PH_T_SPH_DONE) L += ld3(P.sun_color) * P.sun_mult * mk3(trw) * sph_factor * beta;  // :1832
                 pos = ppos;
                 dir = pdir;
                 inv = rcp3(dir);
-                phase = PH_T_OUTER_SECOND;
-            } else if (phase == PH_T_OUTER_SECOND) {
-                float t_min;
-                const int obj = closest_object(P, pos, dir, inv, t_min);            // :1806
-                if (obj == 2) {
-                    // sphere bounce :1809-1833
-                    pos += dir * t_min;
+                gco_obj = -1;
+                if (phase == PH_T_EMIT_CHECK && EMIT && P.emission_scale > 0) {     // :1802 (mi is true here)
+                    t = 0.0f;
+                    Ld = mk3(0.0f);
+                    phase = PH_W_EMIT;
+                } else if (phase == PH_T_SPH_DONE) {
+                    env_pos = pos;                                                  // :1833
+                    rd++;
+                    phase = PH_T_OUTER_TOP;
+                } else {
+                    phase = PH_T_OUTER_SECOND;
+                }
+            }
+            if (phase == PH_T_OUTER_SECOND) {
+                if (gco_obj < 0) gco_obj = closest_object(P, pos, dir, inv, gco_t); // :1806
+                if (gco_obj == 2) {
+                    // sphere bounce :1809-1833 (2 draws)
+                    pos += dir * gco_t;
                     const f3 normal = normalize((pos - ld3(P.sph_center)) / P.sph_radius);
                     const f3 nl = dot(normal, dir) < 0 ? normal : normal * -1;
                     const float phi = 2 * VPT_PI * rnd(rng, draws);
@@ -661,33 +765,41 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceParams P) {
                     sph_factor = fmax_(dot(sun_dir, normal), .0f);
                     ppos = pos;
                     pdir = dir;
+                    gco_obj = -1;
                     start_tr = true; tr_dir = sun_dir; tr_walk_phase = PH_W_SPH; tr_done_phase = PH_T_SPH_DONE;
                 } else {
-                    rd++;
+                    rd++;                          // same ray next iteration: the cached result stays valid
                     phase = PH_T_OUTER_TOP;
                 }
-            } else if (phase == PH_T_SPH_DONE) {
-                L += ld3(P.sun_color) * P.sun_mult * mk3(trw) * sph_factor * beta;  // :1832
-                pos = ppos;
-                dir = pdir;
-                inv = rcp3(dir);
-                env_pos = pos;
-                rd++;
-                phase = PH_T_OUTER_TOP;
-            } else if (phase == PH_T_FINISH) {
-                Record r;
-                r.L[0] = L.x; r.L[1] = L.y; r.L[2] = L.z;
-                r.tr = fmin_(alpha, 1.0f);                                          // :1854
-                r.beta[0] = beta.x; r.beta[1] = beta.y; r.beta[2] = beta.z;
-                r.depth = depth;
-                r.env_pos[0] = env_pos.x; r.env_pos[1] = env_pos.y; r.env_pos[2] = env_pos.z;
-                r.flags = (rd == -1) ? 0u : 1u;
-                const f3 od = (rd == -1) ? dir0 : dir;
-                r.dir[0] = od.x; r.dir[1] = od.y; r.dir[2] = od.z;
-                r.pad_ = 0.0f;
+            }
+            if (phase == PH_T_OUTER_TOP) {
+                if (rd > P.ray_depth) {
+                    phase = PH_T_FINISH;
+                } else {
+                    if (gco_obj < 0) gco_obj = closest_object(P, pos, dir, inv, gco_t);   // :1782
+                    if (gco_obj == 1) {
+                        pos += dir * (gco_t + VPT_EPS);
+                        gco_obj = -1;
+                        vd = 1;
+                        mi = false;
+                        t = 0.0f; geo = false; obj2 = false; wgt = mk3(1.0f);
+                        phase = PH_W_TRACK;
+                    } else if (gco_obj == 0) {
+                        // nothing ahead: the second get_closest_object (:1806) sees the same ray, so
+                        // this and every later iteration is a no-op -> finish (exact)
+                        phase = PH_T_FINISH;
+                    } else {
+                        phase = PH_T_OUTER_SECOND;   // sphere is closest: handled next pass
+                    }
+                }
+            }
+            if (phase == PH_T_FINISH) {
+                const f3 od = dir;
                 float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
-                const float4* src = reinterpret_cast<const float4*>(&r);
-                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                dst[0] = make_float4(L.x, L.y, L.z, fmin_(alpha, 1.0f));           // tr = fminf(tr, 1) :1854
+                dst[1] = make_float4(beta.x, beta.y, beta.z, depth);
+                dst[2] = make_float4(env_pos.x, env_pos.y, env_pos.z, __uint_as_float(1u));
+                dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
                 if (COUNT) {
                     atomicAdd(&P.counters->samples, 1ull);
                     atomicAdd(&P.counters->density_lookups, (unsigned long long)n_d);
@@ -732,6 +844,13 @@ template <bool MULTI, bool COLOR, bool EMIT>
 static hipError_t launch_variant(const TraceParams& P, int blocks, hipStream_t stream) {
     if (P.counters) hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, true>), dim3(blocks), dim3(256), 0, stream, P);
     else hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, false>), dim3(blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_raygen(const TraceParams& P, hipStream_t stream) {
+    const dim3 grid((P.width + 63u) / 64u, (P.height + VPT_RAYGEN_ROWS - 1u) / VPT_RAYGEN_ROWS, P.iter_count), block(64, 4, 1);
+    if (P.counters) hipLaunchKernelGGL((raygen_kernel<true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((raygen_kernel<false>), grid, block, 0, stream, P);
     return hipGetLastError();
 }
 

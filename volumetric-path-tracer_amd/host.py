@@ -84,6 +84,7 @@ def load_library(path=None):
     lib.vpt_test_host_math.argtypes = [C.c_int, vp, vp, C.c_int]
     lib.vpt_test_device_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     lib.vpt_test_device_uniform_stream.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, C.c_int, vp]
+    lib.vpt_test_device_product_stream.argtypes = [vp, C.c_uint, C.c_uint, C.c_int, vp]
     if path is None:
         _lib = lib
     return lib
