@@ -301,6 +301,7 @@ typedef struct vpt_render_stats {
     unsigned long long emission_lookups;  /* N_e                                       */
     unsigned long long tracking_steps;    /* RNG-consuming steps of sample/Tr/emission */
     unsigned long long skip_steps;        /* empty-node pushes                         */
+    unsigned long long queued_rays;       /* rays the last batch handed to the tracer  */
     float              trace_ms;          /* HIP-event time of the trace kernel(s)     */
     float              resolve_ms;        /* HIP-event time of the resolve kernel(s)   */
 } vpt_render_stats;

@@ -87,5 +87,7 @@ def test_config2_sun_and_sky_parity(pkg, sky):
     assert ob.accum.mean() > 1e-3                      # the sky actually contributes
     e = rel_l2(got, ob.accum)
     assert e <= 1e-3, e                                # north-star tolerance
-    assert e <= 2e-5, e                                # achieved (fp32 device libm vs glibc in the sky tail)
-    np.testing.assert_allclose(hb.raw.cpu().numpy()[:, :3], ob.raw[:, :3], rtol=2e-4, atol=2e-5)
+    # achieved: the sky tail is value-only code built with approximate fp32 divide/sqrt and the hardware
+    # exp/log (csrc/vpt_tail.hip); its ill-conditioned geometry terms amplify those ulps to ~1e-4
+    assert e <= 4e-4, e
+    np.testing.assert_allclose(hb.raw.cpu().numpy()[:, :3], ob.raw[:, :3], rtol=2e-3, atol=2e-4)

@@ -40,10 +40,10 @@ def main():
             hb.sync()
             st = hb.ctx.stats()
             if best is None or st.trace_ms < best[0]:
-                best = (st.trace_ms, st.resolve_ms)
+                best = (st.trace_ms, st.resolve_ms, st.queued_rays)
         n = args.width * args.height * args.spp
-        print(" ".join("%s=%s" % kv for kv in zip(keys, combo)), "trace_ms %.3f resolve_ms %.3f -> %.1f Msamples/s (trace only %.1f)" %
-              (best[0], best[1], n / (best[0] + best[1]) / 1e3, n / best[0] / 1e3), flush=True)
+        print(" ".join("%s=%s" % kv for kv in zip(keys, combo)), "trace_ms %.3f resolve_ms %.3f -> %.1f Msamples/s (trace only %.1f) queued %d of %d" %
+              (best[0], best[1], n / (best[0] + best[1]) / 1e3, n / best[0] / 1e3, best[2], n), flush=True)
         hb.ctx.close()
 
 

@@ -1,54 +1,81 @@
 """Build libvpt_hip.so (the C-ABI library of include/vpt_abi.h) for gfx950 with hipcc.
 
-    python volumetric-path-tracer_amd/build.py [--force] [--verbose]
+    python volumetric-path-tracer_amd/build.py [--force] [--verbose] [-DNAME=VALUE ...]
 
-Flags that matter for parity (Arithmetic): -ffp-contract=off (no FMA
-contraction on the decision path), default correctly-rounded fp32 divide/sqrt, no
-fast-math.  The .so is built IN-TREE so it travels to the GPU box with the snapshot.
+Flags that matter for parity (Arithmetic): the tracer, the host code and the
+resolve kernel are compiled STRICT: -ffp-contract=off (no FMA contraction on the decision
+path), HIP's default correctly-rounded fp32 divide/sqrt, no fast-math.  Only vpt_tail.hip
+(the value-only sky/environment tail) is compiled with approximate divide/sqrt and FMA
+contraction.  The .so is built IN-TREE so it travels to the GPU box with the snapshot.
 """
+import concurrent.futures
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libvpt_hip.so")
-SOURCES = ["vpt_host.hip", "vpt_trace.hip", "vpt_resolve.hip", "vpt_atmosphere.hip", "vpt_testhooks.hip"]
 HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", os.path.join("..", "..", "include", "vpt_abi.h"),
            os.path.join("..", "..", "include", "vpt_testhooks.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
-]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+STRICT = ["-ffp-contract=off", "-fno-fast-math"]
+VALUE_ONLY = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+SOURCES = {
+    "vpt_host.hip": STRICT,
+    "vpt_trace.hip": STRICT,
+    "vpt_resolve.hip": STRICT,
+    "vpt_tail.hip": VALUE_ONLY,
+    "vpt_atmosphere.hip": STRICT,
+    "vpt_testhooks.hip": STRICT,
+}
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
-        return OUT
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libvpt_hip.so")
-    if verbose and (r.stdout or r.stderr):
-        print(r.stdout + r.stderr)
+    os.makedirs(OBJ, exist_ok=True)
+    common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src, flags in SOURCES.items():
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or extra_flags or _stale(obj, [os.path.join(CSRC, src)] + common_deps):
+            jobs.append([HIPCC] + COMMON + flags + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for cmd, r in ex.map(run, jobs):
+                if r.returncode != 0:
+                    sys.stderr.write(r.stdout + r.stderr)
+                    raise RuntimeError("hipcc failed: " + " ".join(cmd))
+                if verbose and r.stderr:
+                    print(r.stderr)
+    if jobs or _stale(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        cmd, r = run(cmd)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc link failed")
     return OUT
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv,
           extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a not in ("--force", "--verbose")])
     print("built", OUT)

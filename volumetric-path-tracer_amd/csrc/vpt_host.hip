@@ -501,6 +501,11 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         else out->resolve_ms += ms;
     }
     out->samples = ctx->last_samples;
+    {
+        uint32_t wc[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpy(wc, ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
+        out->queued_rays = wc[1];
+    }
     if (ctx->counting) {
         Counters c;
         HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
