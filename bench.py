@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=16)
     args = ap.parse_args()
 
     import numpy as np
@@ -85,7 +85,6 @@ def main():
     for _ in range(args.warmup):
         one_step()
     fence()
-    trace_ms = resolve_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -95,8 +94,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event times of the LAST step (events live on the ctx stream the kernels run on)
     st = hb.ctx.stats()
-    trace_ms, resolve_ms = st.trace_ms, st.resolve_ms
-    n_trace_launches = max(1, len([1 for _ in range(0, spp, max(1, min(64, spp)))]))
+    trace_ms, resolve_ms, raygen_ms, tail_ms = st.trace_ms, st.resolve_ms, st.raygen_ms, st.tail_ms
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -126,7 +124,9 @@ def main():
             "algorithmic_bytes_per_sample": round(b_trace, 2), "survey_8d_bytes_per_sample": round(b_survey, 2),
             "density_lookups_per_sample": round(nd, 4), "tracking_steps_per_sample": round(cs.tracking_steps / n, 4),
             "skip_steps_per_sample": round(cs.skip_steps / n, 4),
-            "trace_ms_per_step": round(trace_ms, 3), "resolve_ms_per_step": round(resolve_ms, 3),
+            "raygen_ms_per_step": round(raygen_ms, 3), "trace_ms_per_step": round(trace_ms, 3),
+            "tail_ms_per_step": round(tail_ms, 3), "resolve_ms_per_step": round(resolve_ms, 3),
+            "rays_traced_fraction": round(cs.queued_rays / float(W * H * min(2, spp)), 4),
             "note": "dragon grid is 425 KB (L2-resident): the fraction is algorithmic bytes / HBM peak, not measured HBM traffic",
         }
         cpu = None

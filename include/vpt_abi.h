@@ -302,8 +302,10 @@ typedef struct vpt_render_stats {
     unsigned long long tracking_steps;    /* RNG-consuming steps of sample/Tr/emission */
     unsigned long long skip_steps;        /* empty-node pushes                         */
     unsigned long long queued_rays;       /* rays the last batch handed to the tracer  */
-    float              trace_ms;          /* HIP-event time of the trace kernel(s)     */
-    float              resolve_ms;        /* HIP-event time of the resolve kernel(s)   */
+    float              trace_ms;          /* HIP-event time of trace_kernel            */
+    float              resolve_ms;        /* HIP-event time of resolve_kernel          */
+    float              raygen_ms;         /* HIP-event time of raygen_kernel           */
+    float              tail_ms;           /* HIP-event time of tail_kernel             */
 } vpt_render_stats;
 /* enable/disable look-up counting (off by default: counting costs atomics) */
 int  vpt_set_counting(vpt_ctx *ctx, int enable);

@@ -497,7 +497,9 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_pool[s.e1]));
         float ms = 0.0f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[s.e0], ctx->ev_pool[s.e1]));
-        if (s.kind == 0) out->trace_ms += ms;
+        if (s.kind == 0) out->raygen_ms += ms;
+        else if (s.kind == 1) out->trace_ms += ms;
+        else if (s.kind == 2) out->tail_ms += ms;
         else out->resolve_ms += ms;
     }
     out->samples = ctx->last_samples;
@@ -728,19 +730,24 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
         if (blocks < 1) blocks = 1;
-        int e0, e1, rc;
-        if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        // HIP events on the launch stream around every stage (one span per kernel)
+        int ev[5], rc;
+        for (int i = 0; i < 5; i += 2) {
+            int a, b;
+            if ((rc = get_events(ctx, &a, &b)) != 0) return rc;
+            ev[i] = a;
+            if (i + 1 < 5) ev[i + 1] = b;
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
         HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
-        ctx->spans.push_back({e0, e1, 0});
-        if ((rc = get_events(ctx, &e0, &e1)) != 0) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
         HIPCHK(ctx, launch_tail(R, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));
         HIPCHK(ctx, launch_resolve(R, stream));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
-        ctx->spans.push_back({e0, e1, 1});
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[4]], stream));
+        for (int k = 0; k < 4; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
         ctx->last_samples += total;
     }
     return VPT_OK;
