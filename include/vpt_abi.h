@@ -333,6 +333,14 @@ void vpt_camera_update(vpt_camera *cam, vpt_float3 lookfrom, vpt_float3 lookat, 
 void vpt_camera_default(vpt_camera *cam);
 /* GPU_VDB::Bounds, source/gpu_vdb/gpu_vdb.h:131-146 */
 void vpt_gpu_vdb_bounds(const vpt_gpu_vdb *vdb, vpt_float3 *pmin, vpt_float3 *pmax);
+/* the per-instance transform of the .ins loader, source/main.cpp:1060-1095:
+ *   xform = base; xform.translate(-xform.extract_translate()); xform.scale(scale);
+ *   xform = quaternion_to_mat4(rotation) * xform; xform.translate(position)
+ * with mat4's own conventions (matrix_math.h:49-70,130-163,326-344,379-412: storage m[col][row],
+ * scale() touches the diagonal only, operator* as written there).  base/out: float[4][4] as in
+ * vpt_gpu_vdb::xform; position double[3]; rotation double[4] (x, y, z, w). */
+void vpt_instance_xform(const float base[4][4], const double position[3], const double rotation[4],
+                        double scale, float out[4][4]);
 /* Kernel_params defaults of source/main.cpp:1350-1376 (+ the per-frame overrides at
  * :1533-1546: azimuth 120, elevation 30, energy_inject 1.0) */
 void vpt_kernel_params_default(vpt_kernel_params *kp);

@@ -714,7 +714,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
 
     const bool multi = P.num_volumes > 1;
     const bool color = ctx->any_color;
-    const bool emit = ctx->any_emission && kp->emission_scale > 0;
+    // the emission march runs (and consumes random numbers) whenever emission_scale > 0, with or
+    // without emission grids (render_kernel.cu:1802, :1285)
+    const bool emit = kp->emission_scale > 0;
     const int max_blocks = ctx->num_cus * ctx->blocks_per_cu;
 
     for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {
@@ -802,6 +804,38 @@ void vpt_gpu_vdb_bounds(const vpt_gpu_vdb* vdb, vpt_float3* pmin, vpt_float3* pm
     Box b = vdb_bounds(*vdb);
     if (pmin) *pmin = tov(b.lo);
     if (pmax) *pmax = tov(b.hi);
+}
+
+void vpt_instance_xform(const float base[4][4], const double position[3], const double rotation[4], double scale, float out[4][4]) {
+    if (!base || !position || !rotation || !out) return;          // main.cpp:1060-1095
+    float x[4][4];
+    std::memcpy(x, base, sizeof(x));
+    // xform.translate(-xform.extract_translate())   (matrix_math.h:326-336)
+    const float tx = -x[0][3], ty = -x[1][3], tz = -x[2][3];
+    x[0][3] += tx; x[1][3] += ty; x[2][3] += tz;
+    // xform.scale(make_float3(scale))                (matrix_math.h:338-344: diagonal only)
+    const float s = (float)scale;
+    x[0][0] *= s; x[1][1] *= s; x[2][2] *= s;
+    // quaternion_to_mat4(double x4) (matrix_math.h:379-412): n = 1.0 / sqrtf(...) in double
+    double qx = rotation[0], qy = rotation[1], qz = rotation[2], qw = rotation[3];
+    const double n = 1.0 / sqrtf((float)(qx * qx + qy * qy + qz * qz + qw * qw));
+    qx *= n; qy *= n; qz *= n; qw *= n;
+    float r[4][4];     // mat4(m11..m44): m[c][r] = m_(r+1)(c+1)
+    const float m11 = float(1.0f - 2.0f * qy * qy - 2.0f * qz * qz), m12 = float(2.0f * qx * qy + 2.0f * qz * qw), m13 = float(2.0f * qx * qz - 2.0f * qy * qw);
+    const float m21 = float(2.0f * qx * qy - 2.0f * qz * qw), m22 = float(1.0f - 2.0f * qx * qx - 2.0f * qz * qz), m23 = float(2.0f * qy * qz + 2.0f * qx * qw);
+    const float m31 = float(2.0f * qx * qz + 2.0f * qy * qw), m32 = float(2.0f * qy * qz - 2.0f * qx * qw), m33 = float(1.0f - 2.0f * qx * qx - 2.0f * qy * qy);
+    r[0][0] = m11; r[1][0] = m12; r[2][0] = m13; r[3][0] = 0.0f;
+    r[0][1] = m21; r[1][1] = m22; r[2][1] = m23; r[3][1] = 0.0f;
+    r[0][2] = m31; r[1][2] = m32; r[2][2] = m33; r[3][2] = 0.0f;
+    r[0][3] = 0.0f; r[1][3] = 0.0f; r[2][3] = 0.0f; r[3][3] = 1.0f;
+    // xform = rotation_matrix * xform  (operator*, matrix_math.h:130-163: a_rc = A.m[c][r], ret.m[i][j] = sum_k a_ik b_kj)
+    float o[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            o[i][j] = r[0][i] * x[j][0] + r[1][i] * x[j][1] + r[2][i] * x[j][2] + r[3][i] * x[j][3];
+    // xform.translate(position)
+    o[0][3] += (float)position[0]; o[1][3] += (float)position[1]; o[2][3] += (float)position[2];
+    std::memcpy(out, o, sizeof(o));
 }
 
 void vpt_kernel_params_default(vpt_kernel_params* kp) {   // main.cpp:1350-1376 + :1533-1546

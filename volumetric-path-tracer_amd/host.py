@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
     "vpt_atmosphere_default_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
-    "vpt_camera_update", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_kernel_params_default",
+    "vpt_camera_update", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
 ]
 
 
@@ -75,6 +75,9 @@ def load_library(path=None):
     lib.vpt_camera_default.restype = None
     lib.vpt_gpu_vdb_bounds.argtypes = [C.POINTER(GpuVdb), C.POINTER(Float3), C.POINTER(Float3)]
     lib.vpt_gpu_vdb_bounds.restype = None
+    lib.vpt_instance_xform.argtypes = [C.POINTER((C.c_float * 4) * 4), C.POINTER(C.c_double * 3), C.POINTER(C.c_double * 4), C.c_double,
+                                       C.POINTER((C.c_float * 4) * 4)]
+    lib.vpt_instance_xform.restype = None
     lib.vpt_kernel_params_default.argtypes = [C.POINTER(KernelParams)]
     lib.vpt_kernel_params_default.restype = None
     lib.vpt_atmosphere_default_model.argtypes = [C.POINTER(AtmosphereParameters)]

@@ -224,3 +224,188 @@ class HipBinding:
 
     def sync(self):
         self.ctx.sync()
+
+
+# ---- synthetic stand-ins for the assets the reference does not ship -----------------
+def value_noise(shape, cells, seed, octaves=1):
+    """Deterministic trilinear value noise in [0, 1] on a [z, y, x] grid: a random lattice of
+    `cells` periods per axis (doubling per octave, amplitude halving)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros(shape, np.float32)
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        c = cells * (1 << o)
+        lat = rng.random((c + 1, c + 1, c + 1), dtype=np.float32)
+        ax = [np.linspace(0, c, n, endpoint=False, dtype=np.float32) for n in shape]
+        i = [np.minimum(a.astype(np.int32), c - 1) for a in ax]
+        f = [(a - ii).astype(np.float32) for a, ii in zip(ax, i)]
+        f = [t * t * (3 - 2 * t) for t in f]
+        iz, iy, ix = np.ix_(i[0], i[1], i[2])
+        fz, fy, fx = np.ix_(f[0], f[1], f[2])
+        v = ((lat[iz, iy, ix] * (1 - fx) + lat[iz, iy, ix + 1] * fx) * (1 - fy) +
+             (lat[iz, iy + 1, ix] * (1 - fx) + lat[iz, iy + 1, ix + 1] * fx) * fy) * (1 - fz) + \
+            ((lat[iz + 1, iy, ix] * (1 - fx) + lat[iz + 1, iy, ix + 1] * fx) * (1 - fy) +
+             (lat[iz + 1, iy + 1, ix] * (1 - fx) + lat[iz + 1, iy + 1, ix + 1] * fx) * fy) * fz
+        out += np.float32(amp) * v.astype(np.float32)
+        total += amp
+        amp *= 0.5
+    return (out / np.float32(total)).astype(np.float32)
+
+
+def _radial(shape):
+    z, y, x = [np.linspace(-1, 1, n, dtype=np.float32) for n in shape]
+    return np.sqrt(z[:, None, None] ** 2 + y[None, :, None] ** 2 + x[None, None, :] ** 2).astype(np.float32)
+
+
+def _grid_matrix(n, voxel, centre=(0.0, 0.0, 0.0)):
+    """OpenVDB-style index->world Mat4d (row-vector convention): uniform scale + translation
+    so that the grid is centred at `centre`."""
+    m = np.eye(4)
+    m[0, 0] = m[1, 1] = m[2, 2] = voxel
+    m[3, :3] = np.asarray(centre, np.float64) - 0.5 * voxel * (np.asarray(n[::-1], np.float64) - 1)
+    return m
+
+
+def fireball_grids(n=256, seed=1234):
+    """BASELINE config 3 stand-in for the missing fireball.vdb: density = smooth radial
+    falloff x value noise, heat = density^2."""
+    shape = (n, n, n)
+    r = _radial(shape)
+    fall = np.clip(1.0 - r, 0.0, 1.0).astype(np.float32)
+    fall = fall * fall * (3 - 2 * fall)
+    dens = (fall * value_noise(shape, 4, seed, octaves=3) * np.float32(2.0)).astype(np.float32)
+    dens[dens < 0.02] = 0.0
+    return dens, (dens * dens).astype(np.float32)
+
+
+def smoke_grids(n=128, seed=4321):
+    """BASELINE config 5 stand-in for colored_smoke.vdb: density + Cd (vec3 -> float4, w = 1,
+    gpu_vdb.cpp:360-370)."""
+    shape = (n, n, n)
+    r = _radial(shape)
+    fall = np.clip(1.15 - r, 0.0, 1.0).astype(np.float32)
+    dens = (fall * value_noise(shape, 3, seed, octaves=2) * np.float32(1.5)).astype(np.float32)
+    dens[dens < 0.05] = 0.0
+    cd = np.empty(shape + (4,), np.float32)
+    cd[..., 0] = value_noise(shape, 2, seed + 1)
+    cd[..., 1] = value_noise(shape, 2, seed + 2)
+    cd[..., 2] = value_noise(shape, 2, seed + 3)
+    cd[..., 3] = 1.0
+    return dens, cd
+
+
+def cloud_grid(shape=(1216, 704, 1024), seed=42, occupancy=0.35, chunk=64):
+    """BASELINE config 4 stand-in for the Disney cloud: fBm value noise thresholded to
+    ~`occupancy`.  shape is [z, y, x]."""
+    d = value_noise(shape, 4, seed, octaves=4)
+    thr = np.quantile(d[::4, ::4, ::4], 1.0 - occupancy)
+    d = np.maximum(d - np.float32(thr), 0.0).astype(np.float32)
+    d *= np.float32(1.0) / max(np.float32(1e-6), d.max())
+    return d
+
+
+def hdri_map(w=2048, h=1024, seed=7):
+    """Synthetic lat-long HDRI: sky gradient + ground + a sun lobe."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    theta = v[:, None] * np.float32(np.pi)
+    phi = (u[None, :] - 0.5) * np.float32(2 * np.pi)
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta) * np.ones_like(phi), np.sin(theta) * np.sin(phi)], -1).astype(np.float32)
+    sun = np.array([0.5, 0.6, 0.62], np.float32)
+    sun /= np.linalg.norm(sun)
+    c = np.clip((d * sun).sum(-1), -1, 1)
+    sky = np.where(d[..., 1:2] > 0, np.array([0.35, 0.55, 0.95], np.float32) * (0.4 + 0.6 * d[..., 1:2]),
+                   np.array([0.25, 0.22, 0.2], np.float32) * (0.6 + 0.4 * d[..., 1:2]))
+    lobe = (np.exp((c - 1.0) * 400.0) * 60.0 + np.exp((c - 1.0) * 8.0) * 0.8)[..., None] * np.array([1.0, 0.92, 0.8], np.float32)
+    img = np.empty((h, w, 4), np.float32)
+    img[..., :3] = sky + lobe + rng.random((h, w, 1), dtype=np.float32) * 0.01
+    img[..., 3] = 1.0
+    return img
+
+
+def _base_kp(lib, width, height):
+    kp = KernelParams()
+    lib.vpt_kernel_params_default(C.byref(kp))
+    kp.resolution = abi.UInt2(int(width), int(height))
+    kp.max_interactions = 1 << 30
+    return kp
+
+
+def _finish(sd):
+    luts = load_golden("luts.npz")
+    bn = load_golden("bn0.npz")
+    sd.blue_noise = blue_noise_from_rgb(bn["rgb"])
+    sd.emission_lut = np.ascontiguousarray(luts["blackbody"], np.float32)
+    sd.density_color_lut = np.ascontiguousarray(luts["density_color"], np.float32)
+    return sd
+
+
+def fireball_scene(width, height, n=256, lib=None):
+    """BASELINE config 3: emission + blackbody LUT, sun only (emission_scale = 1, pivot = 1)."""
+    lib = lib or load_library()
+    dens, heat = fireball_grids(n)
+    sd = SceneDesc()
+    sd.width, sd.height = int(width), int(height)
+    voxel = 20.0 / n
+    vdb = make_gpu_vdb(dens, (0, 0, 0), (n - 1, n - 1, n - 1), _grid_matrix(dens.shape, voxel), voxel, emission=heat)
+    sd.volumes.append((vdb, dens, heat, None))
+    sd.camera, center, dist = frame_camera(lib, [vdb], width, height)
+    kp = _base_kp(lib, width, height)
+    kp.emission_scale = 1.0
+    kp.emission_pivot = 1.0
+    kp.sky_mult = 0.0
+    sd.kp = kp
+    return _finish(sd)
+
+
+def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacing=None, lib=None):
+    """BASELINE config 5: grid x grid instances of one coloured-smoke grid (density + Cd) on a
+    jittered lattice with random unit quaternions, scale 1, via the .ins transform
+    (vpt_instance_xform == main.cpp:1060-1095), DOF on."""
+    lib = lib or load_library()
+    dens, cd = smoke_grids(n)
+    voxel = 8.0 / n
+    base = make_gpu_vdb(dens, (0, 0, 0), (n - 1, n - 1, n - 1), _grid_matrix(dens.shape, voxel), voxel, color=cd)
+    rng = np.random.default_rng(seed)
+    spacing = spacing or 9.0
+    sd = SceneDesc()
+    sd.width, sd.height = int(width), int(height)
+    F44 = (C.c_float * 4) * 4
+    for gi in range(grid):
+        for gj in range(grid):
+            pos = np.array([(gi - (grid - 1) / 2) * spacing, 0.0, (gj - (grid - 1) / 2) * spacing]) + rng.uniform(-2.0, 2.0, 3)
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            v = GpuVdb.from_buffer_copy(base)
+            out = F44()
+            lib.vpt_instance_xform(C.byref(base.xform), C.byref((C.c_double * 3)(*pos)), C.byref((C.c_double * 4)(*q)), 1.0, C.byref(out))
+            C.memmove(C.byref(v.xform), C.byref(out), C.sizeof(out))
+            sd.volumes.append((v, dens, None, cd))
+    vols = [v for v, _, _, _ in sd.volumes]
+    sd.camera, center, dist = frame_camera(lib, vols, width, height, aperture=aperture)
+    kp = _base_kp(lib, width, height)
+    kp.sky_mult = 0.0
+    sd.kp = kp
+    return _finish(sd)
+
+
+def cloud_scene(width, height, shape=(152, 88, 128), env=(512, 256), integrator=1, lib=None):
+    """BASELINE config 4: large fBm cloud, synthetic lat-long HDRI (environment_type = 1),
+    vol_integrator.  The caller binds atmosphere LUTs (vol_integrator's tail is always the
+    procedural sky, render_kernel.cu:1752)."""
+    lib = lib or load_library()
+    dens = cloud_grid(shape)
+    sd = SceneDesc()
+    sd.width, sd.height = int(width), int(height)
+    voxel = 40.0 / shape[2]
+    nz, ny, nx = shape
+    vdb = make_gpu_vdb(dens, (0, 0, 0), (nx - 1, ny - 1, nz - 1), _grid_matrix(dens.shape, voxel), voxel)
+    sd.volumes.append((vdb, dens, None, None))
+    sd.camera, center, dist = frame_camera(lib, [vdb], width, height)
+    kp = _base_kp(lib, width, height)
+    kp.environment_type = 1
+    kp.integrator = int(integrator)
+    sd.kp = kp
+    sd.env_map = hdri_map(*env)
+    return _finish(sd)
