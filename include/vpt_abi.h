@@ -325,6 +325,18 @@ int  vpt_atmosphere_default_model(vpt_atmosphere_parameters *atm);
 int  vpt_atmosphere_precompute(vpt_ctx *ctx, vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
 int  vpt_atmosphere_read_lut(vpt_ctx *ctx, const vpt_atmosphere_parameters *atm, int which, float *host_out, size_t n_floats);
 
+/* ---- environment importance tables (prerequisite of estimate_sky on the procedural sky) -------
+ * vpt_env_cdf_build: create_cdf's table fill (source/main.cpp:647-757) over the host
+ * single-scattering sky `sample_atmosphere` (main.cpp:242-312) for kp->azimuth/elevation/sky_color:
+ * val4 float4[res*res] (may be NULL), func/cdf float[res*res], marginal_func/marginal_cdf
+ * float[res]; the reference uses res = 180.  Host only, no GPU needed.
+ * vpt_env_cdf_create: the same plus the five texture objects of main.cpp:759-867; fills
+ * kp->sky_tex, env_func_tex, env_cdf_tex, env_marginal_func_tex, env_marginal_cdf_tex,
+ * env_sample_tex_res and env_marginal_int. */
+int  vpt_env_cdf_build(const vpt_kernel_params *kp, int res, float *val4, float *func, float *cdf,
+                       float *marginal_func, float *marginal_cdf, float *marginal_int);
+int  vpt_env_cdf_create(vpt_ctx *ctx, vpt_kernel_params *kp);
+
 /* ---- host-side helpers restating reference host code the path depends on --------------- */
 /* camera::update_camera, source/gpu_vdb/camera.h:110-129 */
 void vpt_camera_update(vpt_camera *cam, vpt_float3 lookfrom, vpt_float3 lookat, vpt_float3 vup,

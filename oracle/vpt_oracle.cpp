@@ -1343,7 +1343,8 @@ int orc_render(const vpt_camera* cam, const vpt_light_list* lights, const vpt_gp
                orc_stats* stats) {
     if (!cam || !lights || !volumes || num_volumes <= 0 || !ref_sphere || !atmosphere || !kp_in) return VPT_E_INVALID;
     if (iter_stride == 0) iter_stride = 1;
-    if (kp_in->environment_type == 0 && !has_luts(*atmosphere) && (kp_in->sky_mult != 0.0f || kp_in->integrator != 0)) return VPT_E_NOT_READY;
+    // vol_integrator's tail is always sample_atmosphere (:1752), whatever environment_type says
+    if (!has_luts(*atmosphere) && ((kp_in->environment_type == 0 && kp_in->sky_mult != 0.0f) || kp_in->integrator != 0)) return VPT_E_NOT_READY;
     Scene sc;
     sc.build(volumes, num_volumes);
     vpt_kernel_params kp = *kp_in;

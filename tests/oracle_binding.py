@@ -115,6 +115,8 @@ class OracleBinding:
             self.atmosphere.single_mie_scattering_texture = self.texture(L["single_mie"], 4)
         if sd.env_map is not None:
             kp.env_tex = self.texture(sd.env_map, 4, address=(abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_CLAMP))
+        if sd.env_cdf is not None:
+            pkg.scene.bind_env_cdf(kp, sd.env_cdf, self.texture)
         self._lights_arr = (abi.PointLight * max(1, len(sd.lights)))(*sd.lights)
         self.lights = abi.LightList(len(sd.lights), C.cast(self._lights_arr, C.POINTER(abi.PointLight)))
         self.stats = OrcStats()

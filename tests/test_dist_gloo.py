@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: world_size-2 `gloo` process groups running dist.combine_means on
+(a) synthetic per-iteration images and (b) the oracle rendering rank-striped iterations of the
+dragon scene -- the same striping / pre-advanced blue noise / weighted all-reduce the GPU ranks use
+(volumetric-path-tracer_amd/dist.py, bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _iteration_image(it, n):
+    return np.random.default_rng(1000 + it).random((n, 3), dtype=np.float32)
+
+
+def _worker_synthetic(rank, world, port, total_iters, out_dir):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    first, stride, pre = pkg.dist.stripe(rank, world)
+    assert (first, stride, pre) == (rank, world, rank)
+    n = 257
+    mean = np.zeros((n, 3), np.float32)
+    k = 0
+    for it in range(first, total_iters, stride):          # running mean over the local index, like resolve_kernel
+        mean = mean + (_iteration_image(it, n) - mean) / np.float32(k + 1)
+        k += 1
+    acc = torch.from_numpy(mean.copy())
+    pkg.dist.combine_means(acc, k)
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), acc.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_iters", [8, 5])
+def test_combine_means_two_ranks(tmp_path, total_iters):
+    port = _free_port()
+    mp.spawn(_worker_synthetic, args=(2, port, total_iters, str(tmp_path)), nprocs=2, join=True)
+    ref = np.mean([_iteration_image(it, 257).astype(np.float64) for it in range(total_iters)], axis=0)
+    a = np.load(tmp_path / "r0.npy"); b = np.load(tmp_path / "r1.npy")
+    np.testing.assert_array_equal(a, b)                    # every rank holds the same image
+    np.testing.assert_allclose(a, ref, rtol=2e-6, atol=2e-7)
+
+
+def _worker_oracle(rank, world, port, spp, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    import oracle_binding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    sd = pkg.scene.dragon_scene(48, 32, "sun")
+    ob = oracle_binding.OracleBinding(sd)
+    first, stride, pre = pkg.dist.stripe(rank, world)
+    phi = np.float32((1.0 + np.sqrt(np.float32(5.0))) / np.float32(2.0))
+    for _ in range(pre):                                   # blue noise pre-advanced `rank` steps (:2320-2325)
+        ob.blue_noise[:, :] = np.fmod(ob.blue_noise + phi, np.float32(1.0))
+    n_local = len(range(first, spp, stride))
+    ob.render(n_local, iter_stride=stride, iteration=first, nthreads=1)
+    acc = torch.from_numpy(ob.accum.copy())
+    pkg.dist.combine_means(acc, n_local)
+    np.save(os.path.join(out_dir, "o%d.npy" % rank), acc.numpy())
+    dist.destroy_process_group()
+
+
+def test_striped_oracle_render_equals_single_process(tmp_path, orc):
+    """2 ranks x striped iterations + one all-reduce == 1 process rendering every iteration."""
+    spp = 6
+    port = _free_port()
+    mp.spawn(_worker_oracle, args=(2, port, spp, str(tmp_path)), nprocs=2, join=True)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    import oracle_binding
+    sd = pkg.scene.dragon_scene(48, 32, "sun")
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(spp, nthreads=1)
+    a = np.load(tmp_path / "o0.npy"); b = np.load(tmp_path / "o1.npy")
+    np.testing.assert_array_equal(a, b)
+    assert ob.accum.max() > 0
+    np.testing.assert_allclose(a, ob.accum, rtol=1e-5, atol=1e-7)

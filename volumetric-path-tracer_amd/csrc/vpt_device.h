@@ -124,6 +124,17 @@ struct TraceParams {
     const float* emission_lut;       // float3[256]
     const float* density_color_lut;  // float3[256]
     unsigned int environment_type;
+    // vol_integrator (integrator != 0) only: uniform_sample_one_light / estimate_sky inputs
+    int integrator;
+    float sky_mult;
+    int env_sample_tex_res;
+    float env_marginal_int;
+    DTexture env_tex;                                      // lat-long HDRI (environment_type 1)
+    DTexture env_func_tex, env_cdf_tex;                    // 2-D f32, unnormalised, point
+    DTexture env_marginal_func_tex, env_marginal_cdf_tex;  // 1-D f32, unnormalised, point
+    int has_atmosphere;
+    float atm_f[24];                                       // packed vpt_atmosphere_parameters scalars
+    DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
 
 struct ResolveParams {
@@ -149,7 +160,7 @@ struct ResolveParams {
     DTexture env_tex;
     // atmosphere
     int has_atmosphere;
-    float atm_f[64];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
+    float atm_f[24];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
 

@@ -22,6 +22,7 @@
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
+hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
@@ -523,7 +524,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
 
 // ---- atmosphere packing (indices: enum AF_* in vpt_resolve.hip) -------------------------------------
 static void pack_atmosphere(const vpt_atmosphere_parameters* a, float* f) {
-    std::memset(f, 0, sizeof(float) * 64);
+    std::memset(f, 0, sizeof(float) * 24);
     f[0] = a->bottom_radius; f[1] = a->top_radius; f[2] = (float)a->use_luminance; f[3] = a->mie_phase_function_g;
     f[4] = a->sun_angular_radius; f[5] = a->mu_s_min; f[6] = a->exposure;
     st3(f + 8, a->sky_spectral_radiance_to_luminance);
@@ -557,13 +558,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         set_error(ctx, "vpt_render: iteration index beyond 2^20 exceeds the 32-bit Philox counter word of this build");
         return VPT_E_UNSUPPORTED;
     }
-    if (kp->integrator != 0) {
-        set_error(ctx, "vpt_render: integrator=%d (vol_integrator, render_kernel.cu:1712) is not implemented yet", kp->integrator);
-        return VPT_E_UNSUPPORTED;
-    }
     if (lights->num_lights > 0 && !lights->light_ptr) return VPT_E_INVALID;
-    if (ctx->any_emission && kp->emission_scale > 0 && !kp->emission_texture) {
-        set_error(ctx, "vpt_render: emission_scale > 0 needs kernel_params.emission_texture");
+    if (ctx->any_emission && kp->emission_scale != 0 && !kp->emission_texture) {
+        set_error(ctx, "vpt_render: emission_scale != 0 needs kernel_params.emission_texture");
         return VPT_E_INVALID;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -587,7 +584,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     st3(R.sky_color, kp->sky_color);
     const f3 sun_dir = degree_to_cartesian(kp->azimuth, kp->elevation);
     st3(R.sun_dir, sun_dir);
-    if (kp->environment_type == 0) {
+    if (kp->environment_type == 0 || kp->integrator != 0) {
         const bool have_luts = atmosphere && atmosphere->transmittance_texture && atmosphere->scattering_texture &&
                                atmosphere->irradiance_texture && atmosphere->single_mie_scattering_texture;
         if (have_luts) {
@@ -607,11 +604,13 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             }
             R.has_atmosphere = 1;
             pack_atmosphere(atmosphere, R.atm_f);
-        } else if (kp->sky_mult != 0.0f) {
-            set_error(ctx, "vpt_render: environment_type=0 with sky_mult != 0 needs the four atmosphere look-up textures");
+        } else if (kp->sky_mult != 0.0f || kp->integrator != 0) {
+            // vol_integrator's tail is always sample_atmosphere (render_kernel.cu:1752)
+            set_error(ctx, "vpt_render: environment_type=0 with sky_mult != 0, or integrator != 0, needs the four atmosphere look-up textures");
             return VPT_E_NOT_READY;
         }
-    } else {
+    }
+    if (kp->environment_type != 0) {
         if (resolve_tex(ctx, kp->env_tex, &R.env_tex) || R.env_tex.channels != 4) {
             set_error(ctx, "vpt_render: environment_type=1 needs a float4 env_tex");
             return VPT_E_INVALID;
@@ -652,6 +651,28 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.emission_lut = reinterpret_cast<const float*>(kp->emission_texture);
     P.density_color_lut = reinterpret_cast<const float*>(kp->density_color_texture);
     P.environment_type = kp->environment_type;
+    P.integrator = kp->integrator;
+    if (kp->integrator != 0) {
+        // uniform_sample_one_light / estimate_sky inputs (render_kernel.cu:1356-1443, 1519-1554)
+        P.sky_mult = kp->sky_mult;
+        P.env_sample_tex_res = kp->env_sample_tex_res;
+        P.env_marginal_int = kp->env_marginal_int;
+        P.env_tex = R.env_tex;
+        P.has_atmosphere = R.has_atmosphere;
+        std::memcpy(P.atm_f, R.atm_f, sizeof(P.atm_f));
+        P.transmittance_tex = R.transmittance_tex; P.scattering_tex = R.scattering_tex;
+        P.irradiance_tex = R.irradiance_tex; P.single_mie_tex = R.single_mie_tex;
+        if (kp->environment_type == 0 && kp->sky_mult > 0.0f) {
+            if (resolve_tex(ctx, kp->env_func_tex, &P.env_func_tex) || resolve_tex(ctx, kp->env_cdf_tex, &P.env_cdf_tex) ||
+                resolve_tex(ctx, kp->env_marginal_func_tex, &P.env_marginal_func_tex) || resolve_tex(ctx, kp->env_marginal_cdf_tex, &P.env_marginal_cdf_tex) ||
+                P.env_func_tex.channels != 1 || P.env_cdf_tex.channels != 1 || P.env_marginal_func_tex.channels != 1 || P.env_marginal_cdf_tex.channels != 1 ||
+                kp->env_sample_tex_res < 2) {
+                set_error(ctx, "vpt_render: integrator != 0 with the procedural sky needs env_func/env_cdf/env_marginal_func/env_marginal_cdf textures "
+                               "(create_cdf, main.cpp:647; vpt_env_cdf_create)");
+                return VPT_E_NOT_READY;
+            }
+        }
+    }
 
     // lights: the reference keeps them in managed memory (main.cpp:1000); we mirror the
     // host array into HBM whenever it changes
@@ -716,7 +737,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     const bool color = ctx->any_color;
     // the emission march runs (and consumes random numbers) whenever emission_scale > 0, with or
     // without emission grids (render_kernel.cu:1802, :1285)
-    const bool emit = kp->emission_scale > 0;
+    // (vol_integrator: estimate_emission returns early only for emission_scale == 0, :1285)
+    const bool emit = kp->integrator != 0 ? kp->emission_scale != 0 : kp->emission_scale > 0;
     const int max_blocks = ctx->num_cus * ctx->blocks_per_cu;
 
     for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {
@@ -743,7 +765,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
-        HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
+        if (kp->integrator != 0) HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
+        else HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
         HIPCHK(ctx, launch_tail(R, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));

@@ -1,0 +1,268 @@
+// vpt_trace_common.h -- device helpers shared by the tracer kernels (vpt_trace.hip: direct_integrator,
+// vpt_trace_vol.hip: vol_integrator): slab / sphere tests, octree point location, dense-grid
+// look-ups, phase sampling, and ONE tracking step of any walk kind (delta tracking `sample`
+// render_kernel.cu:1556, ratio tracking `Tr` :1138, emission march :1275).  Strict arithmetic
+// (vpt_math.h): every translation unit including this file is built with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "vpt_device.h"
+#include "vpt_rng.h"
+
+namespace vpt {
+
+#define VPT_HIST_CAP 12
+#define VPT_CHUNK 256        // queue entries a wave claims per global atomic
+
+VPT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// AABB::Intersect (bvh/AABB.h:182-205) with the reciprocal direction cached per ray
+VPT_D bool box_intersect(f3 pmin, f3 pmax, f3 o, f3 inv, float& tmin, float& tmax) {
+    float t1 = (pmin.x - o.x) * inv.x;
+    float t2 = (pmax.x - o.x) * inv.x;
+    float t3 = (pmin.y - o.y) * inv.y;
+    float t4 = (pmax.y - o.y) * inv.y;
+    float t5 = (pmin.z - o.z) * inv.z;
+    float t6 = (pmax.z - o.z) * inv.z;
+    tmin = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+    tmax = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+    if (tmax <= 0.0f) return false;
+    if (tmin > tmax) return false;
+    if (tmin < 0) {
+        tmin = tmax;
+        if (tmin < 0) return false;
+    }
+    return true;
+}
+VPT_D f3 rcp3(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+
+VPT_D bool contains(f3 pmin, f3 pmax, f3 p) {    // AABB.h:141-146
+    return (p.x >= pmin.x && p.x <= pmax.x && p.y >= pmin.y && p.y <= pmax.y && p.z >= pmin.z && p.z <= pmax.z);
+}
+
+// sphere::intersect + find_discr (geometry/geometry.h:46-70,114-137)
+VPT_D bool sphere_intersect(const TraceParams& P, f3 ray_pos, f3 ray_dir, float& t_min, float& t_max) {
+    f3 orig = ray_pos - ld3(P.sph_center);
+    float A = ray_dir.x * ray_dir.x + ray_dir.y * ray_dir.y + ray_dir.z * ray_dir.z;
+    float B = 2 * (ray_dir.x * orig.x + ray_dir.y * orig.y + ray_dir.z * orig.z);
+    float C = orig.x * orig.x + orig.y * orig.y + orig.z * orig.z - P.sph_radius * P.sph_radius;
+    float x1, x2;
+    if (B == 0) {
+        if (A == 0) return false;
+        x1 = 0;
+        x2 = sqrtf(-C / A);
+    } else {
+        float discr = B * B - 4 * A * C;
+        if (discr < 0) return false;
+        float sq = sqrtf(discr);
+        float q = (B < 0.f) ? -0.5f * (B - sq) : -0.5f * (B + sq);
+        x1 = q / A;
+        x2 = C / q;
+    }
+    t_min = x1;
+    t_max = x2;
+    if (t_min > t_max) {
+        float tmp = t_max;
+        t_max = t_min;
+        t_min = tmp;
+    }
+    if (t_min < 0) {
+        t_min = t_max;
+        if (t_min < 0) return false;
+    }
+    return true;
+}
+
+// get_closest_object (render_kernel.cu:1118-1135): 0 none, 1 volume box, 2 sphere
+VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min) {
+    float tmin1 = VPT_M_INF, tmax1 = -VPT_M_INF, tmin2 = VPT_M_INF, tmax2 = -VPT_M_INF;
+    bool i1 = box_intersect(ld3(P.root_pmin), ld3(P.root_pmax), o, inv, tmin1, tmax1);
+    bool i2 = sphere_intersect(P, o, d, tmin2, tmax2);
+    if (i1 && !i2) { t_min = tmin1; return 1; }
+    if (!i1 && i2) { t_min = tmin2; return 2; }
+    if (i1 && i2) {
+        if (tmin1 < tmin2) { t_min = tmin1; return 1; }
+        if (tmin2 < tmin1) { t_min = tmin2; return 2; }
+    }
+    return 0;
+}
+
+// Three-level point location (get_quadrant x3, render_kernel.cu:1102-1115 + :1193-1227).
+// Child boxes follow divide_bbox (bvh_kernels.cu:150-202): child i covers
+//   x: low half for i in {0,2,4,6}, high half otherwise
+//   y: HIGH half for i in {0,1,4,5}, low half otherwise
+//   z: low half for i < 4, high half otherwise
+// and the first child (index order) whose CLOSED box contains p wins.
+enum { LOC_LEAF = 0, LOC_EMPTY = 1, LOC_OUTSIDE = 2 };
+VPT_D int locate(const TraceParams& P, const uint32_t* occ, f3 p, f3& nmin, f3& nmax, int& leaf) {
+    f3 lo = ld3(P.root_pmin), hi = ld3(P.root_pmax);
+    int path = 0;
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        const float hx = (lo.x + hi.x) * 0.5f;
+        const float hy = (lo.y + hi.y) * 0.5f;
+        const float hz = (lo.z + hi.z) * 0.5f;
+        const uint32_t mx = ((p.x >= lo.x && p.x <= hx) ? 0x55u : 0u) | ((p.x >= hx && p.x <= hi.x) ? 0xAAu : 0u);
+        const uint32_t my = ((p.y >= hy && p.y <= hi.y) ? 0x33u : 0u) | ((p.y >= lo.y && p.y <= hy) ? 0xCCu : 0u);
+        const uint32_t mz = ((p.z >= lo.z && p.z <= hz) ? 0x0Fu : 0u) | ((p.z >= hz && p.z <= hi.z) ? 0xF0u : 0u);
+        const uint32_t m = mx & my & mz;
+        if (m == 0) return LOC_OUTSIDE;
+        const int c = __ffs((int)m) - 1;
+        const bool xh = (c & 1) != 0;
+        const bool yh = (c & 2) == 0;
+        const bool zh = (c & 4) != 0;
+        lo.x = xh ? hx : lo.x; hi.x = xh ? hi.x : hx;
+        lo.y = yh ? hy : lo.y; hi.y = yh ? hi.y : hy;
+        lo.z = zh ? hz : lo.z; hi.z = zh ? hi.z : hz;
+        path = path * 8 + c;
+        const int bit = (level == 0 ? 0 : (level == 1 ? 32 : 96)) + path;
+        if (((occ[bit >> 5] >> (bit & 31)) & 1u) == 0) {
+            nmin = lo;
+            nmax = hi;
+            return LOC_EMPTY;
+        }
+    }
+    leaf = path;
+    return LOC_LEAF;
+}
+
+// world -> normalised texture coordinates (render_kernel.cu:987-997)
+VPT_D bool to_unit(const DVolume& v, f3 p, f3& u) {
+    f3 q;
+    q.x = v.m[0] * p.x + v.m[1] * p.y + v.m[2] * p.z + v.m[3];
+    q.y = v.m[4] * p.x + v.m[5] * p.y + v.m[6] * p.z + v.m[7];
+    q.z = v.m[8] * p.x + v.m[9] * p.y + v.m[10] * p.z + v.m[11];
+    q.x = q.x - v.bmin[0];
+    q.y = q.y - v.bmin[1];
+    q.z = q.z - v.bmin[2];
+    u.x = q.x / v.fdim[0];
+    u.y = q.y / v.fdim[1];
+    u.z = q.z / v.fdim[2];
+    return !(u.x < .0f || u.y < .0f || u.z < .0f || u.x > 1.0f || u.y > 1.0f || u.z > 1.0f);
+}
+
+struct Taps {
+    int i0, i1, j0, j1, k0, k1;
+    float ax, ay, az;
+};
+VPT_D Taps make_taps(const DVolume& v, f3 u) {
+    Taps t;
+    float xb = u.x * v.fdim[0] - 0.5f;
+    float yb = u.y * v.fdim[1] - 0.5f;
+    float zb = u.z * v.fdim[2] - 0.5f;
+    float fx = floorf(xb), fy = floorf(yb), fz = floorf(zb);
+    t.ax = xb - fx;
+    t.ay = yb - fy;
+    t.az = zb - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    t.i0 = min(max(i, 0), v.dim[0] - 1);
+    t.i1 = min(max(i + 1, 0), v.dim[0] - 1);
+    t.j0 = min(max(j, 0), v.dim[1] - 1);
+    t.j1 = min(max(j + 1, 0), v.dim[1] - 1);
+    t.k0 = min(max(k, 0), v.dim[2] - 1);
+    t.k1 = min(max(k + 1, 0), v.dim[2] - 1);
+    return t;
+}
+// trilinear f32 fetch: CUDA "linear, normalised, clamp" addressing, fp32 weights, nested
+// lerp x -> y -> z with lerp(a,b,t) = a + t*(b-a)
+VPT_D float fetch_f32(const float* __restrict__ g, const DVolume& v, const Taps& t) {
+    const uint32_t dx = (uint32_t)v.dim[0];
+    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+    const float c000 = g[r00 + t.i0], c100 = g[r00 + t.i1];
+    const float c010 = g[r10 + t.i0], c110 = g[r10 + t.i1];
+    const float c001 = g[r01 + t.i0], c101 = g[r01 + t.i1];
+    const float c011 = g[r11 + t.i0], c111 = g[r11 + t.i1];
+    const float c00 = c000 + (c100 - c000) * t.ax;
+    const float c10 = c010 + (c110 - c010) * t.ax;
+    const float c01 = c001 + (c101 - c001) * t.ax;
+    const float c11 = c011 + (c111 - c011) * t.ax;
+    const float c0 = c00 + (c10 - c00) * t.ay;
+    const float c1 = c01 + (c11 - c01) * t.ay;
+    return c0 + (c1 - c0) * t.az;
+}
+VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
+VPT_D f3 fetch_f4(const f4* __restrict__ g, const DVolume& v, const Taps& t) {
+    const uint32_t dx = (uint32_t)v.dim[0];
+    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+    const f4 c00 = lerp4(g[r00 + t.i0], g[r00 + t.i1], t.ax);
+    const f4 c10 = lerp4(g[r10 + t.i0], g[r10 + t.i1], t.ax);
+    const f4 c01 = lerp4(g[r01 + t.i0], g[r01 + t.i1], t.ax);
+    const f4 c11 = lerp4(g[r11 + t.i0], g[r11 + t.i1], t.ax);
+    return xyz(lerp4(lerp4(c00, c10, t.ay), lerp4(c01, c11, t.ay), t.az));
+}
+
+// one volume's contribution at world position p (get_density / get_color / get_emission)
+template <bool COLOR, bool EMIT, bool COUNT>
+VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
+                         float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e) {
+    f3 u;
+    const bool inside = to_unit(v, p, u);
+    Taps t;
+    if (inside) t = make_taps(v, u);
+    if (want_density) {
+        if (COUNT) n_d++;
+        if (inside) density += fetch_f32(v.density, v, t);
+    }
+    if (COLOR && want_color) {
+        if (!v.has_color) {
+            color = fmax3(color, mk3(1.0f));
+        } else {
+            if (COUNT) n_c++;
+            f3 c = inside ? fetch_f4(v.color, v, t) : mk3(0.0f);
+            color = fmax3(color, c);
+        }
+    }
+    if (EMIT && want_emission) {
+        if (v.has_emission) {
+            if (COUNT) n_e++;
+            if (inside) {
+                float index = fetch_f32(v.emission, v, t);
+                index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
+                const float* e = P.emission_lut + 3 * (int)index;
+                emission += mk3(e[0], e[1], e[2]) * P.emission_scale;
+            }
+        }
+    }
+}
+
+// coordinate_system :92-102, spherical_direction :104-115, sample_hg :306-325 (2 draws)
+VPT_D void sample_hg(f3& wo, Rng& rng, uint32_t& draws, float g) {
+    float cos_theta;
+    if (fabsf(g) < VPT_EPS) cos_theta = 1 - 2 * rnd(rng, draws);
+    else {
+        float sqr_term = (1 - g * g) / (1 - g + 2 * g * rnd(rng, draws));
+        cos_theta = (1 + g * g - sqr_term * sqr_term) / (2 * g);
+    }
+    float sin_theta = sqrtf(fmax_(.0f, 1.0f - cos_theta * cos_theta));
+    float phi = (2.0f * VPT_PI) * rnd(rng, draws);
+    f3 v1 = wo * -1.0f, v2, v3;
+    if (fabsf(v1.x) > fabsf(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x);
+    else v2 = mk3(0.0f, v1.z, -v1.y);
+    v2 = normalize(v2);
+    v3 = normalize(cross(v1, v2));
+    float sp, cp;
+    det_sincosf(phi, &sp, &cp);
+    wo = v2 * sin_theta * cp + v3 * sin_theta * sp + wo * cos_theta;
+}
+
+VPT_D float henyey_greenstein(float cos_theta, float g) {   // light.h:55-64 (pi/4 normalisation kept)
+    float denominator = 1 + g * g - 2 * g * cos_theta;
+    return VPT_PI_4 * (1 - g * g) / (denominator * sqrtf(denominator));
+}
+
+// vanDerCorput (camera.h:49-62): n = int(rand*100) is in [0, 100], so the radical inverse is read
+// from a 101-entry table that the host fills with the reference's own float loop (vdc_table in
+// vpt_host.hip) -- same bits, no data-dependent loop on the device.
+VPT_D float van_der_corput(const float* table, Rng& rng, uint32_t key, uint32_t& draws) {
+    int n = (int)(rnd_simple(rng, key, draws) * 100);
+    return table[n];
+}
+
+}  // namespace vpt

@@ -1,0 +1,496 @@
+// vpt_trace_vol.hip -- the tracer for integrator != 0: the reference's PBRT-style `vol_integrator`
+// (source/render_kernel.cu:1712-1756) with `uniform_sample_one_light` (:1519-1554), `estimate_sun`
+// (:1478), `estimate_point_light` (:1445), `estimate_sky` (:1356-1443: MIS of the environment with
+// `draw_sample_from_distribution` :167-253, `pdf_li` :1342, `sample_spherical` :292,
+// `sample_env_tex` :897, `sample_atmosphere` :839) and `estimate_emission` (:1275), plus the depth
+// pass (`depth_calculator` :1859).
+//
+// Same organisation as vpt_trace.hip (persistent waves, per-lane path state machine, one shared
+// tracking-step body for every walk kind, queue-fed refill, fused depth pass + first walk); only
+// the integrator control flow between walks differs:
+//
+//   for depth = 1 .. ray_depth:                       sample()  -> W_FIRST / W_TRACK
+//       beta *= sample(); black -> stop                         -> T_VTRACK_DONE
+//       on a medium interaction:
+//           one of {sun, point lights, sky} (1 draw)            -> W_TR (1, 11 or <= 2 walks)
+//           + estimate_emission                                 -> W_EMIT
+//           sample_hg                                           -> T_VSCATTER
+//   L += beta * sample_atmosphere(...)                          -> tail kernel (vpt_tail.hip)
+//
+// Exact early-out: a sample() that ends outside the root box makes every later loop iteration a
+// no-op (get_quadrant(root) == -1 -> break before any draw, :1606/:1629), so the path is finished.
+//
+// Random numbers: states draw at most 2 numbers per pass and a pass starts with a refill point
+// (vpt_rng.h), so states that draw never chain inside one pass (`drew`).  By-value rng copies of
+// the reference (Q-list 2: draw_sample_from_distribution :169, sample_spherical :293) are peeks.
+//
+// Arithmetic: the walk, phase sampling and shadow-ray directions are strict; the environment
+// values (sky radiance, HDRI texels, pdf_li's acos/atan2) are value-only (vpt_sky.h) -- their
+// only influence on control flow is the `isBlack(Li)` / `pdf == 0` tests (:1383,:1393,:1416).
+#include <hip/hip_runtime.h>
+
+#include "vpt_sky.h"
+#include "vpt_walk.h"
+
+namespace vpt {
+
+enum : uint32_t {
+    VH_IDLE = 0,
+    VH_W_FIRST = 1,    // delta tracking: depth pass + first integrator walk, fused
+    VH_W_TRACK = 2,    // delta tracking
+    VH_W_TR = 3,       // ratio tracking (shadow ray); tr_next says where to continue
+    VH_W_EMIT = 4,     // emission march
+    VH_W_LAST = 4,
+    VH_T_FIRST = 16,
+    VH_T_FIRST_DONE = 16,
+    VH_T_REPLAY = 17,
+    VH_T_VTRACK_DONE = 18,
+    VH_T_SUN_DONE = 19,
+    VH_T_PL_DONE = 20,
+    VH_T_PL_NEXT = 21,
+    VH_T_SKY_A0 = 22,
+    VH_T_SKY_A1 = 23,
+    VH_T_SKY_B = 24,
+    VH_T_SKY_C = 25,
+    VH_T_SKY_D = 26,
+    VH_T_SKY_END = 27,
+    VH_T_LIGHT_DONE = 28,
+    VH_T_EMIT_DONE = 29,
+    VH_T_SCATTER = 30,
+    VH_T_FINISH = 31,
+};
+
+VPT_D float power_heuristic(float f_pdf, float g_pdf) {      // light.h:65-69 with nf = ng = 1
+    const float f = 1 * f_pdf, g = 1 * g_pdf;
+    return (f * f) / (f * f + g * g);
+}
+VPT_D float tex_f(const DTexture& t, float u, float v) { return tex2d(t, u, v).x; }
+
+// draw_sample_from_distribution :167-253, on a COPY of the rng (2 draws peeked)
+VPT_D float draw_sample_from_distribution(const TraceParams& P, Rng rng, f3& wo) {
+    uint32_t d = 0;
+    const float xi = rnd(rng, d);
+    const float zeta = rnd(rng, d);
+    const int res = P.env_sample_tex_res;
+    int first = 0, len = res;
+    while (len > 0) {
+        const int half = len >> 1, middle = first + half;
+        if (tex_f(P.env_marginal_cdf_tex, (float)middle, 0.0f) <= xi) {
+            first = middle + 1;
+            len -= half + 1;
+        } else len = half;
+    }
+    const int v = min(max(first - 1, 0), res - 2);
+    float dv = xi - tex_f(P.env_marginal_cdf_tex, (float)v, 0.0f);
+    const float d_cdf_marginal = tex_f(P.env_marginal_cdf_tex, (float)(v + 1), 0.0f) - tex_f(P.env_marginal_cdf_tex, (float)v, 0.0f);
+    if (d_cdf_marginal > .0f) dv /= d_cdf_marginal;
+    const float marginal_pdf = tex_f(P.env_marginal_func_tex, v + dv, 0.0f) / P.env_marginal_int;
+    const float theta = (((float)v + dv) / (float)res) * VPT_PI;
+    first = 0, len = res;
+    while (len > 0) {
+        const int half = len >> 1, middle = first + half;
+        if (tex_f(P.env_cdf_tex, (float)middle, (float)v) <= zeta) {
+            first = middle + 1;
+            len -= half + 1;
+        } else len = half;
+    }
+    const int u = min(max(first - 1, 0), res - 2);
+    float du = zeta - tex_f(P.env_cdf_tex, (float)u, (float)v);
+    const float d_cdf_conditional = tex_f(P.env_cdf_tex, (float)(u + 1), (float)v) - tex_f(P.env_cdf_tex, (float)u, (float)v);
+    if (d_cdf_conditional > 0) du /= d_cdf_conditional;
+    const float conditional_pdf = tex_f(P.env_func_tex, u + du, (float)v) / tex_f(P.env_marginal_func_tex, (float)v, 0.0f);
+    const float phi = (((float)u + du) / (float)res) * VPT_PI * 2.0f;
+    float sin_theta, cos_theta, sin_phi, cos_phi;
+    det_sincosf(theta, &sin_theta, &cos_theta);
+    det_sincosf(phi, &sin_phi, &cos_phi);
+    wo = normalize(mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+    return (marginal_pdf * conditional_pdf) / (2 * VPT_PI * VPT_PI * sin_theta);
+}
+// pdf_li :1342-1354 + draw_pdf_from_distribution :258-269 (INV_2_PI / INV_PI are unparenthesised
+// macros, Q-list 12; the coordinates really are divided by 2 pi^2 sin(theta))
+VPT_D float pdf_li(const TraceParams& P, f3 wi) {
+    const float theta = acosf(clampf(wi.y, -1.0f, 1.0f));
+    const float phi = atan2f(wi.z, wi.x);
+    const float sin_theta = sinf(theta);
+    if (sin_theta == .0f) return .0f;
+    const float denom = 2.0f * VPT_PI * VPT_PI * sin_theta;
+    const float px = (phi * 1.0f / (2.0f * VPT_PI)) / denom, py = (theta * 1.0f / VPT_PI) / denom;
+    const int res = P.env_sample_tex_res;
+    const int iu = min(max((int)(px * res), 0), res - 1);
+    const int iv = min(max((int)(py * res), 0), res - 1);
+    return tex_f(P.env_func_tex, (float)iu, (float)iv) / tex_f(P.env_marginal_func_tex, (float)iv, 0.0f);
+}
+// sample_spherical :292-303, on a COPY of the rng (2 draws peeked)
+VPT_D float sample_spherical(Rng rng, f3& wi) {
+    uint32_t d = 0;
+    const float phi = (2.0f * VPT_PI) * rnd(rng, d);
+    const float cos_theta = 1.0f - 2.0f * rnd(rng, d);
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float sp, cp;
+    det_sincosf(phi, &sp, &cp);
+    wi = mk3(cp * sin_theta, sp * sin_theta, cos_theta);
+    return 1.0f / (4.0f * VPT_PI);
+}
+
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
+__global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) {
+    __shared__ uint32_t s_occ[20];
+    __shared__ float s_hist[VPT_HIST_CAP * 256];
+    if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t total = *P.queue_count;
+    const int lane = __lane_id();
+    const WalkConst K = make_walk_const(P);
+    const f3 sun_dir = ld3(P.sun_dir);
+    const uint32_t regen_min = P.regen_min;
+    const uint32_t trans_min = P.trans_min;
+    const Sky<TraceParams> sky = {P};
+
+    uint32_t phase = VH_IDLE;
+    uint32_t tr_next = VH_IDLE;     // state entered when the current shadow walk ends
+    uint32_t pixel = 0, kiter = 0;
+    Rng rng;
+    rng.c0 = rng.o0 = rng.o1 = rng.o2 = rng.o3 = rng.idx = rng.carry = rng.has_carry = 0u;
+    uint32_t draws = 0, cam_draws = 0;
+    Walk w;
+    w.pos = w.dir = w.inv = mk3(0.0f);
+    w.t = w.distance = 0.0f;
+    w.trw = 1.0f;
+    w.alpha = 0.0f;
+    w.wgt = mk3(1.0f);
+    w.Ld = mk3(0.0f);
+    w.mi = w.geo = w.obj2 = false;
+    f3 ppos = mk3(0.0f), pdir = mk3(0.0f);      // path ray parked during shadow / emission walks
+    f3 org0 = mk3(0.0f), dir0 = mk3(0.0f);
+    f3 beta = mk3(1.0f), L = mk3(0.0f);
+    f3 Lsel = mk3(0.0f);                        // what the selected light estimator returned
+    f3 A = mk3(0.0f);                           // beta * uniform_sample_one_light(...)
+    f3 Li = mk3(0.0f), wi = mk3(0.0f);          // estimate_sky scratch
+    float light_pdf = 0.0f, phase_pdf = 0.0f, mis_w = 0.0f;
+    float depth = 0.0f, t_box = 0.0f;
+    int vdepth = 0, budget = 0, light_index = 0;
+    uint32_t n_hist = 0;
+    WalkCounts cnt;
+    cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
+    bool more = true;
+    uint32_t chunk_next = 0, chunk_end = 0;
+
+    for (;;) {
+        // ==== refill idle lanes from the compacted ray queue (as in vpt_trace.hip) ============
+        const unsigned long long idle = __ballot(phase == VH_IDLE);
+        if (idle != 0ull) {
+            const unsigned long long active = __ballot(1);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
+                const int leader = __ffsll((long long)active) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(P.work_counter, (uint32_t)VPT_CHUNK);
+                base = __shfl(base, leader);
+                chunk_next = min(base, total);
+                chunk_end = min(base + (uint32_t)VPT_CHUNK, total);
+                if (chunk_end == total) more = false;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            if (avail == 0u && !more && idle == active) break;
+            if (avail != 0u && (n_idle >= regen_min || idle == active)) {
+                const uint32_t first = chunk_next;
+                chunk_next += min(n_idle, avail);
+                if (phase == VH_IDLE) {
+                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    if (rank < avail) {
+                        const uint32_t slot = P.queue[first + rank];
+                        kiter = slot / P.n_pixels;
+                        pixel = slot - kiter * P.n_pixels;
+                        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                        const float4* src = reinterpret_cast<const float4*>(P.records + slot);
+                        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                        org0 = mk3(q0.x, q0.y, q0.z);
+                        dir0 = mk3(q1.x, q1.y, q1.z);
+                        const int obj = (int)__float_as_uint(q1.w);      // get_closest_object of the primary ray
+                        rng.o0 = __float_as_uint(q2.x); rng.o1 = __float_as_uint(q2.y);
+                        rng.o2 = __float_as_uint(q2.z); rng.o3 = __float_as_uint(q2.w);
+                        rng.c0 = __float_as_uint(q3.x);
+                        rng.idx = __float_as_uint(q3.y);
+                        rng.carry = 0u; rng.has_carry = 0u;
+                        depth = q3.z;
+                        t_box = q3.w;
+                        draws = rng.c0 * 4u + rng.idx - iteration * 4096u;
+                        cam_draws = draws;
+                        // vol_integrator :1732-1737: every queued ray hits the root box
+                        w.alpha = 0.0f;
+                        w.dir = dir0;
+                        w.inv = rcp3(w.dir);
+                        w.pos = org0 + w.dir * (t_box + VPT_EPS);
+                        L = mk3(0.0f);
+                        beta = mk3(1.0f);
+                        vdepth = 1;
+                        w.mi = false;
+                        w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                        n_hist = 0;
+                        cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
+                        // depth_calculator (:1875-1881) walks the very same segment with the same
+                        // rng copy iff the box is the closest object (then t_min == t_box)
+                        phase = obj == 1 ? VH_W_FIRST : VH_W_TRACK;
+                    }
+                }
+            }
+        }
+
+        // ==== one tracking step for every walking lane =====================================
+        rng_top_up(rng, pixel);
+        if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
+            const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt);
+            if (done) {
+                if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
+                else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
+                else if (phase == VH_W_EMIT) phase = VH_T_EMIT_DONE;
+                else {
+                    w.trw = tr_end(K, w);
+                    phase = tr_next;
+                }
+            }
+        }
+
+        // ==== transitions ===================================================================
+        const unsigned long long tmask = __ballot(phase >= VH_T_FIRST);
+        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= VH_W_FIRST && phase <= VH_W_LAST));
+        while (run_trans && __any(phase >= VH_T_FIRST)) {
+            rng_top_up(rng, pixel);
+            bool drew = false;            // this lane consumed / peeked random numbers in this pass
+            bool start_tr = false;
+            f3 tr_dir = mk3(0.0f);
+            uint32_t tr_done = VH_IDLE;
+
+            if (phase == VH_T_FIRST_DONE) {
+                depth = w.mi ? length(org0 - w.pos) : .0f;                          // :1879-1881
+                // vol_integrator's first sample() (:1740) adds the same densities to Alpha again
+                if (w.alpha < 1.0f) {
+                    if (n_hist > VPT_HIST_CAP) {
+                        phase = VH_T_REPLAY;
+                    } else {
+                        for (uint32_t i = 0; i < n_hist; ++i)
+                            if (w.alpha < 1.0f) w.alpha += s_hist[i * 256 + threadIdx.x];
+                    }
+                }
+                if (phase == VH_T_FIRST_DONE) {
+                    if (COUNT) { cnt.n_d += cnt.n_d; cnt.n_c += cnt.n_c; cnt.n_steps += cnt.n_steps; cnt.n_skips += cnt.n_skips; }
+                    phase = VH_T_VTRACK_DONE;
+                }
+            }
+            if (phase == VH_T_REPLAY) {
+                // history overflow: walk the integrator's first segment for real
+                const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                rng_init(rng, pixel, iteration * 4096u + cam_draws);
+                draws = cam_draws;
+                w.dir = dir0;
+                w.inv = rcp3(w.dir);
+                w.pos = org0 + w.dir * (t_box + VPT_EPS);
+                w.mi = false;
+                w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                phase = VH_W_TRACK;
+            }
+            if (phase == VH_T_VTRACK_DONE) {
+                // :1740-1747
+                beta *= w.wgt;
+                if (is_black(beta)) {
+                    phase = VH_T_FINISH;
+                } else if (!w.mi) {
+                    // no interaction: either the walk left the root box (every later sample() is a
+                    // no-op) or it stopped at the sphere / exit distance inside the box (:1654) and
+                    // the next loop iteration walks again from here
+                    vdepth++;
+                    f3 nmin, nmax;
+                    int leaf;
+                    if (vdepth > P.ray_depth || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
+                        phase = VH_T_FINISH;
+                    } else {
+                        w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                        phase = VH_W_TRACK;
+                    }
+                } else {
+                    // uniform_sample_one_light :1531-1551 (1 draw)
+                    ppos = w.pos;
+                    pdir = w.dir;
+                    const float light_num = rnd(rng, draws) * 3;
+                    drew = true;
+                    Lsel = mk3(0.0f);
+                    if (light_num < 1) {
+                        if (P.sun_mult > .0f) { start_tr = true; tr_dir = sun_dir; tr_done = VH_T_SUN_DONE; phase = VH_W_TR; }
+                        else phase = VH_T_LIGHT_DONE;
+                    } else if (light_num >= 1 && light_num < 2) {
+                        if (P.num_lights > 0) {
+                            budget = 10;                                            // :1459
+                            w.Ld = mk3(0.0f);
+                            phase = VH_T_PL_NEXT;
+                        } else phase = VH_T_LIGHT_DONE;
+                    } else {
+                        if (P.sky_mult > .0f) {
+                            w.Ld = mk3(0.0f);
+                            phase = VH_T_SKY_A0;
+                        } else phase = VH_T_LIGHT_DONE;
+                    }
+                }
+            } else if (phase == VH_T_SUN_DONE) {
+                // estimate_sun :1478-1516
+                const float cos_theta = dot(pdir, sun_dir);
+                const float pp = henyey_greenstein(cos_theta, P.phase_g1);
+                Lsel = (mk3(w.trw) * pp) * ld3(P.sun_color) * P.sun_mult;
+                phase = VH_T_LIGHT_DONE;
+            } else if (phase == VH_T_PL_DONE) {
+                if (budget < P.num_lights) {
+                    const DPointLight& lt = P.lights[light_index];                  // point_light::Le, light.h:104-121
+                    const f3 lp = ld3(lt.pos);
+                    const f3 wl = normalize(lp - ppos);
+                    const float cos_theta = dot(pdir, wl);
+                    const float pp = henyey_greenstein(cos_theta, P.phase_g1);
+                    const float sqr_dist = length(lp * lp - ppos * ppos);
+                    const float falloff = 1 / sqr_dist;
+                    w.Ld += ld3(lt.color) * lt.power * mk3(w.trw) * pp * falloff;
+                }
+                budget--;
+                if (budget >= 0) phase = VH_T_PL_NEXT;
+                else {
+                    Lsel = w.Ld;
+                    phase = VH_T_LIGHT_DONE;
+                }
+            }
+            if (phase == VH_T_PL_NEXT && !drew) {
+                // estimate_point_light :1461-1466 (1 draw)
+                light_index = (int)floorf(rnd(rng, draws) * P.num_lights);
+                drew = true;
+                if (light_index > P.num_lights - 1) light_index = P.num_lights - 1;  // rand()==1.0f guard
+                start_tr = true; tr_dir = normalize(ld3(P.lights[light_index].pos) - ppos); tr_done = VH_T_PL_DONE; phase = VH_W_TR;
+            } else if (phase == VH_T_SKY_A0 && !drew) {
+                // estimate_sky :1373-1374: two draws that are never used
+                (void)rnd(rng, draws);
+                (void)rnd(rng, draws);
+                drew = true;
+                phase = VH_T_SKY_A1;
+            } else if (phase == VH_T_SKY_A1 && !drew) {
+                // light sampling :1378-1402; the samplers work on a copy of the rng (peek)
+                drew = true;
+                if (P.environment_type == 0) {
+                    light_pdf = draw_sample_from_distribution(P, rng, wi);
+                    Li = sky.sample(ppos, wi, sun_dir);
+                } else {
+                    light_pdf = sample_spherical(rng, wi);
+                    Li = env_lookup(P.env_tex, wi);
+                }
+                phase = VH_T_SKY_C;
+                if (light_pdf > .0f && !is_black(Li)) {
+                    phase_pdf = henyey_greenstein(dot(pdir, wi), P.phase_g1);
+                    if (phase_pdf > .0f) { start_tr = true; tr_dir = wi; tr_done = VH_T_SKY_B; phase = VH_W_TR; }
+                }
+            } else if (phase == VH_T_SKY_B) {
+                Li *= mk3(w.trw);
+                if (!is_black(Li)) {
+                    const float weight = power_heuristic(light_pdf, phase_pdf);
+                    w.Ld += Li * phase_pdf * weight / light_pdf;
+                }
+                phase = VH_T_SKY_C;
+            }
+            if (phase == VH_T_SKY_C && !drew) {
+                // phase-function sampling :1404-1431 (2 draws)
+                wi = pdir;
+                phase_pdf = sample_hg_pdf(wi, rng, draws, P.phase_g1);
+                drew = true;
+                phase = VH_T_SKY_END;
+                if (phase_pdf > .0f) {
+                    light_pdf = P.environment_type == 0 ? pdf_li(P, wi) : 1.0f / (4.0f * VPT_PI);
+                    if (light_pdf != 0.0f) {                                        // :1416 `return Ld`
+                        mis_w = power_heuristic(phase_pdf, light_pdf);
+                        start_tr = true; tr_dir = wi; tr_done = VH_T_SKY_D; phase = VH_W_TR;
+                    }
+                }
+            } else if (phase == VH_T_SKY_D) {
+                Li = P.environment_type == 0 ? sky.sample(ppos, wi, sun_dir) : env_lookup(P.env_tex, wi);
+                if (!is_black(Li)) w.Ld += Li * mk3(w.trw) * mis_w;
+                phase = VH_T_SKY_END;
+            }
+            if (phase == VH_T_SKY_END) {
+                Lsel = w.Ld * P.sky_mult;                                           // :1548
+                phase = VH_T_LIGHT_DONE;
+            }
+            if (phase == VH_T_LIGHT_DONE) {
+                A = beta * (Lsel * 3.0f);                                           // :1553, :1745
+                w.pos = ppos;
+                w.dir = pdir;
+                w.inv = rcp3(w.dir);
+                if (EMIT && P.emission_scale != 0) {                                // :1285
+                    w.t = 0.0f;
+                    w.Ld = mk3(0.0f);
+                    phase = VH_W_EMIT;
+                } else {
+                    L += A + mk3(0.0f);
+                    phase = VH_T_SCATTER;
+                }
+            } else if (phase == VH_T_EMIT_DONE) {
+                L += A + w.Ld;                                                      // :1745
+                w.pos = ppos;
+                w.dir = pdir;
+                phase = VH_T_SCATTER;
+            }
+            if (phase == VH_T_SCATTER && !drew) {
+                sample_hg(w.dir, rng, draws, P.phase_g1);                           // :1746 (2 draws)
+                drew = true;
+                w.inv = rcp3(w.dir);
+                vdepth++;
+                if (vdepth > P.ray_depth) phase = VH_T_FINISH;
+                else {
+                    w.mi = false;
+                    w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                    phase = VH_W_TRACK;
+                }
+            }
+            if (phase == VH_T_FINISH) {
+                const f3 od = normalize(w.dir);                                     // :1750
+                const f3 op = length(beta) > 0.9999f ? org0 : w.pos;                // :1753
+                float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
+                dst[0] = make_float4(L.x, L.y, L.z, fmin_(w.alpha, 1.0f));         // :1755
+                dst[1] = make_float4(beta.x, beta.y, beta.z, depth);
+                dst[2] = make_float4(op.x, op.y, op.z, __uint_as_float(1u));
+                dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
+                if (COUNT) {
+                    atomicAdd(&P.counters->samples, 1ull);
+                    atomicAdd(&P.counters->density_lookups, (unsigned long long)cnt.n_d);
+                    atomicAdd(&P.counters->color_lookups, (unsigned long long)cnt.n_c);
+                    atomicAdd(&P.counters->emission_lookups, (unsigned long long)cnt.n_e);
+                    atomicAdd(&P.counters->tracking_steps, (unsigned long long)cnt.n_steps);
+                    atomicAdd(&P.counters->skip_steps, (unsigned long long)cnt.n_skips);
+                }
+                phase = VH_IDLE;
+            }
+
+            if (start_tr) {
+                if (tr_begin(P, K, w, ppos, tr_dir)) {
+                    tr_next = tr_done;
+                    phase = VH_W_TR;
+                } else {
+                    phase = tr_done;
+                }
+            }
+        }
+    }
+}
+
+template <bool MULTI, bool COLOR, bool EMIT>
+static hipError_t launch_vol_variant(const TraceParams& P, int blocks, hipStream_t stream) {
+    if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<MULTI, COLOR, EMIT, true>), dim3(blocks), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((trace_vol_kernel<MULTI, COLOR, EMIT, false>), dim3(blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream) {
+    if (!multi && !color && !emit) return launch_vol_variant<false, false, false>(P, blocks, stream);
+    if (!multi && !color && emit) return launch_vol_variant<false, false, true>(P, blocks, stream);
+    if (!multi && color && !emit) return launch_vol_variant<false, true, false>(P, blocks, stream);
+    if (!multi && color && emit) return launch_vol_variant<false, true, true>(P, blocks, stream);
+    if (multi && !color && !emit) return launch_vol_variant<true, false, false>(P, blocks, stream);
+    if (multi && !color && emit) return launch_vol_variant<true, false, true>(P, blocks, stream);
+    if (multi && color && !emit) return launch_vol_variant<true, true, false>(P, blocks, stream);
+    return launch_vol_variant<true, true, true>(P, blocks, stream);
+}
+
+}  // namespace vpt

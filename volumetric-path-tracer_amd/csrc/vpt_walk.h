@@ -1,0 +1,169 @@
+// vpt_walk.h -- ONE tracking step of any walk kind, shared by the tracer kernels (vpt_trace.hip:
+// direct_integrator, vpt_trace_vol.hip: vol_integrator): delta tracking `sample`
+// (render_kernel.cu:1556), ratio tracking `Tr` (:1138), emission march `estimate_emission` (:1275),
+// plus the Tr prologue / epilogue.  Strict arithmetic (vpt_math.h).
+#pragma once
+
+#include "vpt_trace_common.h"
+
+namespace vpt {
+
+// sample_hg that also returns the phase value the reference returns (henyey_greenstein(-cos_theta, g),
+// :324) -- estimate_sky uses it (:1404)
+VPT_D float sample_hg_pdf(f3& wo, Rng& rng, uint32_t& draws, float g) {
+    float cos_theta;
+    if (fabsf(g) < VPT_EPS) cos_theta = 1 - 2 * rnd(rng, draws);
+    else {
+        float sqr_term = (1 - g * g) / (1 - g + 2 * g * rnd(rng, draws));
+        cos_theta = (1 + g * g - sqr_term * sqr_term) / (2 * g);
+    }
+    float sin_theta = sqrtf(fmax_(.0f, 1.0f - cos_theta * cos_theta));
+    float phi = (2.0f * VPT_PI) * rnd(rng, draws);
+    f3 v1 = wo * -1.0f, v2, v3;
+    if (fabsf(v1.x) > fabsf(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x);
+    else v2 = mk3(0.0f, v1.z, -v1.y);
+    v2 = normalize(v2);
+    v3 = normalize(cross(v1, v2));
+    float sp, cp;
+    det_sincosf(phi, &sp, &cp);
+    wo = v2 * sin_theta * cp + v3 * sin_theta * sp + wo * cos_theta;
+    return henyey_greenstein(-cos_theta, g);
+}
+
+// Constants of a launch that every step needs (kept in SGPRs).
+struct WalkConst {
+    f3 root_lo, root_hi;
+    float inv_max;        // 1 / root->max_extinction                         (:1645)
+    float inv_dm;         // 1 / density_mult                                 (:1646)
+    float sigma_c;        // control variate = root->min_extinction           (:1164)
+    float sigma_r_inv;    // 1 / (max_extinction - sigma_c)                   (:1165)
+};
+VPT_D WalkConst make_walk_const(const TraceParams& P) {
+    WalkConst K;
+    K.root_lo = ld3(P.root_pmin);
+    K.root_hi = ld3(P.root_pmax);
+    K.inv_max = 1.0f / P.max_ext;
+    K.inv_dm = 1.0f / P.density_mult;
+    K.sigma_c = P.min_ext;
+    K.sigma_r_inv = 1.0f / (P.max_ext - K.sigma_c);
+    return K;
+}
+
+// Per-lane walk state.  The same body serves the three walk kinds, so a wave runs it with lanes
+// in different paths, bounces and walk kinds side by side:
+//   WALK_SAMPLE  delta tracking (`sample` :1603-1678): may end in a real collision (mi, wgt)
+//   WALK_TR      ratio tracking (`Tr` :1169-1265): multiplies trw
+//   WALK_EMIT    emission march (`estimate_emission` :1287-1337): adds to Ld
+enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
+struct Walk {
+    f3 pos, dir, inv;     // walk ray (inv = 1 / dir)
+    float t;              // cumulative step (Q-list 1: never reset inside a walk)
+    float distance;       // exit distance / distance to the sphere
+    float trw;            // running transmittance of a Tr walk
+    float alpha;          // `tr` of volume_rt_kernel (:2251), fed to sample() as Alpha
+    f3 wgt;               // return value of sample()
+    f3 Ld;                // emission sum / light sum
+    bool mi, geo, obj2;
+};
+struct WalkCounts {
+    uint32_t n_d, n_c, n_e, n_steps, n_skips;
+};
+
+// Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
+// the fused first walk (record_hist), stride 256 floats.
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
+VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
+                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c) {
+    const bool is_sample = kind == WALK_SAMPLE;
+    const bool is_emit = EMIT && kind == WALK_EMIT;
+    f3 nmin, nmax;
+    int leaf = 0;
+    const int st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
+    if (st == LOC_OUTSIDE) return true;
+    if (st == LOC_EMPTY) {
+        // empty node: push to its far side, at least 0.1 (:1613-1616)
+        float t_min, t_max;
+        box_intersect(nmin, nmax, w.pos, w.inv, t_min, t_max);
+        t_max = fmax_(t_max, 0.1f);
+        w.pos += w.dir * t_max;
+        if (COUNT) c.n_skips++;
+        return false;
+    }
+    if (is_sample) {
+        // :1647-1651
+        float t_min, t_max, geo_dist;
+        box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, w.distance);
+        if (sphere_intersect(P, w.pos, w.dir, geo_dist, t_max)) {
+            w.distance = geo_dist;
+            w.geo = true;
+        }
+    }
+    const float lg = det_logf(1 - rnd(rng, draws));
+    if (COUNT) c.n_steps++;
+    if (is_sample) w.t -= lg * K.inv_max * K.inv_dm;                          // :1652
+    else if (is_emit) w.t -= lg * K.inv_max * P.tr_depth / P.extinction[0];   // :1331
+    else w.t -= lg * K.sigma_r_inv * P.tr_depth;                              // :1231
+    if (!is_emit && w.t >= w.distance) {
+        if (is_sample && w.geo) w.obj2 = true;                                // :1654-1657
+        return true;
+    }
+    w.pos += w.dir * w.t;                                                     // cumulative t (Q-list 1)
+    if (!contains(K.root_lo, K.root_hi, w.pos)) return true;
+    float density = 0.0f;
+    f3 Cd = COLOR ? mk3(0.0f) : mk3(1.0f);
+    f3 em = mk3(0.0f);
+    if (!MULTI) {
+        lookup_volume<COLOR, EMIT, COUNT>(P, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+    } else {
+        const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
+        for (uint32_t q = b; q < e; ++q) {
+            const DVolume& v = P.volumes[P.leaf_indices[q]];
+            lookup_volume<COLOR, EMIT, COUNT>(P, v, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+        }
+    }
+    if (is_sample) {
+        // :1667-1675
+        int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
+        const float* dc = P.density_color_lut + 3 * index;
+        if (w.alpha < 1.0f) w.alpha += density;
+        if (record_hist) {
+            if (n_hist < VPT_HIST_CAP) hist[n_hist * 256] = density;
+            n_hist++;
+        }
+        if (density * K.inv_max > rnd(rng, draws)) {
+            w.mi = true;
+            w.wgt = (ld3(P.albedo) * Cd * mk3(dc[0], dc[1], dc[2]) / ld3(P.extinction)) * P.energy_inject;
+            return true;
+        }
+    } else if (is_emit) {
+        w.Ld += em;                                                           // :1335
+    } else {
+        w.trw *= 1 - ((density - K.sigma_c) * K.sigma_r_inv);                 // :1239
+        const float s2 = w.trw * w.trw;
+        if (sqrtf(s2 + s2 + s2) < VPT_EPS) return true;                       // :1261
+    }
+    return false;
+}
+
+// Tr prologue :1153-1167 (shared by sun / point-light / sky / sphere shadow rays): returns true
+// when a walk is needed; otherwise w.trw holds the result (1: misses the box, 0: sphere in the way)
+VPT_D bool tr_begin(const TraceParams& P, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
+    w.pos = from;
+    w.dir = tr_dir;
+    w.inv = rcp3(tr_dir);
+    float t_min, t_max;
+    if (!contains(K.root_lo, K.root_hi, w.pos)) {
+        if (box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, t_max)) w.pos += w.dir * (t_min + VPT_EPS);
+        else { w.trw = 1.0f; return false; }
+    }
+    float geo_dist;
+    box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, w.distance);
+    if (sphere_intersect(P, w.pos, w.dir, geo_dist, t_max)) { w.trw = 0.0f; return false; }   // :1160
+    w.t = 0.0f;
+    w.trw = 1.0f;
+    return true;
+}
+// Tr epilogue :1166,:1267
+VPT_D float tr_end(const WalkConst& K, const Walk& w) { return clampf(w.trw * expf(-K.sigma_c * w.distance), .0f, 1.0f); }
+
+}  // namespace vpt

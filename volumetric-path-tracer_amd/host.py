@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
     "vpt_atmosphere_default_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
+    "vpt_env_cdf_build", "vpt_env_cdf_create",
     "vpt_camera_update", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
 ]
 
@@ -83,6 +84,8 @@ def load_library(path=None):
     lib.vpt_atmosphere_default_model.argtypes = [C.POINTER(AtmosphereParameters)]
     lib.vpt_atmosphere_precompute.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp]
     lib.vpt_atmosphere_read_lut.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp, C.c_size_t]
+    lib.vpt_env_cdf_build.argtypes = [C.POINTER(KernelParams), C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    lib.vpt_env_cdf_create.argtypes = [vp, C.POINTER(KernelParams)]
     # test probes (include/vpt_testhooks.h)
     lib.vpt_test_host_math.argtypes = [C.c_int, vp, vp, C.c_int]
     lib.vpt_test_device_math.argtypes = [vp, C.c_int, vp, vp, C.c_int]
@@ -95,6 +98,22 @@ def load_library(path=None):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def env_cdf_build(kp, res=180, lib=None):
+    """create_cdf's tables (main.cpp:647-757) as numpy arrays: dict(val, func, cdf, marginal_func,
+    marginal_cdf, marginal_int, res).  Host only."""
+    lib = lib or load_library()
+    val = np.zeros((res, res, 4), np.float32)
+    func = np.zeros((res, res), np.float32)
+    cdf = np.zeros((res, res), np.float32)
+    mf = np.zeros(res, np.float32)
+    mc = np.zeros(res, np.float32)
+    mi = C.c_float()
+    rc = lib.vpt_env_cdf_build(C.byref(kp), int(res), _np_ptr(val), _np_ptr(func), _np_ptr(cdf), _np_ptr(mf), _np_ptr(mc), C.byref(mi))
+    if rc != 0:
+        raise VptError("vpt_env_cdf_build -> %s" % abi.E_NAMES.get(rc, rc))
+    return dict(val=val, func=func, cdf=cdf, marginal_func=mf, marginal_cdf=mc, marginal_int=float(mi.value), res=int(res))
 
 
 class Context:

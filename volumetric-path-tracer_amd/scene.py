@@ -110,6 +110,7 @@ class SceneDesc:
         self.atmosphere = AtmosphereParameters()
         self.atm_luts = None       # dict transmittance/irradiance/scattering/single_mie numpy float4 arrays
         self.env_map = None        # numpy [h, w, 4]
+        self.env_cdf = None        # host.env_cdf_build() tables (integrator != 0 on the procedural sky)
         self.blue_noise = None     # numpy [65536, 3]
         self.emission_lut = None   # numpy [256, 3]
         self.density_color_lut = None
@@ -157,6 +158,18 @@ def dragon_scene(width, height, config="c1", lib=None):
     sd.emission_lut = np.ascontiguousarray(luts["blackbody"], np.float32)
     sd.density_color_lut = np.ascontiguousarray(luts["density_color"], np.float32)
     return sd
+
+
+def bind_env_cdf(kp, t, make_texture):
+    """the five sampler states of create_cdf (main.cpp:775-867) on either backend"""
+    wc = (abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_WRAP)
+    kp.sky_tex = make_texture(t["val"], 4, address=wc)
+    kp.env_func_tex = make_texture(t["func"], 1, normalized=False, linear=False, address=wc)
+    kp.env_cdf_tex = make_texture(t["cdf"], 1, normalized=False, linear=False, address=wc)
+    kp.env_marginal_func_tex = make_texture(t["marginal_func"], 1, normalized=False, linear=False, address=wc)
+    kp.env_marginal_cdf_tex = make_texture(t["marginal_cdf"], 1, normalized=False, linear=False, address=wc)
+    kp.env_sample_tex_res = int(t["res"])
+    kp.env_marginal_int = float(t["marginal_int"])
 
 
 class HipBinding:
@@ -211,6 +224,8 @@ class HipBinding:
             self.atmosphere.single_mie_scattering_texture = ctx.texture(L["single_mie"], 4)
         if sd.env_map is not None:
             kp.env_tex = ctx.texture(sd.env_map, 4, address=(abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_CLAMP))
+        if sd.env_cdf is not None:
+            bind_env_cdf(kp, sd.env_cdf, ctx.texture)
         self._lights_arr = (PointLight * max(1, len(sd.lights)))(*sd.lights)
         self.lights = LightList(len(sd.lights), C.cast(self._lights_arr, C.POINTER(PointLight)))
         # buffers were filled on torch's stream; the ctx renders on its own stream
