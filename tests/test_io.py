@@ -1,0 +1,331 @@
+"""The native readers / writers of include/vpt_io.h (csrc/vpt_io.hip) -- host code, no GPU."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import vdb_writer_py as W
+
+ASSETS = "/root/reference/assets"
+has_assets = os.path.exists(os.path.join(ASSETS, "dragon.vdb"))
+
+
+def _leaf(rng, ncomp, fill=0.6):
+    mask = rng.random(512) < fill
+    vals = rng.random((512, ncomp)).astype(np.float32) + 0.01
+    vals[~mask] = 0.0
+    return vals, mask
+
+
+def _dense_from(leaves, tiles3, ncomp, bg=0.0):
+    pts = []
+    for o, (vals, mask) in leaves.items():
+        n = np.flatnonzero(mask)
+        pts.append(np.stack([o[0] + (n >> 6), o[1] + ((n >> 3) & 7), o[2] + (n & 7)], 1))
+    for o in tiles3:
+        pts.append(np.array([o, np.array(o) + 7]))
+    pts = np.concatenate(pts)
+    lo, hi = pts.min(0), pts.max(0)
+    dim = hi - lo + 1
+    d = np.full((dim[2], dim[1], dim[0], ncomp), bg, np.float32)
+    for o, v in tiles3.items():
+        s = np.maximum(np.array(o) - lo, 0); e = np.minimum(np.array(o) + 8 - lo, dim)
+        d[s[2]:e[2], s[1]:e[1], s[0]:e[0]] = v
+    for o, (vals, mask) in leaves.items():
+        for n in range(512):
+            p = np.array([o[0] + (n >> 6), o[1] + ((n >> 3) & 7), o[2] + (n & 7)]) - lo
+            if (p >= 0).all() and (p < dim).all():
+                d[p[2], p[1], p[0]] = vals[n]
+    return d, lo, hi
+
+
+@pytest.mark.parametrize("flags", [0, W.ZIP, W.ACTIVE_MASK, W.ZIP | W.ACTIVE_MASK])
+def test_vdb_reader_on_synthetic_files(pkg, tmp_path, flags):
+    """density + heat + Cd grids, leaves spread over two Internal4 nodes and two root children
+    (negative coordinates), an active 8^3 tile, every compression framing."""
+    rng = np.random.default_rng(3 + flags)
+    dl = {(0, 0, 0): _leaf(rng, 1), (8, 0, 16): _leaf(rng, 1), (136, 8, 0): _leaf(rng, 1), (-8, -16, -8): _leaf(rng, 1, 0.3)}
+    tiles = {(16, 8, 8): np.float32(0.75)}
+    hl = {(0, 0, 0): _leaf(rng, 1), (8, 0, 16): _leaf(rng, 1)}                 # heat: a smaller active bbox
+    cl = {(0, 0, 0): _leaf(rng, 3), (8, 0, 16): _leaf(rng, 3), (136, 8, 0): _leaf(rng, 3)}
+    path = str(tmp_path / "t.vdb")
+    W.write_vdb(path, [
+        dict(name="density", type="float", leaves=dl, tiles3=tiles, flags=flags, map_values=W.uniform_scale(0.25)),
+        dict(name="heat", type="float", leaves=hl, flags=flags, map_values=W.uniform_scale(0.25)),
+        dict(name="Cd", type="vec3s", leaves=cl, flags=flags, map_values=W.uniform_scale(0.25)),
+        dict(name="vel", type="vec3s", leaves={(0, 0, 0): _leaf(rng, 3)}, flags=flags, map_values=W.uniform_scale(0.25)),   # skipped
+    ])
+    v = pkg.io.VdbFile(path)
+    ref, lo, hi = _dense_from(dl, tiles, 1)
+    d = v.grid(0)
+    np.testing.assert_array_equal(d, ref[..., 0])
+    i = v.info.vdb_info
+    assert (i.dim.x, i.dim.y, i.dim.z) == tuple(hi - lo + 1) and i.bmin.tuple() == tuple(map(float, lo)) and i.bmax.tuple() == tuple(map(float, hi))
+    assert i.max_density == ref.max() and i.min_density == np.float32(1.1920929e-07)      # bbox contains zeros (Q-list 6)
+    assert i.voxelsize == 0.25 and i.has_emission == 1 and i.has_color == 1
+    assert v.stats() == {"leaves": 4, "active_voxels": int(sum(m.sum() for _, m in dl.values())) + 512, "active_tiles": 1}
+    m = np.eye(4) * 0.25; m[3, 3] = 1
+    assert [[v.info.xform[a][b] for b in range(4)] for a in range(4)] == m.T.tolist()
+    # emission / colour are densified over THEIR OWN active bbox (gpu_vdb.cpp:262, 343)
+    he, _, _ = _dense_from(hl, {}, 1)
+    np.testing.assert_array_equal(v.grid(1), he[..., 0])
+    ce, _, _ = _dense_from(cl, {}, 3)
+    c = v.grid(2)
+    np.testing.assert_array_equal(c[..., :3], ce)
+    assert (c[..., 3] == 1).all() and c.shape[:3] != d.shape
+    # channels that are absent / not asked for
+    v2 = pkg.io.VdbFile(path, emission="", color="nope")
+    assert v2.grid(1) is None and v2.grid(2) is None and v2.info.vdb_info.has_color == 0
+
+
+def test_vdb_reader_affine_map_and_errors(pkg, tmp_path):
+    rng = np.random.default_rng(9)
+    aff = np.array([[0.2, 0.1, 0, 0], [-0.1, 0.2, 0, 0], [0, 0, 0.3, 0], [1, 2, 3, 1]], np.float64)
+    path = str(tmp_path / "a.vdb")
+    W.write_vdb(path, [dict(name="density", type="float", leaves={(0, 0, 0): _leaf(rng, 1)}, map_type="AffineMap", map_values=aff.reshape(-1))])
+    v = pkg.io.VdbFile(path, emission=None, color=None)
+    assert [[v.info.xform[a][b] for b in range(4)] for a in range(4)] == aff.astype(np.float32).T.tolist()    # xform[i][j] = M(j, i)
+    assert v.info.vdb_info.voxelsize == np.float32(np.linalg.norm(aff[0, :3]))
+    with pytest.raises(pkg.VptError, match="no float grid named"):
+        pkg.io.VdbFile(path, density="smoke")
+    with pytest.raises(pkg.VptError, match="doesn't exist"):
+        pkg.io.VdbFile(str(tmp_path / "missing.vdb"))
+    bad = tmp_path / "bad.vdb"
+    bad.write_bytes(open(path, "rb").read()[:200])
+    with pytest.raises(pkg.VptError, match="truncated|end offset"):
+        pkg.io.VdbFile(str(bad))
+    junk = tmp_path / "junk.vdb"
+    junk.write_bytes(b"not a vdb file at all........")
+    with pytest.raises(pkg.VptError, match="not an OpenVDB"):
+        pkg.io.VdbFile(str(junk))
+
+
+def test_vdb_reader_matches_committed_dragon_fixture(pkg):
+    """the golden fixture was produced from assets/dragon.vdb by the independent Python reader"""
+    g = pkg.scene.load_golden("dragon_dense.npz")
+    if not has_assets:
+        pytest.skip("reference assets only exist in the build container")
+    v = pkg.io.VdbFile(os.path.join(ASSETS, "dragon.vdb"))                  # blosc + active mask
+    np.testing.assert_array_equal(v.grid(0), g["density"])
+    ref = pkg.scene.make_gpu_vdb(g["density"], g["bbox_min"], g["bbox_max"], g["matrix"], g["voxel_size"])
+    assert bytes(v.info)[:80] == bytes(ref)[:80] and bytes(v.info)[80:] == bytes(ref)[80:]
+    assert v.stats() == {"leaves": 131, "active_voxels": 19660, "active_tiles": 0}
+
+
+@pytest.mark.skipif(not has_assets, reason="reference assets only exist in the build container")
+def test_vdb_reader_matches_python_reader_on_reference_assets(pkg):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import vdb_reader_py as R
+    for name in ("dragon.vdb", "dragon_with_xform.vdb"):
+        v = pkg.io.VdbFile(os.path.join(ASSETS, name))
+        g = R.read_vdb(os.path.join(ASSETS, name))["density"]
+        dense, lo, hi = g.to_dense()
+        np.testing.assert_array_equal(v.grid(0), dense[..., 0])
+        assert v.stats()["active_voxels"] == g.active_voxel_count() and v.stats()["leaves"] == len(g.leaves)
+        assert [[v.info.xform[a][b] for b in range(4)] for a in range(4)] == g.matrix.astype(np.float32).T.tolist()
+
+
+def test_ins_reader_and_instance_transform(pkg, tmp_path):
+    p = tmp_path / "scene.ins"
+    p.write_text("2\n/data/a.vdb\n2\n0 200 0 0 0 0 1 20\n1.5 -2 3 0.5 0.5 0.5 0.5 2\n/data/b with space.vdb\r\n1\n-200 200 0 0 0.7071068 0 0.7071068 1\n")
+    r = pkg.io.read_ins(str(p))
+    assert [f for f, _ in r["files"]] == ["/data/a.vdb", "/data/b with space.vdb"]
+    a = r["files"][0][1]
+    assert list(a[0].position) == [0, 200, 0] and list(a[0].rotation) == [0, 0, 0, 1] and a[0].scale == 20
+    assert list(a[1].position) == [1.5, -2, 3] and a[1].scale == 2
+    # the reference's example file (source/CMakeLists.txt:44-50): identity rotation, scale 20
+    import ctypes as C
+    lib = pkg.load_library()
+    F44 = (C.c_float * 4) * 4
+    base = F44()
+    for i in range(4):
+        base[i][i] = 0.1 if i < 3 else 1.0
+    base[0][3], base[1][3], base[2][3] = 5.0, 6.0, 7.0            # a translation the loader removes (main.cpp:1069)
+    out = F44()
+    lib.vpt_instance_xform(C.byref(base), C.byref((C.c_double * 3)(0, 200, 0)), C.byref((C.c_double * 4)(0, 0, 0, 1)), 20.0, C.byref(out))
+    m = np.array([[out[c][r] for c in range(4)] for r in range(4)], np.float32)     # M[r][c] = m[c][r]
+    np.testing.assert_array_equal(m, np.array([[2, 0, 0, 0], [0, 2, 0, 0], [0, 0, 2, 0], [0, 200, 0, 1]], np.float32))
+    # a 90 degree rotation about y: float64 reference of quaternion_to_mat4 (matrix_math.h:379-412)
+    q = np.array([0, np.sin(np.pi / 4), 0, np.cos(np.pi / 4)])
+    lib.vpt_instance_xform(C.byref(base), C.byref((C.c_double * 3)(1, 2, 3)), C.byref((C.c_double * 4)(*q)), 1.0, C.byref(out))
+    m = np.array([[out[c][r] for c in range(4)] for r in range(4)], np.float64)
+    x, y, z, w = q
+    R = np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y + 2 * z * w, 2 * x * z - 2 * y * w, 0],
+                  [2 * x * y - 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z + 2 * x * w, 0],
+                  [2 * x * z + 2 * y * w, 2 * y * z - 2 * x * w, 1 - 2 * x * x - 2 * y * y, 0], [0, 0, 0, 1]])
+    B = np.diag([0.1, 0.1, 0.1, 1.0])
+    # operator* of matrix_math.h:130-163 reads a_rc = A.m[c][r] and stores the product's (i, j) at m[i][j]
+    A_rc = R.T              # mat4(m11..) stores m[c][r] = m_rc, so a_rc = m[c][r] -> the matrix as written
+    expect = (R @ B)        # ret.m[i][j] = sum_k a_ik b_kj with a = R (as written), b_kj = B.m[j][k] = B[k][j] (B symmetric here)
+    got_m_ij = np.array([[out[i][j] for j in range(4)] for i in range(4)], np.float64)
+    ref_m = expect.copy(); ref_m[0][3] += 1; ref_m[1][3] += 2; ref_m[2][3] += 3
+    np.testing.assert_allclose(got_m_ij, ref_m, atol=1e-7)
+    # light file (main.cpp:989-1017)
+    p2 = tmp_path / "lights.ins"
+    p2.write_text("light\n2\n1 2 3 0.5 0.25 1 100\n-4 5 -6 1 1 1 7.5\n")
+    L = pkg.io.read_ins(str(p2))["lights"]
+    assert len(L) == 2 and L[0].pos.tuple() == (1, 2, 3) and L[0].color.tuple() == (0.5, 0.25, 1) and L[0].power == 100 and L[1].power == 7.5
+    with pytest.raises(pkg.VptError):
+        pkg.io.read_ins(str(tmp_path / "nope.ins"))
+
+
+def _bmp24(rgb):
+    h, w, _ = rgb.shape
+    stride = (w * 3 + 3) & ~3
+    rows = b""
+    for y in range(h - 1, -1, -1):                                # bottom-up
+        row = rgb[y, :, ::-1].astype(np.uint8).tobytes()
+        rows += row + b"\0" * (stride - len(row))
+    hdr = b"BM" + struct.pack("<IHHI", 54 + len(rows), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(rows), 2835, 2835, 0, 0)
+    return hdr + rows
+
+
+def test_bmp_loader_channel_order_and_row_order(pkg, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)        # width 7: padded rows
+    p = tmp_path / "b.bmp"
+    p.write_bytes(_bmp24(img))
+    got = pkg.io.load_bmp(str(p))
+    exp = np.stack([img[..., 0], img[..., 2], img[..., 1]], -1).astype(np.float32) / np.float32(255.0)   # x=R, y=B, z=G
+    np.testing.assert_array_equal(got, exp)
+    if has_assets:
+        bn = pkg.io.load_bmp(os.path.join(ASSETS, "BN0.bmp"))
+        g = pkg.scene.load_golden("bn0.npz")
+        np.testing.assert_array_equal(bn.reshape(-1, 3), pkg.scene.blue_noise_from_rgb(g["rgb"]))
+
+
+def _exr(planes, w, h, compression, half=True):
+    names = sorted(planes)
+    hdr = struct.pack("<II", 20000630, 2)
+    ch = b""
+    for n in names:
+        ch += n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if half else 2, 0, 0, 0, 0, 1, 1)
+    ch += b"\0"
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    hdr += attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box)
+    hdr += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = b""
+        for y in range(y0, min(h, y0 + lines)):
+            for n in names:
+                raw += planes[n][y].astype("<f2" if half else "<f4").tobytes()
+        if compression:
+            a = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+            z = zlib.compress(d.astype(np.uint8).tobytes())
+            data = z if len(z) < len(raw) else raw
+        else:
+            data = raw
+        chunks.append(struct.pack("<iI", y0, len(data)) + data)
+    off = len(hdr) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off)
+        off += len(c)
+    return hdr + table + b"".join(chunks)
+
+
+@pytest.mark.parametrize("compression,half", [(0, True), (2, True), (3, True), (3, False)])
+def test_exr_loader(pkg, tmp_path, compression, half):
+    rng = np.random.default_rng(compression)
+    w, h = 37, 21
+    planes = {c: rng.random((h, w)).astype(np.float16 if half else np.float32) for c in "ABGR"}
+    p = tmp_path / "t.exr"
+    p.write_bytes(_exr(planes, w, h, compression, half))
+    got = pkg.io.load_exr_rgb(str(p))
+    exp = np.stack([planes["R"], planes["G"], planes["B"]], -1).astype(np.float32)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.skipif(not has_assets, reason="reference assets only exist in the build container")
+def test_exr_loader_on_reference_luts(pkg):
+    luts = pkg.scene.load_golden("luts.npz")
+    bb = pkg.io.load_exr_rgb(os.path.join(ASSETS, "blackbody_texture.exr"))
+    dc = pkg.io.load_exr_rgb(os.path.join(ASSETS, "density_color_texture2.exr"))
+    assert bb.shape == (1, 256, 3)
+    np.testing.assert_array_equal(bb[0], luts["blackbody"])
+    np.testing.assert_array_equal(dc[0], luts["density_color"])
+    with pytest.raises(pkg.VptError, match="compression"):      # PIZ-compressed; main.cpp:1400 loads "...texture2.exr" instead
+        pkg.io.load_exr_rgb(os.path.join(ASSETS, "density_color_texture.exr"))
+
+
+def _rgbe(img):
+    m = img.max(-1)
+    e = np.where(m > 1e-32, np.ceil(np.log2(np.maximum(m, 1e-38))), 0).astype(int)
+    sc = np.where(m > 1e-32, 256.0 / (2.0 ** e), 0)
+    out = np.zeros(img.shape[:2] + (4,), np.uint8)
+    out[..., :3] = np.clip(img * sc[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(m > 1e-32, e + 128, 0)
+    return out
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_hdr_loader(pkg, tmp_path, rle):
+    rng = np.random.default_rng(5)
+    w, h = 40, 6
+    img = (rng.random((h, w, 3)) * 10).astype(np.float32)
+    img[2, 5:30] = img[2, 5]                                       # a run for the RLE path
+    img[0, 0] = 0
+    e = _rgbe(img)
+    body = b""
+    for y in range(h):
+        if rle:
+            body += bytes([2, 2, w >> 8, w & 255])
+            for c in range(4):
+                row = e[y, :, c]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        body += bytes([128 + run, row[x]]); x += run
+                    else:
+                        n = min(w - x, 100)
+                        k = 1
+                        while k < n and not (x + k + 2 < w and row[x + k] == row[x + k + 1] == row[x + k + 2]):
+                            k += 1
+                        body += bytes([k]) + row[x:x + k].tobytes(); x += k
+        else:
+            body += e[y].tobytes()
+    p = tmp_path / "e.hdr"
+    p.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + body)
+    got = pkg.io.load_hdr(str(p))
+    f = np.where(e[..., 3:4] == 0, 0.0, 2.0 ** (e[..., 3:4].astype(np.float64) - 136))
+    exp = np.where(e[..., 3:4] == 0, 0.0, (e[..., :3].astype(np.float64) + 0.5) * f).astype(np.float32)    # hdr_loader.h:206-210
+    np.testing.assert_array_equal(got[..., :3], exp)
+    assert (got[..., 3] == 0).all()
+    np.testing.assert_allclose(got[1:, :, :3], img[1:], rtol=0.02, atol=0.05)
+
+
+def test_pfm_ppm_writers(pkg, tmp_path):
+    rng = np.random.default_rng(2)
+    w, h = 9, 4
+    acc = rng.random((h * w, 3)).astype(np.float32)
+    pkg.io.write_pfm(str(tmp_path / "a.pfm"), acc, w, h)
+    raw = (tmp_path / "a.pfm").read_bytes()
+    head = b"PF\n9 4\n-1.0\n"
+    assert raw.startswith(head)
+    data = np.frombuffer(raw[len(head):], "<f4").reshape(h, w, 3)
+    np.testing.assert_array_equal(data[::-1], acc.reshape(h, w, 3))                 # PFM rows are bottom-up
+    disp = (0xFF000000 | rng.integers(0, 1 << 24, h * w)).astype(np.uint32)
+    pkg.io.write_ppm(str(tmp_path / "d.ppm"), disp, w, h)
+    raw = (tmp_path / "d.ppm").read_bytes()
+    assert raw.startswith(b"P6\n9 4\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n9 4\n255\n"):], np.uint8).reshape(h * w, 3)
+    np.testing.assert_array_equal(px, np.stack([(disp >> 16) & 255, (disp >> 8) & 255, disp & 255], 1).astype(np.uint8))
+
+
+def test_io_symbols_exported(pkg):
+    lib = pkg.load_library()
+    assert [s for s in pkg.io.IO_SYMBOLS if not hasattr(lib, s)] == []

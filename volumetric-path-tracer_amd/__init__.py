@@ -10,3 +10,5 @@ from .host import ABI_SYMBOLS, LIB_PATH, Context, VptError, load_library  # noqa
 from . import scene  # noqa: F401
 from . import dist  # noqa: F401
 from . import atmosphere  # noqa: F401
+from . import io  # noqa: F401
+from . import host  # noqa: F401

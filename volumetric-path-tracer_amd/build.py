@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libvpt_hip.so")
 HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", "vpt_trace_common.h", "vpt_walk.h", "vpt_tex.h", "vpt_sky.h", os.path.join("..", "..", "include", "vpt_abi.h"),
-           os.path.join("..", "..", "include", "vpt_testhooks.h")]
+           os.path.join("..", "..", "include", "vpt_testhooks.h"),
+           os.path.join("..", "..", "include", "vpt_io.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
@@ -32,6 +33,7 @@ SOURCES = {
     "vpt_tail.hip": VALUE_ONLY,
     "vpt_atmosphere.hip": STRICT,
     "vpt_env.hip": STRICT,
+    "vpt_io.hip": STRICT,
     "vpt_testhooks.hip": STRICT,
 }
 
@@ -69,7 +71,7 @@ def build(force=False, verbose=False, extra_flags=()):
                 if verbose and r.stderr:
                     print(r.stderr)
     if jobs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", OUT]
         cmd, r = run(cmd)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

@@ -22,9 +22,11 @@ struct DVolume {
     float m[12];   // world->index rows: q.x = m[0]*x + m[1]*y + m[2]*z + m[3], ...
     float bmin[3];
     float fdim[3];
-    int dim[3];
+    int dim[3];            // density texture extent
     int has_color;
     int has_emission;
+    int edim[3];           // emission texture extent
+    int cdim[3];           // colour texture extent
     int pad_;
 };
 

@@ -366,20 +366,22 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         }
         d.density = t.data;
         if (vi.has_emission) {
-            if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1 || t.width != vi.dim.x || t.height != vi.dim.y || t.depth != vi.dim.z) {
-                set_error(ctx, "vpt_scene_set_volumes: volume %d has_emission but no matching f32 emission texture", i);
+            if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1) {
+                set_error(ctx, "vpt_scene_set_volumes: volume %d has_emission but no f32 emission texture", i);
                 return VPT_E_INVALID;
             }
             d.emission = t.data;
+            d.edim[0] = t.width; d.edim[1] = t.height; d.edim[2] = t.depth;
             d.has_emission = 1;
             ctx->any_emission = true;
         }
         if (vi.has_color) {
-            if (resolve_tex(ctx, vi.color_texture, &t) != 0 || t.channels != 4 || t.width != vi.dim.x || t.height != vi.dim.y || t.depth != vi.dim.z) {
-                set_error(ctx, "vpt_scene_set_volumes: volume %d has_color but no matching float4 colour texture", i);
+            if (resolve_tex(ctx, vi.color_texture, &t) != 0 || t.channels != 4) {
+                set_error(ctx, "vpt_scene_set_volumes: volume %d has_color but no float4 colour texture", i);
                 return VPT_E_INVALID;
             }
             d.color = reinterpret_cast<const f4*>(t.data);
+            d.cdim[0] = t.width; d.cdim[1] = t.height; d.cdim[2] = t.depth;
             d.has_color = 1;
             ctx->any_color = true;
         }

@@ -146,32 +146,32 @@ struct Taps {
     int i0, i1, j0, j1, k0, k1;
     float ax, ay, az;
 };
-VPT_D Taps make_taps(const DVolume& v, f3 u) {
+VPT_D Taps make_taps(const int* dim, f3 u) {
     Taps t;
-    float xb = u.x * v.fdim[0] - 0.5f;
-    float yb = u.y * v.fdim[1] - 0.5f;
-    float zb = u.z * v.fdim[2] - 0.5f;
+    float xb = u.x * (float)dim[0] - 0.5f;
+    float yb = u.y * (float)dim[1] - 0.5f;
+    float zb = u.z * (float)dim[2] - 0.5f;
     float fx = floorf(xb), fy = floorf(yb), fz = floorf(zb);
     t.ax = xb - fx;
     t.ay = yb - fy;
     t.az = zb - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
-    t.i0 = min(max(i, 0), v.dim[0] - 1);
-    t.i1 = min(max(i + 1, 0), v.dim[0] - 1);
-    t.j0 = min(max(j, 0), v.dim[1] - 1);
-    t.j1 = min(max(j + 1, 0), v.dim[1] - 1);
-    t.k0 = min(max(k, 0), v.dim[2] - 1);
-    t.k1 = min(max(k + 1, 0), v.dim[2] - 1);
+    t.i0 = min(max(i, 0), dim[0] - 1);
+    t.i1 = min(max(i + 1, 0), dim[0] - 1);
+    t.j0 = min(max(j, 0), dim[1] - 1);
+    t.j1 = min(max(j + 1, 0), dim[1] - 1);
+    t.k0 = min(max(k, 0), dim[2] - 1);
+    t.k1 = min(max(k + 1, 0), dim[2] - 1);
     return t;
 }
 // trilinear f32 fetch: CUDA "linear, normalised, clamp" addressing, fp32 weights, nested
 // lerp x -> y -> z with lerp(a,b,t) = a + t*(b-a)
-VPT_D float fetch_f32(const float* __restrict__ g, const DVolume& v, const Taps& t) {
-    const uint32_t dx = (uint32_t)v.dim[0];
-    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
-    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
-    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
-    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+VPT_D float fetch_f32(const float* __restrict__ g, const int* dim, const Taps& t) {
+    const uint32_t dx = (uint32_t)dim[0];
+    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
+    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
     const float c000 = g[r00 + t.i0], c100 = g[r00 + t.i1];
     const float c010 = g[r10 + t.i0], c110 = g[r10 + t.i1];
     const float c001 = g[r01 + t.i0], c101 = g[r01 + t.i1];
@@ -185,12 +185,12 @@ VPT_D float fetch_f32(const float* __restrict__ g, const DVolume& v, const Taps&
     return c0 + (c1 - c0) * t.az;
 }
 VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
-VPT_D f3 fetch_f4(const f4* __restrict__ g, const DVolume& v, const Taps& t) {
-    const uint32_t dx = (uint32_t)v.dim[0];
-    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
-    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
-    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j0) * dx;
-    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)v.dim[1] + (uint32_t)t.j1) * dx;
+VPT_D f3 fetch_f4(const f4* __restrict__ g, const int* dim, const Taps& t) {
+    const uint32_t dx = (uint32_t)dim[0];
+    const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
+    const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
+    const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
     const f4 c00 = lerp4(g[r00 + t.i0], g[r00 + t.i1], t.ax);
     const f4 c10 = lerp4(g[r10 + t.i0], g[r10 + t.i1], t.ax);
     const f4 c01 = lerp4(g[r01 + t.i0], g[r01 + t.i1], t.ax);
@@ -204,18 +204,19 @@ VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want
                          float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e) {
     f3 u;
     const bool inside = to_unit(v, p, u);
-    Taps t;
-    if (inside) t = make_taps(v, u);
+    // every texture object has its own extent (the reference densifies each grid over its own
+    // active bbox, gpu_vdb.cpp:179,262,343) but is addressed with the density grid's normalised
+    // coordinates
     if (want_density) {
         if (COUNT) n_d++;
-        if (inside) density += fetch_f32(v.density, v, t);
+        if (inside) density += fetch_f32(v.density, v.dim, make_taps(v.dim, u));
     }
     if (COLOR && want_color) {
         if (!v.has_color) {
             color = fmax3(color, mk3(1.0f));
         } else {
             if (COUNT) n_c++;
-            f3 c = inside ? fetch_f4(v.color, v, t) : mk3(0.0f);
+            f3 c = inside ? fetch_f4(v.color, v.cdim, make_taps(v.cdim, u)) : mk3(0.0f);
             color = fmax3(color, c);
         }
     }
@@ -223,7 +224,7 @@ VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want
         if (v.has_emission) {
             if (COUNT) n_e++;
             if (inside) {
-                float index = fetch_f32(v.emission, v, t);
+                float index = fetch_f32(v.emission, v.edim, make_taps(v.edim, u));
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
                 const float* e = P.emission_lut + 3 * (int)index;
                 emission += mk3(e[0], e[1], e[2]) * P.emission_scale;
