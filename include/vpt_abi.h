@@ -341,6 +341,11 @@ int  vpt_env_cdf_create(vpt_ctx *ctx, vpt_kernel_params *kp);
 /* camera::update_camera, source/gpu_vdb/camera.h:110-129 */
 void vpt_camera_update(vpt_camera *cam, vpt_float3 lookfrom, vpt_float3 lookat, vpt_float3 vup,
                        float vfov, float aspect, float aperture);
+/* the "F key" framing of source/main.cpp:526-543: bbox (seeded with the origin) of the transformed
+ * bmin / bmax corners of every instance, lookat = centre, lookfrom = centre + |diagonal| (1,1,1),
+ * vup = (0,1,0); then update_camera.  out_center / out_dist may be NULL. */
+void vpt_camera_frame(vpt_camera *cam, const vpt_gpu_vdb *volumes, int num_volumes, float vfov, float aspect,
+                      float aperture, vpt_float3 *out_center, float *out_dist);
 /* camera() default ctor, camera.h:97-106 */
 void vpt_camera_default(vpt_camera *cam);
 /* GPU_VDB::Bounds, source/gpu_vdb/gpu_vdb.h:131-146 */

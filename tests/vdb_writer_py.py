@@ -129,3 +129,25 @@ def write_vdb(path, grids):
 
 def uniform_scale(s):
     return [s, s, s, s, s, s, 1 / s, 1 / s, 1 / s, 1 / s ** 2, 1 / s ** 2, 1 / s ** 2, 0.5 / s, 0.5 / s, 0.5 / s]
+
+
+def dense_to_leaves(dense, bbox_min):
+    """[z, y, x] dense array -> {leaf origin: (vals[512,1], mask[512])} with active = non-zero"""
+    nz, ny, nx = dense.shape
+    lo = np.asarray(bbox_min, np.int64)
+    leaves = {}
+    o0 = (lo >> 3) << 3
+    hi = lo + np.array([nx, ny, nz]) - 1
+    for ox in range(o0[0], hi[0] + 1, 8):
+        for oy in range(o0[1], hi[1] + 1, 8):
+            for oz in range(o0[2], hi[2] + 1, 8):
+                blk = np.zeros((8, 8, 8), np.float32)              # [x][y][z]
+                xs = slice(max(ox, lo[0]), min(ox + 8, hi[0] + 1))
+                ys = slice(max(oy, lo[1]), min(oy + 8, hi[1] + 1))
+                zs = slice(max(oz, lo[2]), min(oz + 8, hi[2] + 1))
+                sub = dense[zs.start - lo[2]:zs.stop - lo[2], ys.start - lo[1]:ys.stop - lo[1], xs.start - lo[0]:xs.stop - lo[0]]
+                blk[xs.start - ox:xs.stop - ox, ys.start - oy:ys.stop - oy, zs.start - oz:zs.stop - oz] = sub.transpose(2, 1, 0)
+                if (blk != 0).any():
+                    v = blk.reshape(512, 1)                        # n = (x << 6) | (y << 3) | z
+                    leaves[(int(ox), int(oy), int(oz))] = (v, (v[:, 0] != 0))
+    return leaves

@@ -76,7 +76,29 @@ def build(force=False, verbose=False, extra_flags=()):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("hipcc link failed")
+    build_cli(verbose=verbose)
     return OUT
+
+
+CLI_SRC = os.path.join(HERE, "..", "tools", "vpt_cli.cpp")
+CLI_OUT = os.path.join(HERE, "vpt_cli")
+
+
+def build_cli(verbose=False):
+    """the headless main.cpp-equivalent (tools/vpt_cli.cpp), linked against libvpt_hip.so next to it"""
+    inc = os.path.join(HERE, "..", "include")
+    deps = [CLI_SRC, OUT, os.path.join(inc, "vpt_abi.h"), os.path.join(inc, "vpt_io.h")]
+    if not _stale(CLI_OUT, deps):
+        return CLI_OUT
+    cmd = [HIPCC, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-I", inc, CLI_SRC, "-o", CLI_OUT,
+           "-L", HERE, "-lvpt_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building vpt_cli")
+    return CLI_OUT
 
 
 if __name__ == "__main__":

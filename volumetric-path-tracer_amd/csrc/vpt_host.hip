@@ -824,6 +824,23 @@ void vpt_camera_update(vpt_camera* cam, vpt_float3 lookfrom_, vpt_float3 lookat_
     cam->vertical = tov(2.0f * half_height * fd * v);
 }
 
+void vpt_camera_frame(vpt_camera* cam, const vpt_gpu_vdb* volumes, int num_volumes, float vfov, float aspect, float aperture,
+                      vpt_float3* out_center, float* out_dist) {
+    if (!cam || !volumes || num_volumes <= 0) return;     // main.cpp:526-543
+    f3 bbox_min = mk3(.0f), bbox_max = mk3(.0f);
+    for (int i = 0; i < num_volumes; ++i) {
+        const mat4 xt = mat4_transpose(load_xform(volumes[i]));
+        bbox_min = fmin3(bbox_min, mat4_transform_point(xt, v3(volumes[i].vdb_info.bmin)));
+        bbox_max = fmax3(bbox_max, mat4_transform_point(xt, v3(volumes[i].vdb_info.bmax)));
+    }
+    const f3 center = (bbox_max + bbox_min) / 2;
+    const float dist = length(bbox_max - bbox_min);
+    const f3 lookfrom = mk3(center.x + (dist), center.y + (dist), center.z + (dist));
+    vpt_camera_update(cam, tov(lookfrom), tov(center), vpt_float3{.0f, 1.0f, .0f}, vfov, aspect, aperture);
+    if (out_center) *out_center = tov(center);
+    if (out_dist) *out_dist = dist;
+}
+
 void vpt_gpu_vdb_bounds(const vpt_gpu_vdb* vdb, vpt_float3* pmin, vpt_float3* pmax) {
     if (!vdb) return;
     Box b = vdb_bounds(*vdb);

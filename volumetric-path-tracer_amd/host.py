@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "vpt_set_counting", "vpt_get_stats",
     "vpt_atmosphere_default_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
     "vpt_env_cdf_build", "vpt_env_cdf_create",
-    "vpt_camera_update", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
+    "vpt_camera_update", "vpt_camera_frame", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
 ]
 
 
@@ -72,6 +72,8 @@ def load_library(path=None):
     lib.vpt_get_stats.argtypes = [vp, C.POINTER(RenderStats)]
     lib.vpt_camera_update.argtypes = [C.POINTER(Camera), Float3, Float3, Float3, C.c_float, C.c_float, C.c_float]
     lib.vpt_camera_update.restype = None
+    lib.vpt_camera_frame.argtypes = [C.POINTER(Camera), C.POINTER(GpuVdb), C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Float3), C.POINTER(C.c_float)]
+    lib.vpt_camera_frame.restype = None
     lib.vpt_camera_default.argtypes = [C.POINTER(Camera)]
     lib.vpt_camera_default.restype = None
     lib.vpt_gpu_vdb_bounds.argtypes = [C.POINTER(GpuVdb), C.POINTER(Float3), C.POINTER(Float3)]
