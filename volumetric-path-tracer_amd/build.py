@@ -45,7 +45,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), variant=None):
+    """variant: build libvpt_hip_<variant>.so with `extra_flags` next to the default library (perf
+    experiments: select it at run time with VPT_LIB_PATH)."""
+    global OBJ, OUT
+    if variant:
+        OBJ = os.path.join(HERE, "_obj_" + variant)
+        OUT = os.path.join(HERE, "libvpt_hip_%s.so" % variant)
     os.makedirs(OBJ, exist_ok=True)
     common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []
@@ -53,7 +59,7 @@ def build(force=False, verbose=False, extra_flags=()):
     for src, flags in SOURCES.items():
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or extra_flags or _stale(obj, [os.path.join(CSRC, src)] + common_deps):
+        if force or (extra_flags and not variant) or _stale(obj, [os.path.join(CSRC, src)] + common_deps):
             jobs.append([HIPCC] + COMMON + flags + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
@@ -76,7 +82,8 @@ def build(force=False, verbose=False, extra_flags=()):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("hipcc link failed")
-    build_cli(verbose=verbose)
+    if not variant:
+        build_cli(verbose=verbose)
     return OUT
 
 
@@ -102,6 +109,12 @@ def build_cli(verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv,
-          extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a not in ("--force", "--verbose")])
+    variant = None
+    argv = list(sys.argv[1:])
+    if "--variant" in argv:
+        i = argv.index("--variant")
+        variant = argv[i + 1]
+        del argv[i:i + 2]
+    build(force="--force" in argv, verbose="--verbose" in argv,
+          extra_flags=[a for a in argv if a.startswith("-") and a not in ("--force", "--verbose")], variant=variant)
     print("built", OUT)

@@ -55,6 +55,9 @@ VPT_D WalkConst make_walk_const(const TraceParams& P) {
 //   WALK_TR      ratio tracking (`Tr` :1169-1265): multiplies trw
 //   WALK_EMIT    emission march (`estimate_emission` :1287-1337): adds to Ld
 enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
+#ifndef VPT_SKIP_LOOP
+#define VPT_SKIP_LOOP 8
+#endif
 struct Walk {
     f3 pos, dir, inv;     // walk ray (inv = 1 / dir)
     float t;              // cumulative step (Q-list 1: never reset inside a walk)
@@ -76,19 +79,31 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
                      float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c) {
     const bool is_sample = kind == WALK_SAMPLE;
     const bool is_emit = EMIT && kind == WALK_EMIT;
-    f3 nmin, nmax;
+    // Empty-node pushes are cheap and the tracking step below is expensive, so the wave first loops
+    // on the pushes until none of its walking lanes stands in an empty node (at most VPT_SKIP_LOOP
+    // rounds): the tracking step then runs with (nearly) all walkers participating instead of the
+    // one third that would otherwise be at a leaf in any given pass.  Per lane the sequence of
+    // operations is unchanged.
     int leaf = 0;
-    const int st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
-    if (st == LOC_OUTSIDE) return true;
-    if (st == LOC_EMPTY) {
-        // empty node: push to its far side, at least 0.1 (:1613-1616)
-        float t_min, t_max;
-        box_intersect(nmin, nmax, w.pos, w.inv, t_min, t_max);
-        t_max = fmax_(t_max, 0.1f);
-        w.pos += w.dir * t_max;
-        if (COUNT) c.n_skips++;
-        return false;
+    int st = LOC_EMPTY;
+#pragma unroll 1
+    for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
+        if (st == LOC_EMPTY) {
+            f3 nmin, nmax;
+            st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
+            if (st == LOC_EMPTY) {
+                // empty node: push to its far side, at least 0.1 (:1613-1616)
+                float t_min, t_max;
+                box_intersect(nmin, nmax, w.pos, w.inv, t_min, t_max);
+                t_max = fmax_(t_max, 0.1f);
+                w.pos += w.dir * t_max;
+                if (COUNT) c.n_skips++;
+            }
+        }
+        if (!__any(st == LOC_EMPTY)) break;
     }
+    if (st == LOC_EMPTY) return false;           // still crossing empty nodes: next pass
+    if (st == LOC_OUTSIDE) return true;
     if (is_sample) {
         // :1647-1651
         float t_min, t_max, geo_dist;

@@ -43,7 +43,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VPT_LIB_PATH") or LIB_PATH      # VPT_LIB_PATH: perf-experiment variants (build.py --variant)
     if not os.path.exists(p):
         raise VptError("%s not found: run `python volumetric-path-tracer_amd/build.py` (hipcc, gfx950)" % p)
     lib = C.CDLL(p)
