@@ -135,7 +135,7 @@ struct TraceParams {
     DTexture env_func_tex, env_cdf_tex;                    // 2-D f32, unnormalised, point
     DTexture env_marginal_func_tex, env_marginal_cdf_tex;  // 1-D f32, unnormalised, point
     int has_atmosphere;
-    float atm_f[24];                                       // packed vpt_atmosphere_parameters scalars
+    float atm_f[40];                                       // packed vpt_atmosphere_parameters scalars
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
 
@@ -162,7 +162,7 @@ struct ResolveParams {
     DTexture env_tex;
     // atmosphere
     int has_atmosphere;
-    float atm_f[24];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
+    float atm_f[40];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
 

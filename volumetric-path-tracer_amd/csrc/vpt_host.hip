@@ -526,7 +526,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
 
 // ---- atmosphere packing (indices: enum AF_* in vpt_resolve.hip) -------------------------------------
 static void pack_atmosphere(const vpt_atmosphere_parameters* a, float* f) {
-    std::memset(f, 0, sizeof(float) * 24);
+    std::memset(f, 0, sizeof(float) * 40);
     f[0] = a->bottom_radius; f[1] = a->top_radius; f[2] = (float)a->use_luminance; f[3] = a->mie_phase_function_g;
     f[4] = a->sun_angular_radius; f[5] = a->mu_s_min; f[6] = a->exposure;
     st3(f + 8, a->sky_spectral_radiance_to_luminance);
@@ -534,6 +534,24 @@ static void pack_atmosphere(const vpt_atmosphere_parameters* a, float* f) {
     st3(f + 14, a->solar_irradiance);
     st3(f + 17, a->ground_albedo);
     st3(f + 20, a->white_point);
+    // launch-uniform sub-expressions of the look-up functions, evaluated once here (vpt_sky.h AF_*)
+    const float top = a->top_radius, bottom = a->bottom_radius;
+    const float H = sqrtf(top * top - bottom * bottom);                       // render_kernel.cu:438, :527
+    f[7] = H;
+    f[23] = 1.0f / H;
+    const float dmus = H - (top - bottom);                                    // d_max - d_min of :548-552
+    f[24] = 1.0f / dmus;
+    const float A = -2.0f * a->mu_s_min * bottom / dmus;                      // :553
+    f[25] = 1.0f / A;
+    f[26] = 1.0f / (top - bottom);                                            // :636
+    f[27] = cosf(a->sun_angular_radius);                                      // :875
+    const bool lum = a->use_luminance != 0;
+    const float sa = a->sun_angular_radius;
+    f3 solar = v3(a->solar_irradiance) / (VPT_PI * sa * sa);                  // GetSolarRadiance :835
+    if (lum) solar = solar * v3(a->sun_spectral_radiance_to_luminance);
+    st3(f + 28, solar);
+    const float expo = lum ? a->exposure * 1e-5f : a->exposure;               // :883
+    st3(f + 31, mk3(expo) / v3(a->white_point));
 }
 
 // ---- the hot path ---------------------------------------------------------------------------------

@@ -1,54 +1,100 @@
 // vpt_sky.h -- Bruneton precomputed atmospheric scattering, look-up side: `sample_atmosphere`
-// (render_kernel.cu:839-895) and the functions under it (:369-835).  VALUE-ONLY arithmetic (see
-// vpt_tail.hip); used by the environment tail (vpt_tail.hip) and by estimate_sky in the
+// (render_kernel.cu:839-895) and the functions under it (:369-835; published algorithm:
+// E. Bruneton, "Precomputed Atmospheric Scattering", EGSR 2008 + the 2017 reference implementation
+// `functions.glsl`).  Used by the environment tail (vpt_tail.hip) and by estimate_sky in the
 // vol_integrator tracer (vpt_trace_vol.hip).  RP is any parameter block with atm_f[] and the four
 // look-up textures (ResolveParams, TraceParams).
+//
+// VALUE-ONLY arithmetic: the result is added to L once and feeds no random walk.  The
+// reference evaluates it under --use_fast_math; here, independent of the including translation
+// unit's flags, it is written with
+//   * v_rcp_f32 / v_sqrt_f32 based divide and sqrt (1 ulp each, like __fdividef / __fsqrt_rn-less
+//     fast math) and hardware exp2 / log2 for the tone curve,
+//   * FMA-contracted interpolation (a + t (b - a) as one subtract + one fma),
+//   * float instead of double for the texture-coordinate maps (:419; the doubles come from
+//     unsuffixed literals), but DOUBLE kept where the reference's doubles matter: the
+//     r^2 (mu^2 - 1) + R^2 discriminants (:389, :401) cancel catastrophically in fp32,
+//   * launch-uniform sub-expressions (H, 1/H, A of :553, ...) evaluated once on the host
+//     (pack_atmosphere, vpt_host.hip) -- gfx950 has no scalar float ALU, so a uniform sqrt would
+//     otherwise be repeated by every wave,
+//   * compile-time table extents (constants.h:50-62), 32-bit unsigned texel offsets (SGPR base +
+//     VGPR offset addressing), and the y/z taps shared between the two nu slices and the two 3-D
+//     tables of GetCombinedScattering.
+// Tolerance against the oracle (which restates the reference literally): tests/test_gpu_atmosphere.py.
 #pragma once
 
 #include "vpt_tex.h"
 
 namespace vpt {
 
-// ---- Bruneton precomputed atmospheric scattering, look-up side ------------------------------
-// (render_kernel.cu:369-895; published algorithm: E. Bruneton, "Precomputed Atmospheric
-// Scattering", EGSR 2008 + 2017 reference implementation `functions.glsl`.)
-// atm_f[] packing is defined in vpt_host.hip (pack_atmosphere).
-//
-// The four tables have fixed power-of-two extents (constants.h:50-62), so their samplers are
-// specialised at compile time: "linear, normalised, wrap/clamp" for the 2-D tables
-// (atmosphere.cpp:503-573) and "linear, normalised, clamp" for the 3-D ones (:575-675), with the
-// y/z taps shared between the two nu slices and the two 3-D tables of GetCombinedScattering.
+// atm_f[] layout; written by pack_atmosphere (vpt_host.hip)
 enum {
     AF_BOTTOM = 0, AF_TOP = 1, AF_USE_LUM = 2, AF_MIE_G = 3, AF_SUN_ANG = 4, AF_MU_S_MIN = 5, AF_EXPOSURE = 6,
+    AF_H = 7,                 // sqrt(top^2 - bottom^2)
     AF_SKY_K = 8, AF_SUN_K = 11, AF_SOLAR = 14, AF_GROUND = 17, AF_WHITE = 20,
+    AF_INV_H = 23,            // 1 / H
+    AF_INV_DMUS = 24,         // 1 / (H - (top - bottom)): the mu_s map of :548-552
+    AF_INV_A = 25,            // 1 / A, A = -2 mu_s_min bottom / (H - (top - bottom))     (:553)
+    AF_INV_TB = 26,           // 1 / (top - bottom)
+    AF_COS_SUN = 27,          // cos(sun_angular_radius)
+    AF_SOLAR_RAD = 28,        // solar_irradiance / (pi sun_angular_radius^2) [* sun_k]  (GetSolarRadiance :835)
+    AF_EXPO_W = 31,           // exposure [* 1e-5] / white_point                          (:883-885)
+    AF_COUNT = 34,
 };
-VPT_D f3 ld_f3(const float4* p, int i) { const float4 v = p[i]; return mk3(v.x, v.y, v.z); }
-VPT_D f3 lerp3r(f3 a, f3 b, float t) { return a + (b - a) * t; }
-struct Tap { int i0, i1; float a; };
+
+#ifdef VPT_SKY_DBG_DIV
+VPT_D float frcp(float x) { return 1.0f / x; }
+VPT_D float fdiv(float a, float b) { return a / b; }
+#else
+VPT_D float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+VPT_D float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
+#ifdef VPT_SKY_DBG_SQRT
+VPT_D float fsqrt(float x) { return sqrtf(x); }
+#else
+VPT_D float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#endif
+#ifdef VPT_SKY_DBG_NOFMA
+VPT_D float ffma(float a, float b, float c) { return a * b + c; }
+#else
+VPT_D float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+VPT_D float flerp(float a, float b, float t) { return ffma(t, b - a, a); }
+VPT_D f3 flerp3(f3 a, f3 b, float t) { return mk3(flerp(a.x, b.x, t), flerp(a.y, b.y, t), flerp(a.z, b.z, t)); }
+VPT_D f3 fscale_add3(f3 a, float s, f3 b) { return mk3(ffma(a.x, s, b.x), ffma(a.y, s, b.y), ffma(a.z, s, b.z)); }
+// texel fetch through a 32-bit BYTE offset (tables are <= 16 MiB): SGPR base + VGPR offset addressing
+VPT_D f3 ld_f3(const float4* __restrict__ p, uint32_t i) {
+    const uint32_t off = i << 4;
+    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + off);
+    return mk3(v.x, v.y, v.z);
+}
+
+struct Tap { uint32_t i0, i1; float a; };
 template <int N, bool WRAP>
 VPT_D Tap lut_tap(float u) {
     Tap t;
-    const float xb = u * (float)N - 0.5f;
+    const float xb = ffma(u, (float)N, -0.5f);
     const float fl = floorf(xb);
     t.a = xb - fl;
     const int i = (int)fl;
     if (WRAP) {
-        t.i0 = i & (N - 1);
-        t.i1 = (i + 1) & (N - 1);
+        t.i0 = (uint32_t)i & (uint32_t)(N - 1);
+        t.i1 = (uint32_t)(i + 1) & (uint32_t)(N - 1);
     } else {
-        t.i0 = min(max(i, 0), N - 1);
-        t.i1 = min(max(i + 1, 0), N - 1);
+        t.i0 = (uint32_t)min(max(i, 0), N - 1);
+        t.i1 = (uint32_t)min(max(i + 1, 0), N - 1);
     }
     return t;
 }
-// 2-D 256x64 float4 table, x wraps, y clamps
+// 2-D 256x64 float4 table, x wraps, y clamps (atmosphere.cpp:503-573)
 VPT_D f3 lut2d(const float* data, float u, float v) {
     const float4* p = reinterpret_cast<const float4*>(data);
     const Tap tx = lut_tap<256, true>(u), ty = lut_tap<64, false>(v);
-    const f3 c0 = lerp3r(ld_f3(p, ty.i0 * 256 + tx.i0), ld_f3(p, ty.i0 * 256 + tx.i1), tx.a);
-    const f3 c1 = lerp3r(ld_f3(p, ty.i1 * 256 + tx.i0), ld_f3(p, ty.i1 * 256 + tx.i1), tx.a);
-    return lerp3r(c0, c1, ty.a);
+    const f3 c0 = flerp3(ld_f3(p, ty.i0 * 256u + tx.i0), ld_f3(p, ty.i0 * 256u + tx.i1), tx.a);
+    const f3 c1 = flerp3(ld_f3(p, ty.i1 * 256u + tx.i0), ld_f3(p, ty.i1 * 256u + tx.i1), tx.a);
+    return flerp3(c0, c1, ty.a);
 }
+
 template <class RP>
 struct Sky {
     const RP& R;
@@ -60,121 +106,127 @@ struct Sky {
 
     VPT_D static float ClampCosine(float mu) { return clampf(mu, -1.0f, 1.0f); }
     VPT_D float ClampRadius(float r) const { return clampf(r, bottom(), top()); }
-    VPT_D static float SafeSqrt(float a) { return sqrtf(fmax_(a, 0.0f)); }
+    VPT_D static float SafeSqrt(float a) { return fsqrt(fmax_(a, 0.0f)); }
+    // r^2 (mu^2 - 1) + R^2 in double (:389, :401)
+    VPT_D static double Disc(float r, float mu, float R_) { return (double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(R_ * R_); }
     VPT_D float DistanceToTop(float r, float mu) const {                              // :389
-        float disc = (float)((double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(top() * top()));
-        return fmax_(-r * mu + SafeSqrt(disc), 0.0f);
+        return fmax_(-r * mu + SafeSqrt((float)Disc(r, mu, top())), 0.0f);
     }
-    VPT_D bool HitsGround(float r, float mu) const {                                  // :401
-        return mu < 0.0f && (double)(r * r) * ((double)(mu * mu) - 1.0) + (double)(bottom() * bottom()) >= 0.0;
+    // sqrt(d^2 + 2 r mu d + r^2) in DOUBLE, rounded once (:475, :781): at a ground point the result
+    // decides between r = bottom and bottom + 1 ulp (0.5 m), i.e. rho = 0 or 2.5 km in the table maps
+    VPT_D static float RadiusAt(float r, float mu, float d) {
+        return (float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r));
     }
+    VPT_D bool HitsGround(float r, float mu) const { return mu < 0.0f && Disc(r, mu, bottom()) >= 0.0; }   // :401
     template <int N>
-    VPT_D static float UnitToTex(float x) {                                           // :419
-        return (float)(0.5 / (double)N + (double)x * (1.0 - 1.0 / (double)N));
-    }
+#ifdef VPT_SKY_DBG_UNIT
+    VPT_D static float UnitToTex(float x) { return (float)(0.5 / (double)N + (double)x * (1.0 - 1.0 / (double)N)); }
+#else
+    VPT_D static float UnitToTex(float x) { return ffma(x, (float)(1.0 - 1.0 / (double)N), (float)(0.5 / (double)N)); }   // :419
+#endif
     VPT_D f3 TransmittanceToTop(float r, float mu) const {                            // :429-470
-        float H = sqrtf(top() * top() - bottom() * bottom());
-        float rho = SafeSqrt(r * r - bottom() * bottom());
-        float d = DistanceToTop(r, mu);
-        float d_min = top() - r;
-        float d_max = rho + H;
-        float x_mu = (d - d_min) / (d_max - d_min);
-        float x_r = rho / H;
+        const float rho = SafeSqrt(r * r - bottom() * bottom());
+        const float d = DistanceToTop(r, mu);
+        const float d_min = top() - r;
+        const float d_max = rho + f(AF_H);
+        const float x_mu = fdiv(d - d_min, d_max - d_min);
+        const float x_r = rho * f(AF_INV_H);
         return lut2d(R.transmittance_tex.data, UnitToTex<256>(x_mu), UnitToTex<64>(x_r));
     }
     VPT_D f3 Transmittance(float r, float mu, float d, bool ground) const {           // :472
-        float r_d = ClampRadius((float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r)));
-        float mu_d = ClampCosine((r * mu + d) / r_d);
-        if (ground) return fmin3(TransmittanceToTop(r_d, -mu_d) / TransmittanceToTop(r, -mu), mk3(1.0f));
-        return fmin3(TransmittanceToTop(r, mu) / TransmittanceToTop(r_d, mu_d), mk3(1.0f));
+        const float r_d = ClampRadius(RadiusAt(r, mu, d));
+        const float mu_d = ClampCosine(fdiv(r * mu + d, r_d));
+        f3 num, den;
+        if (ground) { num = TransmittanceToTop(r_d, -mu_d); den = TransmittanceToTop(r, -mu); }
+        else { num = TransmittanceToTop(r, mu); den = TransmittanceToTop(r_d, mu_d); }
+        return fmin3(mk3(fdiv(num.x, den.x), fdiv(num.y, den.y), fdiv(num.z, den.z)), mk3(1.0f));
     }
     VPT_D f3 TransmittanceToSun(float r, float mu_s) const {                          // :486
-        float sin_theta_h = bottom() / r;
-        float cos_theta_h = -sqrtf(fmax_(1.0f - sin_theta_h * sin_theta_h, 0.0f));
-        float sa = f(AF_SUN_ANG);
-        return TransmittanceToTop(r, mu_s) * smoothstep(-sin_theta_h * sa, sin_theta_h * sa, mu_s - cos_theta_h);
+        const float sin_theta_h = fdiv(bottom(), r);
+        const float cos_theta_h = -fsqrt(fmax_(1.0f - sin_theta_h * sin_theta_h, 0.0f));
+        const float sa = f(AF_SUN_ANG);
+        const float a = -sin_theta_h * sa, b = sin_theta_h * sa;
+        const float y = clampf(fdiv(mu_s - cos_theta_h - a, b - a), 0.0f, 1.0f);     // smoothstep
+        return TransmittanceToTop(r, mu_s) * (y * y * (3.0f - (2.0f * y)));
     }
     VPT_D static float RayleighPhase(float nu) {                                      // :508
-        float k = 3.0f / (16.0f * VPT_PI);
+        const float k = 3.0f / (16.0f * VPT_PI);
         return k * (1.0f + nu * nu);
     }
     VPT_D static float MiePhase(float g, float nu) {                                  // :514
-        float k = 3.0f / (8.0f * VPT_PI) * (1.0f - g * g) / (2.0f + g * g);
+        const float k = fdiv(3.0f / (8.0f * VPT_PI) * (1.0f - g * g), 2.0f + g * g);
         const float b = 1.0f + g * g - 2.0f * g * nu;
-        return k * (1.0f + nu * nu) / (b * sqrtf(b));     // pow(b, 1.5)
+        return fdiv(k * (1.0f + nu * nu), b * fsqrt(b));                              // pow(b, 1.5)
     }
     VPT_D f4 ScatteringUvwz(float r, float mu, float mu_s, float nu, bool ground) const {   // :520-569
-        float H = sqrtf(top() * top() - bottom() * bottom());
-        float rho = SafeSqrt(r * r - bottom() * bottom());
-        float u_r = UnitToTex<32>(rho / H);
-        float r_mu = r * mu;
-        float disc = r_mu * r_mu - r * r + bottom() * bottom();
+        const float H = f(AF_H);
+        const float rho = SafeSqrt(r * r - bottom() * bottom());
+        const float u_r = UnitToTex<32>(rho * f(AF_INV_H));
+        const float r_mu = r * mu;
+        const float disc = r_mu * r_mu - r * r + bottom() * bottom();
         float u_mu;
         if (ground) {
-            float d = -r_mu - SafeSqrt(disc);
-            float d_min = r - bottom();
-            float d_max = rho;
-            u_mu = 0.5f - 0.5f * UnitToTex<64>(d_max == d_min ? 0.0f : (d - d_min) / (d_max - d_min));
+            const float d = -r_mu - SafeSqrt(disc);
+            const float d_min = r - bottom();
+            const float d_max = rho;
+            u_mu = 0.5f - 0.5f * UnitToTex<64>(d_max == d_min ? 0.0f : fdiv(d - d_min, d_max - d_min));
         } else {
-            float d = -r_mu + SafeSqrt(disc + H * H);
-            float d_min = top() - r;
-            float d_max = rho + H;
-            u_mu = 0.5f + 0.5f * UnitToTex<64>((d - d_min) / (d_max - d_min));
+            const float d = -r_mu + SafeSqrt(disc + H * H);
+            const float d_min = top() - r;
+            const float d_max = rho + H;
+            u_mu = 0.5f + 0.5f * UnitToTex<64>(fdiv(d - d_min, d_max - d_min));
         }
-        float d = DistanceToTop(bottom(), mu_s);
-        float d_min = top() - bottom();
-        float d_max = H;
-        float a = (d - d_min) / (d_max - d_min);
-        float A = -2.0f * f(AF_MU_S_MIN) * bottom() / (d_max - d_min);
-        float u_mu_s = UnitToTex<32>(fmax_(1.0f - a / A, 0.0f) / (1.0f + a));
-        float u_nu = (nu + 1.0f) / 2.0f;
+        const float d = DistanceToTop(bottom(), mu_s);
+        const float a = (d - (top() - bottom())) * f(AF_INV_DMUS);
+        const float u_mu_s = UnitToTex<32>(fdiv(fmax_(1.0f - a * f(AF_INV_A), 0.0f), 1.0f + a));
+        const float u_nu = (nu + 1.0f) * 0.5f;
         return mk4(u_nu, u_mu_s, u_mu, u_r);
     }
-    // bilinear (y, z) x linear (x) fetch of BOTH 3-D tables at one u, sharing the taps
-    VPT_D void fetch_pair(const Tap& tx, const Tap& ty, const Tap& tz, f3& sc, f3& mie) const {
-        const float4* ps = reinterpret_cast<const float4*>(R.scattering_tex.data);
-        const float4* pm = reinterpret_cast<const float4*>(R.single_mie_tex.data);
-        const int r00 = (tz.i0 * 128 + ty.i0) * 256, r10 = (tz.i0 * 128 + ty.i1) * 256;
-        const int r01 = (tz.i1 * 128 + ty.i0) * 256, r11 = (tz.i1 * 128 + ty.i1) * 256;
+    // bilinear (y, z) x linear (x) fetch of BOTH 3-D tables at one u, sharing the row offsets
+    VPT_D void fetch_pair(const Tap& tx, const uint32_t r00, const uint32_t r10, const uint32_t r01, const uint32_t r11, float ay, float az,
+                          f3& sc, f3& mie) const {
+        const float4* __restrict__ ps = reinterpret_cast<const float4*>(R.scattering_tex.data);
+        const float4* __restrict__ pm = reinterpret_cast<const float4*>(R.single_mie_tex.data);
         {
-            const f3 c00 = lerp3r(ld_f3(ps, r00 + tx.i0), ld_f3(ps, r00 + tx.i1), tx.a);
-            const f3 c10 = lerp3r(ld_f3(ps, r10 + tx.i0), ld_f3(ps, r10 + tx.i1), tx.a);
-            const f3 c01 = lerp3r(ld_f3(ps, r01 + tx.i0), ld_f3(ps, r01 + tx.i1), tx.a);
-            const f3 c11 = lerp3r(ld_f3(ps, r11 + tx.i0), ld_f3(ps, r11 + tx.i1), tx.a);
-            sc = lerp3r(lerp3r(c00, c10, ty.a), lerp3r(c01, c11, ty.a), tz.a);
+            const f3 c00 = flerp3(ld_f3(ps, r00 + tx.i0), ld_f3(ps, r00 + tx.i1), tx.a);
+            const f3 c10 = flerp3(ld_f3(ps, r10 + tx.i0), ld_f3(ps, r10 + tx.i1), tx.a);
+            const f3 c01 = flerp3(ld_f3(ps, r01 + tx.i0), ld_f3(ps, r01 + tx.i1), tx.a);
+            const f3 c11 = flerp3(ld_f3(ps, r11 + tx.i0), ld_f3(ps, r11 + tx.i1), tx.a);
+            sc = flerp3(flerp3(c00, c10, ay), flerp3(c01, c11, ay), az);
         }
         {
-            const f3 c00 = lerp3r(ld_f3(pm, r00 + tx.i0), ld_f3(pm, r00 + tx.i1), tx.a);
-            const f3 c10 = lerp3r(ld_f3(pm, r10 + tx.i0), ld_f3(pm, r10 + tx.i1), tx.a);
-            const f3 c01 = lerp3r(ld_f3(pm, r01 + tx.i0), ld_f3(pm, r01 + tx.i1), tx.a);
-            const f3 c11 = lerp3r(ld_f3(pm, r11 + tx.i0), ld_f3(pm, r11 + tx.i1), tx.a);
-            mie = lerp3r(lerp3r(c00, c10, ty.a), lerp3r(c01, c11, ty.a), tz.a);
+            const f3 c00 = flerp3(ld_f3(pm, r00 + tx.i0), ld_f3(pm, r00 + tx.i1), tx.a);
+            const f3 c10 = flerp3(ld_f3(pm, r10 + tx.i0), ld_f3(pm, r10 + tx.i1), tx.a);
+            const f3 c01 = flerp3(ld_f3(pm, r01 + tx.i0), ld_f3(pm, r01 + tx.i1), tx.a);
+            const f3 c11 = flerp3(ld_f3(pm, r11 + tx.i0), ld_f3(pm, r11 + tx.i1), tx.a);
+            mie = flerp3(flerp3(c00, c10, ay), flerp3(c01, c11, ay), az);
         }
     }
     VPT_D f3 CombinedScattering(float r, float mu, float mu_s, float nu, bool ground, f3& single_mie) const {  // :672
-        f4 uvwz = ScatteringUvwz(r, mu, mu_s, nu, ground);
-        float tex_coord_x = uvwz.x * 7.0f;
-        float tex_x = floorf(tex_coord_x);
-        float lerp = tex_coord_x - tex_x;
-        float u0 = (tex_x + uvwz.y) / 8.0f;
-        float u1 = (tex_x + 1.0f + uvwz.y) / 8.0f;
-        float l0 = 1.0f - lerp;
+        const f4 uvwz = ScatteringUvwz(r, mu, mu_s, nu, ground);
+        const float tex_coord_x = uvwz.x * 7.0f;
+        const float tex_x = floorf(tex_coord_x);
+        const float lerp = tex_coord_x - tex_x;
+        const float u0 = (tex_x + uvwz.y) * 0.125f;
+        const float u1 = (tex_x + 1.0f + uvwz.y) * 0.125f;
         const Tap ty = lut_tap<128, false>(uvwz.z), tz = lut_tap<32, false>(uvwz.w);
+        const uint32_t r00 = (tz.i0 * 128u + ty.i0) * 256u, r10 = (tz.i0 * 128u + ty.i1) * 256u;
+        const uint32_t r01 = (tz.i1 * 128u + ty.i0) * 256u, r11 = (tz.i1 * 128u + ty.i1) * 256u;
         f3 s0, m0, s1, m1;
-        fetch_pair(lut_tap<256, false>(u0), ty, tz, s0, m0);
-        fetch_pair(lut_tap<256, false>(u1), ty, tz, s1, m1);
-        single_mie = m0 * l0 + m1 * lerp;
-        return s0 * l0 + s1 * lerp;
+        fetch_pair(lut_tap<256, false>(u0), r00, r10, r01, r11, ty.a, tz.a, s0, m0);
+        fetch_pair(lut_tap<256, false>(u1), r00, r10, r01, r11, ty.a, tz.a, s1, m1);
+        single_mie = flerp3(m0, m1, lerp);            // m0 (1 - lerp) + m1 lerp
+        return flerp3(s0, s1, lerp);
     }
     VPT_D f3 Irradiance(float r, float mu_s) const {                                  // :633-654
-        float x_r = (r - bottom()) / (top() - bottom());
-        float x_mu_s = mu_s * 0.5f + 0.5f;
+        const float x_r = (r - bottom()) * f(AF_INV_TB);
+        const float x_mu_s = ffma(mu_s, 0.5f, 0.5f);
         return lut2d(R.irradiance_tex.data, UnitToTex<256>(x_mu_s), UnitToTex<64>(x_r));
     }
     VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance) const {   // :694 (shadow_length = 0)
         float r = length(camera);
         float rmu = dot(camera, view_ray);
-        float dtop = -rmu - sqrtf(rmu * rmu - r * r + top() * top());
+        const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
         if (dtop > 0.0f) {
             camera = camera + view_ray * dtop;
             r = top();
@@ -183,93 +235,89 @@ struct Sky {
             transmittance = mk3(1.0f);
             return mk3(0.0f);
         }
-        float mu = rmu / r;
-        float mu_s = dot(camera, sun_direction) / r;
-        float nu = dot(view_ray, sun_direction);
-        bool ground = HitsGround(r, mu);
+        const float inv_r = frcp(r);
+        const float mu = rmu * inv_r;
+        const float mu_s = dot(camera, sun_direction) * inv_r;
+        const float nu = dot(view_ray, sun_direction);
+        const bool ground = HitsGround(r, mu);
         transmittance = ground ? mk3(0.0f) : TransmittanceToTop(r, mu);
         f3 single_mie;
-        f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
-        f3 sky = scattering * RayleighPhase(nu) + single_mie * MiePhase(f(AF_MIE_G), nu);
+        const f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        f3 sky = fscale_add3(single_mie, MiePhase(f(AF_MIE_G), nu), scattering * RayleighPhase(nu));
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
     VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance) const {   // :749 (shadow_length = 0)
-        f3 view_ray = normalize(point - camera);
+        const f3 delta = point - camera;
+        float d = length(delta);
+        const f3 view_ray = delta * frcp(d);
         float r = length(camera);
         float rmu = dot(camera, view_ray);
-        float dtop = -rmu - sqrtf(rmu * rmu - r * r + top() * top());
+        const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
         if (dtop > 0.0f) {
             camera = camera + view_ray * dtop;
             r = top();
             rmu += dtop;
+            d = length(point - camera);
         }
-        float mu = rmu / r;
-        float mu_s = dot(camera, sun_direction) / r;
-        float nu = dot(view_ray, sun_direction);
-        float d = length(point - camera);
-        bool ground = HitsGround(r, mu);
+        const float inv_r = frcp(r);
+        const float mu = rmu * inv_r;
+        const float mu_s = dot(camera, sun_direction) * inv_r;
+        const float nu = dot(view_ray, sun_direction);
+        const bool ground = HitsGround(r, mu);
         transmittance = Transmittance(r, mu, d, ground);
         f3 single_mie;
         f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
         d = fmax_(d, 0.0f);
-        float r_p = ClampRadius((float)sqrt((double)(d * d) + 2.0 * (double)r * (double)mu * (double)d + (double)(r * r)));
-        float mu_p = (r * mu + d) / r_p;
-        float mu_s_p = (r * mu_s + d * nu) / r_p;
+        const float r_p = ClampRadius(RadiusAt(r, mu, d));
+        const float inv_rp = frcp(r_p);
+        const float mu_p = (r * mu + d) * inv_rp;
+        const float mu_s_p = (r * mu_s + d * nu) * inv_rp;
         f3 single_mie_p;
-        f3 scattering_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, ground, single_mie_p);
-        f3 shadow_t = transmittance;
-        scattering = scattering - shadow_t * scattering_p;
-        single_mie = single_mie - shadow_t * single_mie_p;
-        single_mie = single_mie * smoothstep(0.0f, 0.01f, mu_s);
-        f3 sky = scattering * RayleighPhase(nu) + single_mie * MiePhase(f(AF_MIE_G), nu);
+        const f3 scattering_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, ground, single_mie_p);
+        scattering = scattering - transmittance * scattering_p;
+        single_mie = single_mie - transmittance * single_mie_p;
+        const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);                           // smoothstep(0, 0.01, mu_s)
+        single_mie = single_mie * (y * y * (3.0f - (2.0f * y)));
+        f3 sky = fscale_add3(single_mie, MiePhase(f(AF_MIE_G), nu), scattering * RayleighPhase(nu));
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
     // sample_atmosphere :839-895
     VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction) const {
-        f3 earth_center = mk3(.0f, -bottom(), .0f);
-        f3 p = ray_pos - earth_center;
-        float p_dot_v = dot(p, ray_dir);
-        float p_dot_p = dot(p, p);
-        float d2 = p_dot_p - p_dot_v * p_dot_v;
-        float dist = -p_dot_v - sqrtf(earth_center.y * earth_center.y - d2);
-        float ground_alpha = 0.0f;
-        f3 ground_radiance = mk3(0.0f);
+        const f3 earth_center = mk3(.0f, -bottom(), .0f);
+        const f3 p = ray_pos - earth_center;
+        const float p_dot_v = dot(p, ray_dir);
+        const float p_dot_p = dot(p, p);
+        const float d2 = p_dot_p - p_dot_v * p_dot_v;
+        const float dist = -p_dot_v - fsqrt(earth_center.y * earth_center.y - d2);
+        f3 radiance;
         if (dist > 0.0f) {
-            f3 point = ray_pos + ray_dir * dist;
-            f3 normal = normalize(point - earth_center);
-            f3 pt = point - earth_center;
-            float r = length(pt);
-            float mu_s = dot(pt, sun_direction) / r;
-            f3 sky_irr = Irradiance(r, mu_s) * ((1.0f + dot(normal, pt) / r) * 0.5f);     // :818
+            const f3 pt = ray_pos + ray_dir * dist - earth_center;
+            const float r = length(pt);
+            const float inv_r = frcp(r);
+            const f3 normal = pt * inv_r;
+            const float mu_s = dot(pt, sun_direction) * inv_r;
+            f3 sky_irr = Irradiance(r, mu_s) * ((1.0f + dot(normal, pt) * inv_r) * 0.5f);     // :818
             f3 sun_irr = v(AF_SOLAR) * TransmittanceToSun(r, mu_s) * fmax_(dot(normal, sun_direction), 0.0f);
             if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
-            ground_radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
+            radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
             f3 tr;
-            f3 in_scatter = SkyRadianceToPoint(ray_pos - earth_center, pt, sun_direction, tr);
-            ground_radiance = ground_radiance * tr + in_scatter;
-            ground_alpha = 1.0f;
-        }
-        if (ground_alpha == 0.0f) {
-            // lerp(radiance_sky, ground_radiance, ground_alpha) (:881): with the ground hit the blend weight
-            // is exactly 1 and the sky-only radiance only enters as a + (b - a), i.e. b to within one
-            // rounding -- it is not evaluated then (value-only path)
+            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr);
+            radiance = radiance * tr + in_scatter;
+            // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
+            // rounding: the sky-only branch below is not evaluated for ground hits
+        } else {
             f3 tr_sky;
-            f3 radiance_sky = SkyRadiance(ray_pos - earth_center, ray_dir, sun_direction, tr_sky);
-            float sa = f(AF_SUN_ANG);
-            if (dot(ray_dir, sun_direction) > cosf(sa)) {
-                f3 solar = v(AF_SOLAR) / (VPT_PI * sa * sa);
-                if (lum()) solar *= v(AF_SUN_K);
-                radiance_sky = radiance_sky + tr_sky * solar;
-            }
-            ground_radiance = radiance_sky;
+            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky);
+            if (dot(ray_dir, sun_direction) > f(AF_COS_SUN)) radiance = radiance + tr_sky * v(AF_SOLAR_RAD);
         }
-        f3 exposure = lum() ? mk3(f(AF_EXPOSURE)) * 1e-5f : mk3(f(AF_EXPOSURE));
-        f3 e = -ground_radiance / v(AF_WHITE) * exposure;
-        f3 om = mk3(1.0f) - mk3(__expf(e.x), __expf(e.y), __expf(e.z));
-        const float g = (float)(1.0 / 2.2);
-        return mk3(__powf(om.x, g), __powf(om.y, g), __powf(om.z, g));
+        // pow(1 - exp(-radiance / white_point * exposure), 1 / 2.2)   (:883-885)
+        const f3 e = radiance * v(AF_EXPO_W);
+        const float l2e = 1.4426950408889634f, g = (float)(1.0 / 2.2);
+        const f3 om = mk3(1.0f - __builtin_amdgcn_exp2f(-e.x * l2e), 1.0f - __builtin_amdgcn_exp2f(-e.y * l2e), 1.0f - __builtin_amdgcn_exp2f(-e.z * l2e));
+        return mk3(__builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(om.x)), __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(om.y)),
+                   __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(om.z)));
     }
 };
 
