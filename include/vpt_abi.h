@@ -303,9 +303,9 @@ typedef struct vpt_render_stats {
     unsigned long long skip_steps;        /* empty-node pushes                         */
     unsigned long long queued_rays;       /* rays the last batch handed to the tracer  */
     float              trace_ms;          /* HIP-event time of trace_kernel            */
-    float              resolve_ms;        /* HIP-event time of resolve_kernel          */
+    float              resolve_ms;        /* 0: the resolve is fused into the tail kernel */
     float              raygen_ms;         /* HIP-event time of raygen_kernel           */
-    float              tail_ms;           /* HIP-event time of tail_kernel             */
+    float              tail_ms;           /* HIP-event time of tail_resolve_kernel      */
 } vpt_render_stats;
 /* enable/disable look-up counting (off by default: counting costs atomics) */
 int  vpt_set_counting(vpt_ctx *ctx, int enable);

@@ -24,8 +24,7 @@ namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
-hipError_t launch_tail(const ResolveParams& R, hipStream_t stream);
-hipError_t launch_resolve(const ResolveParams& R, hipStream_t stream);
+hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream);
 }  // namespace vpt
 
@@ -788,11 +787,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (kp->integrator != 0) HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
         else HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
-        HIPCHK(ctx, launch_tail(R, stream));
+        HIPCHK(ctx, launch_tail_resolve(R, stream));             // environment tail + resolve, fused
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));
-        HIPCHK(ctx, launch_resolve(R, stream));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[4]], stream));
-        for (int k = 0; k < 4; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
+        for (int k = 0; k < 3; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
         ctx->last_samples += total;
     }
     return VPT_OK;

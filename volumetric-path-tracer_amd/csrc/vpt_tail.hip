@@ -1,9 +1,10 @@
-// vpt_tail.hip -- stage 2 of the hot path: the environment tail of direct_integrator
-// (render_kernel.cu:1838-1850) for every pixel-sample of a batch: Bruneton sky `sample_atmosphere`
-// (:839-895) or the lat-long HDRI.
+// vpt_tail.hip -- last stage of the hot path, fused: the environment tail of the integrators
+// (direct_integrator render_kernel.cu:1838-1850, vol_integrator :1752: Bruneton sky
+// `sample_atmosphere` :839-895 or the lat-long HDRI) for every path record of a batch, followed by
+// what volume_rt_kernel does with a sample value (:2263-2316): NaN guard, running means, tonemap.
 //
-// This is VALUE-ONLY arithmetic: nothing downstream branches on it that feeds a random walk, the
-// result is added to L once.  The reference evaluates it with `--use_fast_math`
+// The environment value is VALUE-ONLY arithmetic: nothing downstream branches on it that feeds a
+// random walk, the result is added to L once.  The reference evaluates it with `--use_fast_math`
 // (source/CMakeLists.txt:133); this translation unit is likewise built with approximate fp32
 // divide/sqrt and FMA contraction and uses the hardware exp/log/pow (see build.py) -- unlike the
 // strict-arithmetic tracer.  Tolerance against the oracle: tests/test_gpu_atmosphere.py.
@@ -13,42 +14,102 @@
 
 namespace vpt {
 
-// stage 2: environment tail, one thread per pixel-sample (every sample of the batch, including
-// the primary-ray misses finalised by raygen).  Rewrites the first 16 bytes of the record to
-// {value.xyz, tr}; the rest of the line is left alone.
-__global__ __launch_bounds__(256) void tail_kernel(const ResolveParams R) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= R.n_pixels * R.iter_count) return;
-    float4* rec = reinterpret_cast<float4*>(const_cast<Record*>(R.records) + s);
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    f3 value = mk3(q0.x, q0.y, q0.z);
-    const f3 beta = mk3(q1.x, q1.y, q1.z);
-    const f3 env_pos = mk3(q2.x, q2.y, q2.z);
-    const uint32_t flags = __float_as_uint(q2.w);
-    const f3 dir = mk3(q3.x, q3.y, q3.z);
-    if (flags & 1u) {
-        const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
-        const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
-        if (R.integrator != 0) {
-            // vol_integrator :1752: L += beta * sample_atmosphere(ray_pos, ray_dir) -- always the
-            // procedural sky, no sky_mult / sky_color, whatever environment_type says
-            const Sky<ResolveParams> sky = {R};
-            value += beta * sky.sample(env_pos, dir, sun_dir);
-        } else if (R.environment_type == 0) {                                       // :1838-1842
-            if (R.has_atmosphere) {
-                const Sky<ResolveParams> sky = {R};
-                value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
-            }
-        } else {                                                                     // :1843-1850
-            value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
-        }
-    }
-    rec[0] = make_float4(value.x, value.y, value.z, q0.w);
+// IEEE divide regardless of this translation unit's relaxed flags (the accumulation below is
+// order- and rounding-sensitive: it is the running mean of the reference, :2278-2287)
+VPT_D f3 div_rn(f3 a, float b) { return mk3(__fdiv_rn(a.x, b), __fdiv_rn(a.y, b), __fdiv_rn(a.z, b)); }
+VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
+    f3 a = v * (v + 0.0245786f) - 0.000090537f;
+    f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    return mk3(__fdiv_rn(a.x, b.x), __fdiv_rn(a.y, b.y), __fdiv_rn(a.z, b.z));
 }
 
-hipError_t launch_tail(const ResolveParams& R, hipStream_t stream) {
-    const uint32_t total = R.n_pixels * R.iter_count;
-    hipLaunchKernelGGL(tail_kernel, dim3((total + 255u) / 256u), dim3(256), 0, stream, R);
+// stage 3 (last): one thread per PIXEL walks the batch's path records in iteration order:
+//   environment tail of the integrator (direct :1838-1850 / vol :1752)  -> sample value
+//   NaN/Inf guard (:2263-2264), viz_dof tint (:2266-2274), running means (:2278-2287)
+// and, once per batch, ACES tonemap + gamma + 8-bit pack + raw buffer (:2292-2316).
+// Adjacent lanes read adjacent 64-byte records (4 KiB contiguous per wave and iteration); the sky
+// evaluation is the dominant cost and runs at full lane utilisation.
+__global__ __launch_bounds__(256) void tail_resolve_kernel(const ResolveParams R) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R.n_pixels) return;
+    f3 acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
+    f3 cst = R.cost ? mk3(R.cost[3 * idx], R.cost[3 * idx + 1], R.cost[3 * idx + 2]) : mk3(0.0f);
+    float dep = R.depth ? R.depth[idx] : 0.0f;
+    float tr_last = 0.0f;
+    const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
+    const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const Sky<ResolveParams> sky = {R};
+
+    for (uint32_t k = 0; k < R.iter_count; ++k) {
+        const uint32_t iteration = R.iter_begin + k * R.iter_stride;
+        const uint32_t local_it = iteration / R.iter_stride;
+        const float4* rec = reinterpret_cast<const float4*>(R.records + ((size_t)k * R.n_pixels + idx));
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        f3 value = mk3(q0.x, q0.y, q0.z);
+        float tr = q0.w;
+        const f3 beta = mk3(q1.x, q1.y, q1.z);
+        const float depth = q1.w;
+        const f3 env_pos = mk3(q2.x, q2.y, q2.z);
+        const uint32_t flags = __float_as_uint(q2.w);
+        const f3 dir = mk3(q3.x, q3.y, q3.z);
+        if (flags & 1u) {
+            if (R.integrator != 0) {
+                // vol_integrator :1752: L += beta * sample_atmosphere(ray_pos, ray_dir) -- always the
+                // procedural sky, no sky_mult / sky_color, whatever environment_type says
+                value += beta * sky.sample(env_pos, dir, sun_dir);
+            } else if (R.environment_type == 0) {                                   // :1838-1842
+                if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
+            } else {                                                                 // :1843-1850
+                value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
+            }
+        }
+        // :2263-2264
+        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
+        if (isnan(tr) || isinf(tr)) tr = 1.0f;
+        // :2266-2274
+        if (R.viz_dof) {
+            float aof = clampf(__fdiv_rn(1.0f, R.lens_radius), .0f, 3.402823466e+38F);
+            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
+            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
+            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
+        }
+        // :2278-2287 (cost is always BLACK, :2249)
+        if (local_it == 0) {
+            acc = value;
+            cst = mk3(0.0f);
+            dep = depth;
+        } else if (iteration < R.max_interactions) {
+            const float n = (float)(local_it + 1);
+            acc = acc + div_rn(value - acc, n);
+            cst = cst + div_rn(mk3(0.0f) - cst, n);
+            dep = dep + __fdiv_rn(depth - dep, n);
+        }
+        tr_last = tr;
+    }
+    R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;
+    if (R.cost) { R.cost[3 * idx] = cst.x; R.cost[3 * idx + 1] = cst.y; R.cost[3 * idx + 2] = cst.z; }
+    if (R.depth) R.depth[idx] = dep;
+
+    if (R.display || R.raw) {
+        // :2292-2316
+        f3 val = mk3(0.59719f * acc.x + 0.35458f * acc.y + 0.04823f * acc.z,
+                     0.07600f * acc.x + 0.90834f * acc.y + 0.01566f * acc.z,
+                     0.02840f * acc.x + 0.13383f * acc.y + 0.83777f * acc.z);
+        val = rtt_and_odt_fit(val);
+        val = mk3(1.60475f * val.x + -0.53108f * val.y + -0.07367f * val.z,
+                  -0.10208f * val.x + 1.10813f * val.y + -0.00605f * val.z,
+                  -0.00327f * val.x + -0.07276f * val.y + 1.07602f * val.z) * R.exposure_scale;
+        const float ig = (float)(1.0 / 2.2);
+        const unsigned int r = (unsigned int)(255.0f * fmin_(powf(fmax_(val.x, 0.0f), ig), 1.0f));
+        const unsigned int g = (unsigned int)(255.0f * fmin_(powf(fmax_(val.y, 0.0f), ig), 1.0f));
+        const unsigned int b = (unsigned int)(255.0f * fmin_(powf(fmax_(val.z, 0.0f), ig), 1.0f));
+        if (R.display) R.display[idx] = 0xff000000u | (r << 16) | (g << 8) | b;
+        if (R.raw) reinterpret_cast<float4*>(R.raw)[idx] = make_float4(val.x, val.y, val.z, tr_last);
+    }
+}
+
+hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream) {
+    hipLaunchKernelGGL(tail_resolve_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
     return hipGetLastError();
 }
 
