@@ -50,8 +50,8 @@ struct vpt_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu = 4;
-    uint32_t regen_min = 24;
-    uint32_t trans_min = 48;
+    uint32_t regen_min = 8;
+    uint32_t trans_min = 32;
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene

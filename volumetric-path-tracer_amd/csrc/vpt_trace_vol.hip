@@ -132,7 +132,22 @@ VPT_D float sample_spherical(Rng rng, f3& wi) {
     return 1.0f / (4.0f * VPT_PI);
 }
 
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
+// SKYLUT: environment_type == 0 -- estimate_sky evaluates the Bruneton sky inside the tracer (large
+// code, high register pressure); the HDRI instantiation (BASELINE config 4) carries none of it.
+// out of line on purpose: the sky evaluation needs ~130 registers of its own; inlined (twice) into
+// the state machine it pushed the whole kernel into scratch spills inside the walk loop
+__device__ __noinline__ void sky_eval(const TraceParams* P, float px, float py, float pz, float dx, float dy, float dz, float* out) {
+    const Sky<TraceParams> sky = {*P};
+    const f3 r = sky.sample(mk3(px, py, pz), mk3(dx, dy, dz), ld3(P->sun_dir));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
+    float o[3];
+    sky_eval(&P, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, o);
+    return mk3(o[0], o[1], o[2]);
+}
+
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT>
 __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[VPT_HIST_CAP * 256];
@@ -145,7 +160,6 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
     const f3 sun_dir = ld3(P.sun_dir);
     const uint32_t regen_min = P.regen_min;
     const uint32_t trans_min = P.trans_min;
-    const Sky<TraceParams> sky = {P};
 
     uint32_t phase = VH_IDLE;
     uint32_t tr_next = VH_IDLE;     // state entered when the current shadow walk ends
@@ -371,9 +385,9 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             } else if (phase == VH_T_SKY_A1 && !drew) {
                 // light sampling :1378-1402; the samplers work on a copy of the rng (peek)
                 drew = true;
-                if (P.environment_type == 0) {
+                if (SKYLUT) {
                     light_pdf = draw_sample_from_distribution(P, rng, wi);
-                    Li = sky.sample(ppos, wi, sun_dir);
+                    Li = sky_at(P, ppos, wi);
                 } else {
                     light_pdf = sample_spherical(rng, wi);
                     Li = env_lookup(P.env_tex, wi);
@@ -398,14 +412,15 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                 drew = true;
                 phase = VH_T_SKY_END;
                 if (phase_pdf > .0f) {
-                    light_pdf = P.environment_type == 0 ? pdf_li(P, wi) : 1.0f / (4.0f * VPT_PI);
+                    light_pdf = SKYLUT ? pdf_li(P, wi) : 1.0f / (4.0f * VPT_PI);
                     if (light_pdf != 0.0f) {                                        // :1416 `return Ld`
                         mis_w = power_heuristic(phase_pdf, light_pdf);
                         start_tr = true; tr_dir = wi; tr_done = VH_T_SKY_D; phase = VH_W_TR;
                     }
                 }
             } else if (phase == VH_T_SKY_D) {
-                Li = P.environment_type == 0 ? sky.sample(ppos, wi, sun_dir) : env_lookup(P.env_tex, wi);
+                if (SKYLUT) Li = sky_at(P, ppos, wi);
+                else Li = env_lookup(P.env_tex, wi);
                 if (!is_black(Li)) w.Ld += Li * mk3(w.trw) * mis_w;
                 phase = VH_T_SKY_END;
             }
@@ -475,22 +490,23 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
     }
 }
 
-template <bool MULTI, bool COLOR, bool EMIT>
+template <bool GENERIC, bool SKYLUT>
 static hipError_t launch_vol_variant(const TraceParams& P, int blocks, hipStream_t stream) {
-    if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<MULTI, COLOR, EMIT, true>), dim3(blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL((trace_vol_kernel<MULTI, COLOR, EMIT, false>), dim3(blocks), dim3(256), 0, stream, P);
+    if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, true, SKYLUT>), dim3(blocks), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, false, SKYLUT>), dim3(blocks), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 
+// Two scene specialisations only (the generic one handles any mix of instances / colour / emission
+// grids with the same results: COLOR with no colour grid yields Cd = 1, EMIT is gated by
+// emission_scale), times the environment kind.
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream) {
-    if (!multi && !color && !emit) return launch_vol_variant<false, false, false>(P, blocks, stream);
-    if (!multi && !color && emit) return launch_vol_variant<false, false, true>(P, blocks, stream);
-    if (!multi && color && !emit) return launch_vol_variant<false, true, false>(P, blocks, stream);
-    if (!multi && color && emit) return launch_vol_variant<false, true, true>(P, blocks, stream);
-    if (multi && !color && !emit) return launch_vol_variant<true, false, false>(P, blocks, stream);
-    if (multi && !color && emit) return launch_vol_variant<true, false, true>(P, blocks, stream);
-    if (multi && color && !emit) return launch_vol_variant<true, true, false>(P, blocks, stream);
-    return launch_vol_variant<true, true, true>(P, blocks, stream);
+    const bool generic = multi || color || emit;
+    const bool skylut = P.environment_type == 0;
+    if (!generic && !skylut) return launch_vol_variant<false, false>(P, blocks, stream);
+    if (!generic && skylut) return launch_vol_variant<false, true>(P, blocks, stream);
+    if (generic && !skylut) return launch_vol_variant<true, false>(P, blocks, stream);
+    return launch_vol_variant<true, true>(P, blocks, stream);
 }
 
 }  // namespace vpt

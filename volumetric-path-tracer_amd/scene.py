@@ -34,15 +34,20 @@ def make_gpu_vdb(density, bbox_min, bbox_max, matrix, voxel_size, emission=None,
     density: float32 [z, y, x] dense copy over the active bbox.  matrix: OpenVDB Mat4d
     (row-vector convention).  xform[i][j] = matrix(j, i) (gpu_vdb.cpp:81-92).
     """
-    d = np.ascontiguousarray(density, dtype=np.float32)
     v = GpuVdb()
     vi = v.vdb_info
+    if isinstance(density, np.ndarray):
+        d = np.ascontiguousarray(density, dtype=np.float32)
+        dmax, dmin = d.max(), np.maximum(FLT_EPSILON, d).min()
+    else:                                                                       # torch tensor already in HBM
+        d = density
+        dmax, dmin = np.float32(d.max().item()), np.float32(d.clamp(min=float(FLT_EPSILON)).min().item())
     vi.voxelsize = float(np.float32(voxel_size))
     vi.dim = Int3(int(d.shape[2]), int(d.shape[1]), int(d.shape[0]))
     vi.bmin = f3(np.asarray(bbox_min, dtype=np.float32))
     vi.bmax = f3(np.asarray(bbox_max, dtype=np.float32))
-    vi.max_density = float(max(np.float32(0.0), d.max()))                       # gpu_vdb.cpp:206
-    vi.min_density = float(min(FLT_MAX, np.maximum(FLT_EPSILON, d).min()))      # gpu_vdb.cpp:207
+    vi.max_density = float(max(np.float32(0.0), dmax))                          # gpu_vdb.cpp:206
+    vi.min_density = float(min(FLT_MAX, dmin))                                  # gpu_vdb.cpp:207
     vi.has_color = 1 if color is not None else 0
     vi.has_emission = 1 if emission is not None else 0
     m = np.asarray(matrix, dtype=np.float64).astype(np.float32)
@@ -184,13 +189,22 @@ class HipBinding:
         self.dev = torch.device("cuda", self.ctx.device)
         ctx = self.ctx
         vols = []
+        shared = {}                          # instances of one file share its textures (main.cpp:1064)
         for vdb, dens, emis, col in sd.volumes:
             v = GpuVdb.from_buffer_copy(vdb)
-            v.vdb_info.density_texture = ctx.texture(dens, 1)
+            if isinstance(dens, np.ndarray):
+                tex_key = id(dens)
+                if tex_key not in shared:
+                    shared[tex_key] = ctx.texture(dens, 1)
+                v.vdb_info.density_texture = shared[tex_key]
+            else:                            # torch tensor in HBM: adopted without a copy
+                v.vdb_info.density_texture = ctx.texture_device(dens, (dens.shape[2], dens.shape[1], dens.shape[0]), 1)
             if emis is not None:
                 v.vdb_info.emission_texture = ctx.texture(emis, 1)
             if col is not None:
-                v.vdb_info.color_texture = ctx.texture(col, 4)
+                if id(col) not in shared:
+                    shared[id(col)] = ctx.texture(col, 4)
+                v.vdb_info.color_texture = shared[id(col)]
             vols.append(v)
         self.volumes = vols
         ctx.set_volumes(vols)
@@ -319,6 +333,48 @@ def cloud_grid(shape=(1216, 704, 1024), seed=42, occupancy=0.35, chunk=64):
     return d
 
 
+def cloud_grid_torch(shape=(1216, 704, 1024), seed=42, occupancy=0.35, device="cuda", chunk=64):
+    """cloud_grid evaluated on the GPU with torch (bench-only generator for the full-size config 4
+    grid, 3.5 GB): same construction -- 4 octaves of trilinear value noise on random lattices,
+    thresholded to ~`occupancy`, normalised to max 1 -- returned as a CUDA float32 tensor [z, y, x]."""
+    import torch
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    lats = []
+    for o in range(4):
+        c = 4 * (1 << o)
+        lats.append(torch.from_numpy(rng.random((c + 1, c + 1, c + 1), dtype=np.float32)).to(device))
+
+    def axis(n, c):
+        a = torch.arange(n, device=device, dtype=torch.float32) * (c / n)
+        i = torch.clamp(a.to(torch.int64), max=c - 1)
+        f = a - i.to(torch.float32)
+        return i, f * f * (3 - 2 * f)
+
+    for z0 in range(0, nz, chunk):
+        z1 = min(nz, z0 + chunk)
+        acc = torch.zeros((z1 - z0, ny, nx), dtype=torch.float32, device=device)
+        amp, total = 1.0, 0.0
+        for o, lat in enumerate(lats):
+            c = lat.shape[0] - 1
+            iz, fz = axis(nz, c); iy, fy = axis(ny, c); ix, fx = axis(nx, c)
+            iz, fz = iz[z0:z1], fz[z0:z1]
+            # separable trilinear: interpolate x, then y, then z
+            lx = lat[:, :, ix] * (1 - fx) + lat[:, :, ix + 1] * fx                      # [c+1, c+1, nx]
+            ly = lx[:, iy, :] * (1 - fy)[None, :, None] + lx[:, iy + 1, :] * fy[None, :, None]     # [c+1, ny, nx]
+            v = ly[iz] * (1 - fz)[:, None, None] + ly[iz + 1] * fz[:, None, None]
+            acc += amp * v
+            total += amp
+            amp *= 0.5
+        out[z0:z1] = acc / total
+    sub = out[::4, ::4, ::4].flatten()
+    thr = torch.quantile(sub[torch.randperm(sub.numel(), device=device)[:4_000_000]], 1.0 - occupancy)
+    out.sub_(thr).clamp_(min=0.0)
+    out.mul_(1.0 / max(1e-6, float(out.max())))
+    return out
+
+
 def hdri_map(w=2048, h=1024, seed=7):
     """Synthetic lat-long HDRI: sky gradient + ground + a sun lobe."""
     rng = np.random.default_rng(seed)
@@ -405,12 +461,13 @@ def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacin
     return _finish(sd)
 
 
-def cloud_scene(width, height, shape=(152, 88, 128), env=(512, 256), integrator=1, lib=None):
+def cloud_scene(width, height, shape=(152, 88, 128), env=(512, 256), integrator=1, lib=None, device_grid=None):
     """BASELINE config 4: large fBm cloud, synthetic lat-long HDRI (environment_type = 1),
     vol_integrator.  The caller binds atmosphere LUTs (vol_integrator's tail is always the
     procedural sky, render_kernel.cu:1752)."""
     lib = lib or load_library()
-    dens = cloud_grid(shape)
+    dens = device_grid if device_grid is not None else cloud_grid(shape)
+    shape = tuple(int(x) for x in dens.shape)
     sd = SceneDesc()
     sd.width, sd.height = int(width), int(height)
     voxel = 40.0 / shape[2]
