@@ -23,6 +23,11 @@ int vpt_test_device_uniform_stream(vpt_ctx *ctx, unsigned long long seed, unsign
 /* n draws of the product's own Philox stream (csrc/vpt_rng.h) for key = seed, offset, drawn
  * through the trace kernel's refill-point protocol */
 int vpt_test_device_product_stream(vpt_ctx *ctx, unsigned int key, unsigned int offset, int n, float *out);
+/* schedule histogram of the last counted render (vpt_set_counting(ctx, 1)): wave-level sums of
+ * [0] tracer loop passes, [1] walking lanes, [2] lanes parked in transition states, [3] idle lanes,
+ * [4] passes that ran transitions, [5] inner transition passes, [6] lanes in them, [7] lanes that
+ * executed the tracking step proper */
+int vpt_test_get_schedule(vpt_ctx *ctx, unsigned long long out[8]);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""perf probe over bench scenes: python tools/perf_probe2.py --config c3 --spp 16 --set VPT_TRANS_MIN=8,32"""
+import argparse, itertools, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c3"); ap.add_argument("--spp", type=int, default=8); ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--set", action="append", default=[])
+a = ap.parse_args()
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+S = pkg.scene
+if a.config == "c3": sd = S.fireball_scene(1920, 1080, n=256)
+elif a.config == "c5": sd = S.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0)
+elif a.config == "c4":
+    sd = S.cloud_scene(1920, 1080, env=(2048, 1024), integrator=1, device_grid=S.cloud_grid_torch((608, 352, 512), device="cuda"))
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+else:
+    sd = S.dragon_scene(1920, 1080, a.config)
+    if a.config == "c2": pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+keys = [s.split("=")[0] for s in a.set]; vals = [s.split("=")[1].split(",") for s in a.set]
+for combo in itertools.product(*vals) if vals else [()]:
+    for k, v in zip(keys, combo): os.environ[k] = v
+    hb = S.HipBinding(sd, device=0)
+    best = None
+    for _ in range(a.reps):
+        hb.render(a.spp, iteration=0); hb.sync(); st = hb.ctx.stats()
+        tot = st.raygen_ms + st.trace_ms + st.tail_ms + st.resolve_ms
+        if best is None or tot < best[0]: best = (tot, st.raygen_ms, st.trace_ms, st.tail_ms)
+    n = sd.width * sd.height * a.spp
+    print(a.config, " ".join("%s=%s" % kv for kv in zip(keys, combo)), "raygen %.3f trace %.3f tail %.3f ms -> %.1f Msamples/s" % (best[1], best[2], best[3], n / best[0] / 1e3), flush=True)
+    hb.ctx.close()
+
+import ctypes as C
+hb = S.HipBinding(sd, device=0)
+hb.ctx.set_counting(True)
+hb.render(min(a.spp, 4), iteration=0); hb.sync()
+out = (C.c_ulonglong * 8)()
+pkg.load_library().vpt_test_get_schedule(hb.ctx.h, out)
+o = list(out); st = hb.ctx.stats()
+if o[0]:
+    print("schedule: passes %d | per pass: walking %.1f, parked-in-T %.1f, idle %.1f lanes | trans passes %.3f/pass with %.1f lanes each (%.2f inner passes) | tracking-step lanes %.1f/pass"
+          % (o[0], o[1] / o[0], o[2] / o[0], o[3] / o[0], o[4] / o[0], o[6] / max(1, o[5]), o[5] / max(1, o[4]), o[7] / o[0]))
+    print("per traced ray: passes*64/rays = %.1f lane-passes, steps %.2f, skips %.2f" % (o[0] * 64 / max(1, st.queued_rays), st.tracking_steps / max(1, st.queued_rays), st.skip_steps / max(1, st.queued_rays)))

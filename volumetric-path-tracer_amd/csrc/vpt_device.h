@@ -76,6 +76,11 @@ struct Counters {
     unsigned long long emission_lookups;
     unsigned long long tracking_steps;
     unsigned long long skip_steps;
+    // schedule histogram of the tracer (counting builds only; wave-level sums, see vpt_testhooks.h):
+    // [0] loop passes, [1] walking lanes, [2] lanes parked in transition states, [3] idle lanes,
+    // [4] passes that ran transitions, [5] inner transition passes, [6] lanes in them,
+    // [7] lanes that executed the tracking step proper (after the empty-node loop)
+    unsigned long long sched[8];
 };
 
 struct TraceParams {

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/vpt_abi.h"
+#include "../../include/vpt_testhooks.h"
 #include "vpt_device.h"
 
 namespace vpt {
@@ -520,6 +521,15 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         out->tracking_steps = c.tracking_steps;
         out->skip_steps = c.skip_steps;
     }
+    return VPT_OK;
+}
+
+int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    Counters c;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    std::memcpy(out, c.sched, sizeof(c.sched));
     return VPT_OK;
 }
 

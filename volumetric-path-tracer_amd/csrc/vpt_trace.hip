@@ -301,7 +301,24 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         // >= trans_min lanes wait for it or nothing else can make progress.
         const unsigned long long tmask = __ballot(phase >= PH_T_FIRST);
         const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
+        if (COUNT) {
+            const unsigned long long wm = __ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST), im = __ballot(phase == PH_IDLE);
+            if (lane == 0) {
+                atomicAdd(&P.counters->sched[0], 1ull);
+                atomicAdd(&P.counters->sched[1], (unsigned long long)__popcll(wm));
+                atomicAdd(&P.counters->sched[2], (unsigned long long)__popcll(tmask));
+                atomicAdd(&P.counters->sched[3], (unsigned long long)__popcll(im));
+                if (run_trans) atomicAdd(&P.counters->sched[4], 1ull);
+            }
+        }
         while (run_trans && __any(phase >= PH_T_FIRST)) {
+            if (COUNT) {
+                const unsigned long long tm = __ballot(phase >= PH_T_FIRST);
+                if (lane == 0) {
+                    atomicAdd(&P.counters->sched[5], 1ull);
+                    atomicAdd(&P.counters->sched[6], (unsigned long long)__popcll(tm));
+                }
+            }
             rng_top_up(rng, pixel);
             bool start_tr = false;
             uint32_t tr_walk_phase = PH_IDLE, tr_done_phase = PH_IDLE;

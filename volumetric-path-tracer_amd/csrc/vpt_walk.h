@@ -104,6 +104,10 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     }
     if (st == LOC_EMPTY) return false;           // still crossing empty nodes: next pass
     if (st == LOC_OUTSIDE) return true;
+    if (COUNT) {
+        const unsigned long long m = __ballot(1);
+        if (__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&P.counters->sched[7], (unsigned long long)__popcll(m));
+    }
     if (is_sample) {
         // :1647-1651
         float t_min, t_max, geo_dist;
