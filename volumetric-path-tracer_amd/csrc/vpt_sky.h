@@ -90,9 +90,10 @@ VPT_D Tap lut_tap(float u) {
 VPT_D f3 lut2d(const float* data, float u, float v) {
     const float4* p = reinterpret_cast<const float4*>(data);
     const Tap tx = lut_tap<256, true>(u), ty = lut_tap<64, false>(v);
-    const f3 c0 = flerp3(ld_f3(p, ty.i0 * 256u + tx.i0), ld_f3(p, ty.i0 * 256u + tx.i1), tx.a);
-    const f3 c1 = flerp3(ld_f3(p, ty.i1 * 256u + tx.i0), ld_f3(p, ty.i1 * 256u + tx.i1), tx.a);
-    return flerp3(c0, c1, ty.a);
+    f3 c = flerp3(ld_f3(p, ty.i0 * 256u + tx.i0), ld_f3(p, ty.i0 * 256u + tx.i1), tx.a);
+    if (ty.a != 0.0f)          // a zero weight is exact: c0 + 0 (c1 - c0) == c0 (points ON the ground: rho = 0)
+        c = flerp3(c, flerp3(ld_f3(p, ty.i1 * 256u + tx.i0), ld_f3(p, ty.i1 * 256u + tx.i1), tx.a), ty.a);
+    return c;
 }
 
 template <class RP>
@@ -182,24 +183,29 @@ struct Sky {
         const float u_nu = (nu + 1.0f) * 0.5f;
         return mk4(u_nu, u_mu_s, u_mu, u_r);
     }
-    // bilinear (y, z) x linear (x) fetch of BOTH 3-D tables at one u, sharing the row offsets
+    // bilinear (y, z) x linear (x) fetch of BOTH 3-D tables at one u, sharing the row offsets.
+    // A zero interpolation weight is exact -- c0 + 0 (c1 - c0) == c0 -- so rows / slices with weight 0
+    // are not fetched: a point ON the ground (r = bottom: rho = 0 and d_min = d_max) sits exactly on
+    // the first r slice and on a mu row, and needs 2 of the 8 texels per table.
     VPT_D void fetch_pair(const Tap& tx, const uint32_t r00, const uint32_t r10, const uint32_t r01, const uint32_t r11, float ay, float az,
                           f3& sc, f3& mie) const {
         const float4* __restrict__ ps = reinterpret_cast<const float4*>(R.scattering_tex.data);
         const float4* __restrict__ pm = reinterpret_cast<const float4*>(R.single_mie_tex.data);
-        {
-            const f3 c00 = flerp3(ld_f3(ps, r00 + tx.i0), ld_f3(ps, r00 + tx.i1), tx.a);
-            const f3 c10 = flerp3(ld_f3(ps, r10 + tx.i0), ld_f3(ps, r10 + tx.i1), tx.a);
-            const f3 c01 = flerp3(ld_f3(ps, r01 + tx.i0), ld_f3(ps, r01 + tx.i1), tx.a);
-            const f3 c11 = flerp3(ld_f3(ps, r11 + tx.i0), ld_f3(ps, r11 + tx.i1), tx.a);
-            sc = flerp3(flerp3(c00, c10, ay), flerp3(c01, c11, ay), az);
+        sc = flerp3(ld_f3(ps, r00 + tx.i0), ld_f3(ps, r00 + tx.i1), tx.a);
+        mie = flerp3(ld_f3(pm, r00 + tx.i0), ld_f3(pm, r00 + tx.i1), tx.a);
+        if (ay != 0.0f) {
+            sc = flerp3(sc, flerp3(ld_f3(ps, r10 + tx.i0), ld_f3(ps, r10 + tx.i1), tx.a), ay);
+            mie = flerp3(mie, flerp3(ld_f3(pm, r10 + tx.i0), ld_f3(pm, r10 + tx.i1), tx.a), ay);
         }
-        {
-            const f3 c00 = flerp3(ld_f3(pm, r00 + tx.i0), ld_f3(pm, r00 + tx.i1), tx.a);
-            const f3 c10 = flerp3(ld_f3(pm, r10 + tx.i0), ld_f3(pm, r10 + tx.i1), tx.a);
-            const f3 c01 = flerp3(ld_f3(pm, r01 + tx.i0), ld_f3(pm, r01 + tx.i1), tx.a);
-            const f3 c11 = flerp3(ld_f3(pm, r11 + tx.i0), ld_f3(pm, r11 + tx.i1), tx.a);
-            mie = flerp3(flerp3(c00, c10, ay), flerp3(c01, c11, ay), az);
+        if (az != 0.0f) {
+            f3 s1 = flerp3(ld_f3(ps, r01 + tx.i0), ld_f3(ps, r01 + tx.i1), tx.a);
+            f3 m1 = flerp3(ld_f3(pm, r01 + tx.i0), ld_f3(pm, r01 + tx.i1), tx.a);
+            if (ay != 0.0f) {
+                s1 = flerp3(s1, flerp3(ld_f3(ps, r11 + tx.i0), ld_f3(ps, r11 + tx.i1), tx.a), ay);
+                m1 = flerp3(m1, flerp3(ld_f3(pm, r11 + tx.i0), ld_f3(pm, r11 + tx.i1), tx.a), ay);
+            }
+            sc = flerp3(sc, s1, az);
+            mie = flerp3(mie, m1, az);
         }
     }
     VPT_D f3 CombinedScattering(float r, float mu, float mu_s, float nu, bool ground, f3& single_mie) const {  // :672
