@@ -162,12 +162,13 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
 }
 #ifndef VPT_TRACE_WAVES_PER_EU
-#define VPT_TRACE_WAVES_PER_EU 2
+#define VPT_TRACE_WAVES_PER_EU 3
 #endif
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
 __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[VPT_HIST_CAP * 256];      // [entry][thread]: densities seen by the fused first walk
+    __shared__ float s_park[30 * 256];                // [field][thread]: path-level state parked in LDS
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
 
@@ -184,7 +185,6 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     Rng rng;
     rng.c0 = rng.o0 = rng.o1 = rng.o2 = rng.o3 = rng.idx = rng.carry = rng.has_carry = 0u;
     uint32_t draws = 0;            // draws since the stream origin of this sample (offset iteration*4096)
-    uint32_t cam_draws = 0;        // draws consumed by camera::get_ray
     Walk w;                        // current walk ray + walk results
     w.pos = w.dir = w.inv = mk3(0.0f);
     w.t = w.distance = 0.0f;
@@ -193,16 +193,18 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     w.wgt = mk3(1.0f);
     w.Ld = mk3(0.0f);
     w.mi = w.geo = w.obj2 = false;
-    f3 ppos = mk3(0.0f), pdir = mk3(0.0f);                      // path ray parked during shadow / emission walks
-    f3 org0 = mk3(0.0f), dir0 = mk3(0.0f);                      // primary ray
-    f3 env_pos = mk3(0.0f);
-    f3 beta = mk3(1.0f), L = mk3(0.0f);
-    float depth = 0.0f;
-    int rd = 0, vd = 0, budget = 0, light_index = 0;
+    float* const park = s_park + threadIdx.x;
+    const LdsF3 ppos = {park + 0 * 256}, pdir = {park + 3 * 256};    // path ray parked during shadow / emission walks
+    const LdsF3 org0 = {park + 6 * 256}, dir0 = {park + 9 * 256};    // primary ray
+    const LdsF3 env_pos = {park + 12 * 256};
+    const LdsF3 beta = {park + 15 * 256}, L = {park + 18 * 256};
+    const LdsF depth = {park + 21 * 256}, sph_factor = {park + 22 * 256};
+    int* const parki = reinterpret_cast<int*>(park);
+    const LdsI rd = {parki + 23 * 256}, vd = {parki + 24 * 256}, budget = {parki + 25 * 256}, light_index = {parki + 26 * 256};
+    const LdsI cam_draws_p = {parki + 27 * 256};
     uint32_t n_hist = 0;
     int gco_obj = -1;              // cached get_closest_object result for the current (pos, dir), -1 = stale
     float gco_t = 0.0f;
-    float sph_factor = 0.0f;
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
     bool more = true;
@@ -250,13 +252,13 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         rng.carry = 0u; rng.has_carry = 0u;
                         depth = q3.z;
                         draws = rng.c0 * 4u + rng.idx - iteration * 4096u;
-                        cam_draws = draws;
+                        cam_draws_p = (int)draws;                    // draws consumed by camera::get_ray
                         // depth_calculator :1859-1889 and direct_integrator :1772-1785 start from the
                         // same ray with the same rng copy
                         w.alpha = 0.0f;
-                        env_pos = org0;
-                        w.pos = org0;
-                        w.dir = dir0;
+                        env_pos = mk3(q0.x, q0.y, q0.z);
+                        w.pos = mk3(q0.x, q0.y, q0.z);
+                        w.dir = mk3(q1.x, q1.y, q1.z);
                         w.inv = rcp3(w.dir);
                         L = mk3(0.0f);
                         beta = mk3(1.0f);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 
             if (phase == PH_T_FIRST_DONE) {
                 // the walk just finished IS depth_calculator's walk (:1879-1881) ...
-                depth = w.mi ? length(org0 - w.pos) : .0f;
+                depth = w.mi ? length(f3(org0) - w.pos) : .0f;
                 // ... and direct_integrator's first sample() call (:1789), which would add the same
                 // densities to Alpha a second time (:1670)
                 if (w.alpha < 1.0f) {
@@ -347,10 +349,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 // history overflow (long walk through thin medium): replay the integrator's first walk
                 // for real, from the primary ray and the post-camera rng state
                 const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                const uint32_t cam_draws = (uint32_t)(int)cam_draws_p;
                 rng_init(rng, pixel, iteration * 4096u + cam_draws);
                 draws = cam_draws;
-                w.pos = org0;
-                w.dir = dir0;
+                w.pos = f3(org0);
+                w.dir = f3(dir0);
                 w.inv = rcp3(w.dir);
                 w.mi = false;
                 rd = 1;
@@ -360,14 +363,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             if (phase == PH_T_TRACK_DONE) {
                 // :1789-1796
                 beta *= w.wgt;
-                const bool brk = is_black(beta) || w.obj2;
+                const bool brk = is_black(f3(beta)) || w.obj2;
                 if (!brk && w.mi) {
                     sample_hg(w.dir, rng, draws, P.phase_g1);
                     w.inv = rcp3(w.dir);
                 }
                 gco_obj = -1;
                 vd++;
-                if (!brk && vd <= P.volume_depth) {
+                if (!brk && (int)vd <= P.volume_depth) {
                     w.mi = false;
                     w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
                     phase = PH_W_TRACK;
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     phase = PH_T_OUTER_SECOND;
                 }
             } else if (phase == PH_T_SUN_DONE) {
-                const float cos_theta = dot(pdir, sun_dir);
+                const float cos_theta = dot(f3(pdir), sun_dir);
                 const float phase_pdf = henyey_greenstein(cos_theta, P.phase_g1);
                 const f3 Lsun = mk3(w.trw) * phase_pdf;
-                L += (Lsun * ld3(P.sun_color) * P.sun_mult) * beta;                 // :1514, :1798
+                L += (Lsun * ld3(P.sun_color) * P.sun_mult) * f3(beta);             // :1514, :1798
                 if (P.num_lights > 0) {
                     budget = 10;                                                    // :1459
                     w.Ld = mk3(0.0f);
@@ -392,35 +395,37 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     phase = PH_T_EMIT_CHECK;
                 }
             } else if (phase == PH_T_PL_DONE) {
-                if (budget < P.num_lights) {
+                if ((int)budget < P.num_lights) {
                     // point_light::Le, light.h:104-121
-                    const DPointLight& lt = P.lights[light_index];
+                    const DPointLight& lt = P.lights[(int)light_index];
                     const f3 lp = ld3(lt.pos);
-                    const f3 wi = normalize(lp - ppos);
-                    const float cos_theta = dot(pdir, wi);
+                    const f3 pp = ppos;
+                    const f3 wi = normalize(lp - pp);
+                    const float cos_theta = dot(f3(pdir), wi);
                     const float phase_pdf = henyey_greenstein(cos_theta, P.phase_g1);
-                    const float sqr_dist = length(lp * lp - ppos * ppos);
+                    const float sqr_dist = length(lp * lp - pp * pp);
                     const float falloff = 1 / sqr_dist;
                     w.Ld += ld3(lt.color) * lt.power * mk3(w.trw) * phase_pdf * falloff;
                 }
                 budget--;
-                if (budget >= 0) phase = PH_T_PL_NEXT;
+                if ((int)budget >= 0) phase = PH_T_PL_NEXT;
                 else {
-                    L += w.Ld * beta;                                               // :1799
+                    L += w.Ld * f3(beta);                                           // :1799
                     phase = PH_T_EMIT_CHECK;
                 }
             }
             if (phase == PH_T_PL_NEXT) {
                 // estimate_point_light :1461-1466 (1 draw)
-                light_index = (int)floorf(rnd(rng, draws) * P.num_lights);
-                if (light_index > P.num_lights - 1) light_index = P.num_lights - 1;  // rand()==1.0f guard
-                const DPointLight& lt = P.lights[light_index];
-                start_tr = true; tr_dir = normalize(ld3(lt.pos) - ppos); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
+                int li = (int)floorf(rnd(rng, draws) * P.num_lights);
+                if (li > P.num_lights - 1) li = P.num_lights - 1;                    // rand()==1.0f guard
+                light_index = li;
+                const DPointLight& lt = P.lights[li];
+                start_tr = true; tr_dir = normalize(ld3(lt.pos) - f3(ppos)); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
             } else if (phase == PH_T_EMIT_CHECK || phase == PH_T_EMIT_DONE || phase == PH_T_SPH_DONE) {
                 if (phase == PH_T_EMIT_DONE) L += w.Ld;                             // :1803
-                if (phase == PH_T_SPH_DONE) L += ld3(P.sun_color) * P.sun_mult * mk3(w.trw) * sph_factor * beta;  // :1832
-                w.pos = ppos;
-                w.dir = pdir;
+                if (phase == PH_T_SPH_DONE) L += ld3(P.sun_color) * P.sun_mult * mk3(w.trw) * (float)sph_factor * f3(beta);  // :1832
+                w.pos = f3(ppos);
+                w.dir = f3(pdir);
                 w.inv = rcp3(w.dir);
                 gco_obj = -1;
                 if (phase == PH_T_EMIT_CHECK && EMIT && P.emission_scale > 0) {     // :1802 (mi is true here)
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 }
             }
             if (phase == PH_T_OUTER_TOP) {
-                if (rd > P.ray_depth) {
+                if ((int)rd > P.ray_depth) {
                     phase = PH_T_FINISH;
                 } else {
                     if (gco_obj < 0) gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t);   // :1782
@@ -487,11 +492,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 }
             }
             if (phase == PH_T_FINISH) {
-                const f3 od = w.dir;
+                const f3 od = w.dir, oL = L, ob = beta, oe = env_pos;
                 float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
-                dst[0] = make_float4(L.x, L.y, L.z, fmin_(w.alpha, 1.0f));         // tr = fminf(tr, 1) :1854
-                dst[1] = make_float4(beta.x, beta.y, beta.z, depth);
-                dst[2] = make_float4(env_pos.x, env_pos.y, env_pos.z, __uint_as_float(1u));
+                dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // tr = fminf(tr, 1) :1854
+                dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
+                dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
                 dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
                 if (COUNT) {
                     atomicAdd(&P.counters->samples, 1ull);
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
 
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
-            if (start_tr) phase = tr_begin(P, K, w, ppos, tr_dir) ? tr_walk_phase : tr_done_phase;
+            if (start_tr) phase = tr_begin(P, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
         }
     }
 }

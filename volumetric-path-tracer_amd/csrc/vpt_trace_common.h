@@ -12,6 +12,29 @@
 
 namespace vpt {
 
+// Path-level state that only the (infrequent) transition states touch lives in LDS, one column per
+// thread ([field][thread]: conflict-free), so that the walk loop keeps fewer registers live and a
+// third wave fits per SIMD.  The proxies make the integrator code read as if they were registers.
+struct LdsF {
+    float* p;
+    VPT_D operator float() const { return *p; }
+    VPT_D void operator=(float v) const { *p = v; }
+};
+struct LdsI {
+    int* p;
+    VPT_D operator int() const { return *p; }
+    VPT_D void operator=(int v) const { *p = v; }
+    VPT_D void operator++(int) const { *p += 1; }
+    VPT_D void operator--(int) const { *p -= 1; }
+};
+struct LdsF3 {
+    float* p;                                   // x at p[0], y at p[256], z at p[512]
+    VPT_D operator f3() const { return mk3(p[0], p[256], p[512]); }
+    VPT_D void operator=(f3 v) const { p[0] = v.x; p[256] = v.y; p[512] = v.z; }
+    VPT_D void operator+=(f3 v) const { p[0] += v.x; p[256] += v.y; p[512] += v.z; }
+    VPT_D void operator*=(f3 v) const { p[0] *= v.x; p[256] *= v.y; p[512] *= v.z; }
+};
+
 #define VPT_HIST_CAP 12
 #define VPT_CHUNK 256        // queue entries a wave claims per global atomic
 
