@@ -50,7 +50,7 @@ struct vpt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 3;
     uint32_t regen_min = 8;
     uint32_t trans_min = 32;
     std::string last_error;

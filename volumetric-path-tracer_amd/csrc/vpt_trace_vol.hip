@@ -148,9 +148,10 @@ VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
 }
 
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT>
-__global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[VPT_HIST_CAP * 256];
+    __shared__ float s_park[40 * 256];                // [field][thread]: path-level state parked in LDS (vpt_trace_common.h)
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
     uint32_t pixel = 0, kiter = 0;
     Rng rng;
     rng.c0 = rng.o0 = rng.o1 = rng.o2 = rng.o3 = rng.idx = rng.carry = rng.has_carry = 0u;
-    uint32_t draws = 0, cam_draws = 0;
+    uint32_t draws = 0;
     Walk w;
     w.pos = w.dir = w.inv = mk3(0.0f);
     w.t = w.distance = 0.0f;
@@ -175,15 +176,17 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
     w.wgt = mk3(1.0f);
     w.Ld = mk3(0.0f);
     w.mi = w.geo = w.obj2 = false;
-    f3 ppos = mk3(0.0f), pdir = mk3(0.0f);      // path ray parked during shadow / emission walks
-    f3 org0 = mk3(0.0f), dir0 = mk3(0.0f);
-    f3 beta = mk3(1.0f), L = mk3(0.0f);
-    f3 Lsel = mk3(0.0f);                        // what the selected light estimator returned
-    f3 A = mk3(0.0f);                           // beta * uniform_sample_one_light(...)
-    f3 Li = mk3(0.0f), wi = mk3(0.0f);          // estimate_sky scratch
-    float light_pdf = 0.0f, phase_pdf = 0.0f, mis_w = 0.0f;
-    float depth = 0.0f, t_box = 0.0f;
-    int vdepth = 0, budget = 0, light_index = 0;
+    float* const park = s_park + threadIdx.x;
+    int* const parki = reinterpret_cast<int*>(park);
+    const LdsF3 ppos = {park + 0 * 256}, pdir = {park + 3 * 256};     // path ray parked during shadow / emission walks
+    const LdsF3 org0 = {park + 6 * 256}, dir0 = {park + 9 * 256};
+    const LdsF3 beta = {park + 12 * 256}, L = {park + 15 * 256};
+    const LdsF3 Lsel = {park + 18 * 256};                              // what the selected light estimator returned
+    const LdsF3 A = {park + 21 * 256};                                 // beta * uniform_sample_one_light(...)
+    const LdsF3 Li = {park + 24 * 256}, wi = {park + 27 * 256};        // estimate_sky scratch
+    const LdsF light_pdf = {park + 30 * 256}, phase_pdf = {park + 31 * 256}, mis_w = {park + 32 * 256};
+    const LdsF depth = {park + 33 * 256}, t_box = {park + 34 * 256};
+    const LdsI vdepth = {parki + 35 * 256}, budget = {parki + 36 * 256}, light_index = {parki + 37 * 256}, cam_draws_p = {parki + 38 * 256};
     uint32_t n_hist = 0;
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
@@ -219,8 +222,9 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
                         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-                        org0 = mk3(q0.x, q0.y, q0.z);
-                        dir0 = mk3(q1.x, q1.y, q1.z);
+                        const f3 o0 = mk3(q0.x, q0.y, q0.z), d0 = mk3(q1.x, q1.y, q1.z);
+                        org0 = o0;
+                        dir0 = d0;
                         const int obj = (int)__float_as_uint(q1.w);      // get_closest_object of the primary ray
                         rng.o0 = __float_as_uint(q2.x); rng.o1 = __float_as_uint(q2.y);
                         rng.o2 = __float_as_uint(q2.z); rng.o3 = __float_as_uint(q2.w);
@@ -230,12 +234,12 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                         depth = q3.z;
                         t_box = q3.w;
                         draws = rng.c0 * 4u + rng.idx - iteration * 4096u;
-                        cam_draws = draws;
+                        cam_draws_p = (int)draws;
                         // vol_integrator :1732-1737: every queued ray hits the root box
                         w.alpha = 0.0f;
-                        w.dir = dir0;
+                        w.dir = d0;
                         w.inv = rcp3(w.dir);
-                        w.pos = org0 + w.dir * (t_box + VPT_EPS);
+                        w.pos = o0 + w.dir * (q3.w + VPT_EPS);
                         L = mk3(0.0f);
                         beta = mk3(1.0f);
                         vdepth = 1;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             uint32_t tr_done = VH_IDLE;
 
             if (phase == VH_T_FIRST_DONE) {
-                depth = w.mi ? length(org0 - w.pos) : .0f;                          // :1879-1881
+                depth = w.mi ? length(f3(org0) - w.pos) : .0f;                      // :1879-1881
                 // vol_integrator's first sample() (:1740) adds the same densities to Alpha again
                 if (w.alpha < 1.0f) {
                     if (n_hist > VPT_HIST_CAP) {
@@ -296,11 +300,12 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             if (phase == VH_T_REPLAY) {
                 // history overflow: walk the integrator's first segment for real
                 const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                const uint32_t cam_draws = (uint32_t)(int)cam_draws_p;
                 rng_init(rng, pixel, iteration * 4096u + cam_draws);
                 draws = cam_draws;
-                w.dir = dir0;
+                w.dir = f3(dir0);
                 w.inv = rcp3(w.dir);
-                w.pos = org0 + w.dir * (t_box + VPT_EPS);
+                w.pos = f3(org0) + w.dir * ((float)t_box + VPT_EPS);
                 w.mi = false;
                 w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
                 phase = VH_W_TRACK;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             if (phase == VH_T_VTRACK_DONE) {
                 // :1740-1747
                 beta *= w.wgt;
-                if (is_black(beta)) {
+                if (is_black(f3(beta))) {
                     phase = VH_T_FINISH;
                 } else if (!w.mi) {
                     // no interaction: either the walk left the root box (every later sample() is a
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                     vdepth++;
                     f3 nmin, nmax;
                     int leaf;
-                    if (vdepth > P.ray_depth || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
+                    if ((int)vdepth > P.ray_depth || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
                         phase = VH_T_FINISH;
                     } else {
                         w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
@@ -348,23 +353,23 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                 }
             } else if (phase == VH_T_SUN_DONE) {
                 // estimate_sun :1478-1516
-                const float cos_theta = dot(pdir, sun_dir);
+                const float cos_theta = dot(f3(pdir), sun_dir);
                 const float pp = henyey_greenstein(cos_theta, P.phase_g1);
                 Lsel = (mk3(w.trw) * pp) * ld3(P.sun_color) * P.sun_mult;
                 phase = VH_T_LIGHT_DONE;
             } else if (phase == VH_T_PL_DONE) {
-                if (budget < P.num_lights) {
-                    const DPointLight& lt = P.lights[light_index];                  // point_light::Le, light.h:104-121
-                    const f3 lp = ld3(lt.pos);
-                    const f3 wl = normalize(lp - ppos);
-                    const float cos_theta = dot(pdir, wl);
+                if ((int)budget < P.num_lights) {
+                    const DPointLight& lt = P.lights[(int)light_index];             // point_light::Le, light.h:104-121
+                    const f3 lp = ld3(lt.pos), pq = ppos;
+                    const f3 wl = normalize(lp - pq);
+                    const float cos_theta = dot(f3(pdir), wl);
                     const float pp = henyey_greenstein(cos_theta, P.phase_g1);
-                    const float sqr_dist = length(lp * lp - ppos * ppos);
+                    const float sqr_dist = length(lp * lp - pq * pq);
                     const float falloff = 1 / sqr_dist;
                     w.Ld += ld3(lt.color) * lt.power * mk3(w.trw) * pp * falloff;
                 }
                 budget--;
-                if (budget >= 0) phase = VH_T_PL_NEXT;
+                if ((int)budget >= 0) phase = VH_T_PL_NEXT;
                 else {
                     Lsel = w.Ld;
                     phase = VH_T_LIGHT_DONE;
@@ -372,10 +377,11 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             }
             if (phase == VH_T_PL_NEXT && !drew) {
                 // estimate_point_light :1461-1466 (1 draw)
-                light_index = (int)floorf(rnd(rng, draws) * P.num_lights);
+                int li = (int)floorf(rnd(rng, draws) * P.num_lights);
                 drew = true;
-                if (light_index > P.num_lights - 1) light_index = P.num_lights - 1;  // rand()==1.0f guard
-                start_tr = true; tr_dir = normalize(ld3(P.lights[light_index].pos) - ppos); tr_done = VH_T_PL_DONE; phase = VH_W_TR;
+                if (li > P.num_lights - 1) li = P.num_lights - 1;                    // rand()==1.0f guard
+                light_index = li;
+                start_tr = true; tr_dir = normalize(ld3(P.lights[li].pos) - f3(ppos)); tr_done = VH_T_PL_DONE; phase = VH_W_TR;
             } else if (phase == VH_T_SKY_A0 && !drew) {
                 // estimate_sky :1373-1374: two draws that are never used
                 (void)rnd(rng, draws);
@@ -385,43 +391,52 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             } else if (phase == VH_T_SKY_A1 && !drew) {
                 // light sampling :1378-1402; the samplers work on a copy of the rng (peek)
                 drew = true;
+                f3 wv, Lv;
+                float lp;
                 if (SKYLUT) {
-                    light_pdf = draw_sample_from_distribution(P, rng, wi);
-                    Li = sky_at(P, ppos, wi);
+                    lp = draw_sample_from_distribution(P, rng, wv);
+                    Lv = sky_at(P, f3(ppos), wv);
                 } else {
-                    light_pdf = sample_spherical(rng, wi);
-                    Li = env_lookup(P.env_tex, wi);
+                    lp = sample_spherical(rng, wv);
+                    Lv = env_lookup(P.env_tex, wv);
                 }
+                light_pdf = lp;
+                wi = wv;
+                Li = Lv;
                 phase = VH_T_SKY_C;
-                if (light_pdf > .0f && !is_black(Li)) {
-                    phase_pdf = henyey_greenstein(dot(pdir, wi), P.phase_g1);
-                    if (phase_pdf > .0f) { start_tr = true; tr_dir = wi; tr_done = VH_T_SKY_B; phase = VH_W_TR; }
+                if (lp > .0f && !is_black(Lv)) {
+                    const float pp = henyey_greenstein(dot(f3(pdir), wv), P.phase_g1);
+                    phase_pdf = pp;
+                    if (pp > .0f) { start_tr = true; tr_dir = wv; tr_done = VH_T_SKY_B; phase = VH_W_TR; }
                 }
             } else if (phase == VH_T_SKY_B) {
-                Li *= mk3(w.trw);
-                if (!is_black(Li)) {
-                    const float weight = power_heuristic(light_pdf, phase_pdf);
-                    w.Ld += Li * phase_pdf * weight / light_pdf;
+                const f3 Lv = f3(Li) * mk3(w.trw);
+                if (!is_black(Lv)) {
+                    const float lp = light_pdf, pp = phase_pdf;
+                    const float weight = power_heuristic(lp, pp);
+                    w.Ld += Lv * pp * weight / lp;
                 }
                 phase = VH_T_SKY_C;
             }
             if (phase == VH_T_SKY_C && !drew) {
                 // phase-function sampling :1404-1431 (2 draws)
-                wi = pdir;
-                phase_pdf = sample_hg_pdf(wi, rng, draws, P.phase_g1);
+                f3 wv = pdir;
+                const float pp = sample_hg_pdf(wv, rng, draws, P.phase_g1);
+                wi = wv;
                 drew = true;
                 phase = VH_T_SKY_END;
-                if (phase_pdf > .0f) {
-                    light_pdf = SKYLUT ? pdf_li(P, wi) : 1.0f / (4.0f * VPT_PI);
-                    if (light_pdf != 0.0f) {                                        // :1416 `return Ld`
-                        mis_w = power_heuristic(phase_pdf, light_pdf);
-                        start_tr = true; tr_dir = wi; tr_done = VH_T_SKY_D; phase = VH_W_TR;
+                if (pp > .0f) {
+                    const float lp = SKYLUT ? pdf_li(P, wv) : 1.0f / (4.0f * VPT_PI);
+                    if (lp != 0.0f) {                                               // :1416 `return Ld`
+                        mis_w = power_heuristic(pp, lp);
+                        start_tr = true; tr_dir = wv; tr_done = VH_T_SKY_D; phase = VH_W_TR;
                     }
                 }
             } else if (phase == VH_T_SKY_D) {
-                if (SKYLUT) Li = sky_at(P, ppos, wi);
-                else Li = env_lookup(P.env_tex, wi);
-                if (!is_black(Li)) w.Ld += Li * mk3(w.trw) * mis_w;
+                f3 Lv;
+                if (SKYLUT) Lv = sky_at(P, f3(ppos), f3(wi));
+                else Lv = env_lookup(P.env_tex, f3(wi));
+                if (!is_black(Lv)) w.Ld += Lv * mk3(w.trw) * (float)mis_w;
                 phase = VH_T_SKY_END;
             }
             if (phase == VH_T_SKY_END) {
@@ -429,22 +444,23 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                 phase = VH_T_LIGHT_DONE;
             }
             if (phase == VH_T_LIGHT_DONE) {
-                A = beta * (Lsel * 3.0f);                                           // :1553, :1745
-                w.pos = ppos;
-                w.dir = pdir;
+                const f3 Av = f3(beta) * (f3(Lsel) * 3.0f);                         // :1553, :1745
+                A = Av;
+                w.pos = f3(ppos);
+                w.dir = f3(pdir);
                 w.inv = rcp3(w.dir);
                 if (EMIT && P.emission_scale != 0) {                                // :1285
                     w.t = 0.0f;
                     w.Ld = mk3(0.0f);
                     phase = VH_W_EMIT;
                 } else {
-                    L += A + mk3(0.0f);
+                    L += Av + mk3(0.0f);
                     phase = VH_T_SCATTER;
                 }
             } else if (phase == VH_T_EMIT_DONE) {
-                L += A + w.Ld;                                                      // :1745
-                w.pos = ppos;
-                w.dir = pdir;
+                L += f3(A) + w.Ld;                                                  // :1745
+                w.pos = f3(ppos);
+                w.dir = f3(pdir);
                 phase = VH_T_SCATTER;
             }
             if (phase == VH_T_SCATTER && !drew) {
@@ -452,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
                 drew = true;
                 w.inv = rcp3(w.dir);
                 vdepth++;
-                if (vdepth > P.ray_depth) phase = VH_T_FINISH;
+                if ((int)vdepth > P.ray_depth) phase = VH_T_FINISH;
                 else {
                     w.mi = false;
                     w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
@@ -461,10 +477,11 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             }
             if (phase == VH_T_FINISH) {
                 const f3 od = normalize(w.dir);                                     // :1750
-                const f3 op = length(beta) > 0.9999f ? org0 : w.pos;                // :1753
+                const f3 ob = beta, oL = L;
+                const f3 op = length(ob) > 0.9999f ? f3(org0) : w.pos;              // :1753
                 float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
-                dst[0] = make_float4(L.x, L.y, L.z, fmin_(w.alpha, 1.0f));         // :1755
-                dst[1] = make_float4(beta.x, beta.y, beta.z, depth);
+                dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // :1755
+                dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
                 dst[2] = make_float4(op.x, op.y, op.z, __uint_as_float(1u));
                 dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
                 if (COUNT) {
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void trace_vol_kernel(const TraceParams P) 
             }
 
             if (start_tr) {
-                if (tr_begin(P, K, w, ppos, tr_dir)) {
+                if (tr_begin(P, K, w, f3(ppos), tr_dir)) {
                     tr_next = tr_done;
                     phase = VH_W_TR;
                 } else {
