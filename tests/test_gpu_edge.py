@@ -1,0 +1,123 @@
+"""Edge cases of volume_rt_kernel's own bookkeeping (render_kernel.cu:2227-2326), HIP vs oracle:
+frozen accumulation past max_interactions, render = false, viz_dof tint, exposure, the HDRI
+background of direct_integrator, ragged resolutions, batches that span several record chunks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((b ** 2).sum())))
+
+
+def _both(pkg, sd, n, atmosphere=False, **render_kw):
+    import oracle_binding
+    if atmosphere:
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    hb = pkg.scene.HipBinding(sd, device=0)
+    ob = oracle_binding.OracleBinding(sd)
+    hb.render(n, **render_kw)
+    hb.sync()
+    ob.render(n, **render_kw)
+    return hb, ob
+
+
+def _same(hb, ob, tol=2e-6):
+    got = hb.accum.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ob.accum) <= tol
+    np.testing.assert_allclose(hb.depth.cpu().numpy(), ob.depth, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(hb.raw.cpu().numpy(), ob.raw, rtol=2e-4, atol=2e-5)
+    disp = hb.display.cpu().numpy().view(np.uint32)
+    sh = np.array([16, 8, 0])
+    assert np.abs(((disp[:, None] >> sh) & 255).astype(int) - ((ob.display[:, None] >> sh) & 255).astype(int)).max() <= 1
+    np.testing.assert_array_equal(hb.blue_noise.cpu().numpy(), ob.blue_noise)
+
+
+def test_accumulation_freezes_past_max_interactions(pkg):
+    """iteration >= max_interactions: the sample is WHITE and is not accumulated (:2254, :2282)"""
+    sd = pkg.scene.dragon_scene(97, 61, "sun")               # ragged size: partial raygen tiles
+    sd.kp.max_interactions = 3
+    hb, ob = _both(pkg, sd, 6)
+    _same(hb, ob)
+    sd2 = pkg.scene.dragon_scene(97, 61, "sun")
+    hb2, _ = _both(pkg, sd2, 3)
+    np.testing.assert_array_equal(hb.accum.cpu().numpy(), hb2.accum.cpu().numpy())     # iterations 3..5 changed nothing
+
+
+def test_render_false_yields_white(pkg):
+    sd = pkg.scene.dragon_scene(64, 48, "c1")
+    sd.kp.render = 0
+    hb, ob = _both(pkg, sd, 2)
+    _same(hb, ob)
+    assert (hb.accum.cpu().numpy() == 1.0).all()             # value = WHITE (:2248)
+
+
+def test_viz_dof_and_exposure(pkg):
+    sd = pkg.scene.dragon_scene(96, 64, "sun")
+    lib = pkg.load_library()
+    import ctypes as C
+    cam, _, _ = pkg.scene.frame_camera(lib, [sd.volumes[0][0]], 96, 64, aperture=0.8)
+    cam.viz_dof = 1
+    sd.camera = cam
+    sd.kp.exposure_scale = 1.7
+    hb, ob = _both(pkg, sd, 3)
+    _same(hb, ob)
+    a = hb.accum.cpu().numpy()
+    assert (np.abs(a[:, 0] - a[:, 1]) > 1e-3).any()           # the tint is there
+
+
+def test_direct_integrator_hdri_background(pkg):
+    """environment_type 1 with integrator 0: lat-long look-up * sky_color * beta / 4 pi (:1843-1850)"""
+    sd = pkg.scene.dragon_scene(128, 72, "c2")
+    sd.kp.environment_type = 1
+    sd.kp.sky_color = pkg.abi.Float3(0.9, 1.0, 1.1)
+    sd.env_map = pkg.scene.hdri_map(256, 128)
+    hb, ob = _both(pkg, sd, 3)
+    got = hb.accum.cpu().numpy()
+    assert rel_l2(got, ob.accum) <= 1e-3                      # atan2/acos are value-only arithmetic
+    assert rel_l2(got, ob.accum) <= 2e-5
+    assert got.mean() > 1e-2
+
+
+def test_batches_spanning_record_chunks(pkg, monkeypatch):
+    """a 7-iteration batch rendered in chunks of 2 iterations == the same batch in one chunk, starting
+    at a non-zero iteration"""
+    sd = pkg.scene.dragon_scene(80, 50, "sun")
+    import oracle_binding
+    monkeypatch.setenv("VPT_BATCH_ITERS", "2")
+    hb = pkg.scene.HipBinding(sd, device=0)
+    hb.render(7, iteration=0)
+    hb.sync()
+    monkeypatch.delenv("VPT_BATCH_ITERS")
+    hb1 = pkg.scene.HipBinding(sd, device=0)
+    hb1.render(7, iteration=0)
+    hb1.sync()
+    np.testing.assert_array_equal(hb.accum.cpu().numpy(), hb1.accum.cpu().numpy())
+    np.testing.assert_array_equal(hb.display.cpu().numpy(), hb1.display.cpu().numpy())
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(7)
+    assert rel_l2(hb.accum.cpu().numpy(), ob.accum) <= 2e-6
+
+
+def test_nan_guard_substitutes_running_mean(pkg):
+    """a NaN sample (here: a NaN albedo poisons every interacting path) is replaced by the current
+    mean (:2263) -- pixels whose paths never interact are untouched"""
+    sd = pkg.scene.dragon_scene(64, 48, "sun")
+    hb0, _ = _both(pkg, sd, 1)
+    base = hb0.accum.cpu().numpy().copy()
+    import oracle_binding
+    sd.kp.albedo = pkg.abi.Float3(float("nan"), 1.0, 1.0)
+    hb = pkg.scene.HipBinding(sd, device=0)
+    ob = oracle_binding.OracleBinding(sd)
+    # iteration 0 clean (albedo patched after the first launch), iteration 1 poisoned
+    clean = pkg.abi.Float3(1.0, 1.0, 1.0)
+    hb.kp.albedo = clean; ob.kp.albedo = clean
+    hb.render(1); hb.sync(); ob.render(1)
+    hb.kp.albedo = sd.kp.albedo; ob.kp.albedo = sd.kp.albedo
+    hb.render(1); hb.sync(); ob.render(1)
+    got = hb.accum.cpu().numpy()
+    assert np.isfinite(got).all() and np.isfinite(ob.accum).all()
+    assert rel_l2(got, ob.accum) <= 2e-6
