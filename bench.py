@@ -166,8 +166,11 @@ def main():
                 tj = json.load(f).get(cfg)
             if tj and tj.get("width") == W and tj.get("height") == H:
                 per_sample = tj["bytes_per_launch"] / float(tj["samples_per_launch"])
-                launches = max(1, -(-spp // tj["iterations_per_launch"]))
+                # iterations per tracer launch: the chunk rule of vpt_render_batch (<= 64 iterations, <= 16 GiB of records)
+                ipl = max(1, min(64, spp, (16 << 30) // (W * H * 64)))
+                launches = -(-spp // ipl)
                 roofline["traffic"] = round(per_sample * samples_per_step_rank / launches / 1e9, 4)
+                roofline["launches_per_step"] = launches
                 roofline["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
         cpu = None
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)

@@ -724,9 +724,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         P.lights = ctx->d_lights;
     }
 
-    // ---- batch chunking: records for `chunk` iterations stay below ~2 GiB
+    // ---- batch chunking: records for `chunk` iterations stay below 16 GiB (sized for 288 GB of HBM: the
+    // persistent tracer drains one long queue per chunk, so fewer, larger chunks waste fewer wave-tails)
     const size_t per_iter = (size_t)n_pixels;
-    size_t chunk = ((size_t)2 << 30) / (per_iter * sizeof(Record));
+    size_t chunk = ((size_t)16 << 30) / (per_iter * sizeof(Record));
     if (chunk < 1) chunk = 1;
     if (chunk > 64) chunk = 64;
     if (chunk > iter_count) chunk = iter_count;

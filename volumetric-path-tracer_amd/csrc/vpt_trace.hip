@@ -127,21 +127,25 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             }
             // :1883-1888: sphere first -> depth is the distance to it
             const float depth = (obj == 2) ? length(org0 - (org0 + dir0 * t_hit)) : 0.0f;
+            // one 64-byte line per sample, written as four 16-byte stores whatever the branch (selecting the
+            // VALUES per branch keeps the stores vectorised; per-branch stores degrade to 16 dword stores)
+            const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
+            float4 r0, r1, r2, r3;
             if (!traced) {
                 // final: L = 0 (or WHITE when not rendering, :2248), beta = 1 (0), tr = 0
-                const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
-                dst[0] = make_float4(l, l, l, 0.0f);
-                dst[1] = make_float4(b, b, b, depth);
-                dst[2] = make_float4(org0.x, org0.y, org0.z, __uint_as_float(rendered ? 1u : 0u));
-                dst[3] = make_float4(dir0.x, dir0.y, dir0.z, 0.0f);
+                r0 = make_float4(l, l, l, 0.0f);
+                r1 = make_float4(b, b, b, depth);
+                r2 = make_float4(org0.x, org0.y, org0.z, __uint_as_float(rendered ? 1u : 0u));
+                r3 = make_float4(dir0.x, dir0.y, dir0.z, 0.0f);
                 n_final++;
             } else {
-                dst[0] = make_float4(org0.x, org0.y, org0.z, t_hit);
-                dst[1] = make_float4(dir0.x, dir0.y, dir0.z, __uint_as_float((uint32_t)obj));
-                dst[2] = make_float4(__uint_as_float(rng.o0), __uint_as_float(rng.o1), __uint_as_float(rng.o2), __uint_as_float(rng.o3));
-                dst[3] = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), depth, t_box);
+                r0 = make_float4(org0.x, org0.y, org0.z, t_hit);
+                r1 = make_float4(dir0.x, dir0.y, dir0.z, __uint_as_float((uint32_t)obj));
+                r2 = make_float4(__uint_as_float(rng.o0), __uint_as_float(rng.o1), __uint_as_float(rng.o2), __uint_as_float(rng.o3));
+                r3 = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), depth, t_box);
                 enqueue = true;
             }
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
         }
         const unsigned long long m = __ballot(enqueue);
         if (m != 0ull) {
