@@ -29,7 +29,10 @@ VPT_D f3 rtt_and_odt_fit(f3 v) {                                                
 // and, once per batch, ACES tonemap + gamma + 8-bit pack + raw buffer (:2292-2316).
 // Adjacent lanes read adjacent 64-byte records (4 KiB contiguous per wave and iteration); the sky
 // evaluation is the dominant cost and runs at full lane utilisation.
-__global__ __launch_bounds__(256) void tail_resolve_kernel(const ResolveParams R) {
+#ifndef VPT_TAIL_WAVES_PER_EU
+#define VPT_TAIL_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
     f3 acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
