@@ -485,7 +485,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         vd = 1;
                         w.mi = false;
                         w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
-                        phase = PH_W_TRACK;
+                        // A ray that sat INSIDE the box (a walk that stopped at t >= distance, or a
+                        // scattered ray) is moved to the box's far side here, so the walk it starts
+                        // usually finds itself outside the octree at once (get_quadrant(root) == -1,
+                        // :1606): no draw, no look-up, sample() returns WHITE.  That empty walk is
+                        // resolved right here instead of costing a pass of the walk loop.
+                        f3 nmin, nmax;
+                        int leaf;
+                        phase = locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE ? PH_T_TRACK_DONE : PH_W_TRACK;
                     } else if (gco_obj == 0) {
                         // nothing ahead: the second get_closest_object (:1806) sees the same ray, so
                         // this and every later iteration is a no-op -> finish (exact)

@@ -35,7 +35,9 @@ struct LdsF3 {
     VPT_D void operator*=(f3 v) const { p[0] *= v.x; p[256] *= v.y; p[512] *= v.z; }
 };
 
+#ifndef VPT_HIST_CAP
 #define VPT_HIST_CAP 12
+#endif
 #define VPT_CHUNK 256        // queue entries a wave claims per global atomic
 
 VPT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
