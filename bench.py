@@ -94,14 +94,18 @@ def main():
     first_it, stride, bn_pre = pkg.dist.stripe(rank, world)
     bn0 = hb.blue_noise.clone()
 
+    tstream = torch.cuda.current_stream(dev)
+
     def one_step():
         hb.blue_noise.copy_(bn0)
+        tstream.synchronize()                           # torch's stream -> visible to the ctx stream
         if bn_pre:
             hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre)
         hb.render(spp, iter_stride=stride, iteration=first_it)
         if world > 1:
             hb.sync()                                   # ctx stream -> visible to torch's stream
             pkg.dist.combine_means(hb.accum, spp)
+            tstream.synchronize()                       # the next step's kernels overwrite accum
 
     def fence():
         if world > 1:
