@@ -161,9 +161,15 @@ VPT_D bool to_unit(const DVolume& v, f3 p, f3& u) {
     q.x = q.x - v.bmin[0];
     q.y = q.y - v.bmin[1];
     q.z = q.z - v.bmin[2];
+#ifdef VPT_ABL_FASTDIV
+    u.x = q.x * __builtin_amdgcn_rcpf(v.fdim[0]);
+    u.y = q.y * __builtin_amdgcn_rcpf(v.fdim[1]);
+    u.z = q.z * __builtin_amdgcn_rcpf(v.fdim[2]);
+#else
     u.x = q.x / v.fdim[0];
     u.y = q.y / v.fdim[1];
     u.z = q.z / v.fdim[2];
+#endif
     return !(u.x < .0f || u.y < .0f || u.z < .0f || u.x > 1.0f || u.y > 1.0f || u.z > 1.0f);
 }
 

@@ -90,7 +90,11 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
             f3 nmin, nmax;
+#ifdef VPT_ABL_NOLOCATE
+            st = LOC_LEAF; nmin = nmax = mk3(0.0f);
+#else
             st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
+#endif
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
                 float t_min, t_max;
@@ -112,12 +116,18 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         // :1647-1651
         float t_min, t_max, geo_dist;
         box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, w.distance);
+#ifndef VPT_ABL_NOSPHERE
         if (sphere_intersect(P, w.pos, w.dir, geo_dist, t_max)) {
             w.distance = geo_dist;
             w.geo = true;
         }
+#endif
     }
+#ifdef VPT_ABL_FASTLOG
+    const float lg = __logf(1 - rnd(rng, draws));
+#else
     const float lg = det_logf(1 - rnd(rng, draws));
+#endif
     if (COUNT) c.n_steps++;
     if (is_sample) w.t -= lg * K.inv_max * K.inv_dm;                          // :1652
     else if (is_emit) w.t -= lg * K.inv_max * P.tr_depth / P.extinction[0];   // :1331
@@ -141,15 +151,16 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         }
     }
     if (is_sample) {
-        // :1667-1675
-        int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
-        const float* dc = P.density_color_lut + 3 * index;
+        // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
+        // (one correctly rounded divide by emission_pivot) and fetch are evaluated there.
         if (w.alpha < 1.0f) w.alpha += density;
         if (record_hist) {
             if (n_hist < VPT_HIST_CAP) hist[n_hist * 256] = density;
             n_hist++;
         }
         if (density * K.inv_max > rnd(rng, draws)) {
+            const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
+            const float* dc = P.density_color_lut + 3 * index;
             w.mi = true;
             w.wgt = (ld3(P.albedo) * Cd * mk3(dc[0], dc[1], dc[2]) / ld3(P.extinction)) * P.energy_inject;
             return true;
