@@ -7,9 +7,12 @@
  *
  * PARITY UNPINNED: the reference ships no tests, golden images or known answers for
  * this path and cannot be built here (CUDA/OpenVDB/Windows deps).
- * What is pinned: Philox4x32-10 against the Random123 known-answer vector, the
- * dragon.vdb asset facts (voxel count, bbox, value range), and closed-form
- * properties (homogeneous-slab transmittance, trilinear exactness on linear fields).
+ * What is pinned (tests/test_oracle_pins.py): Philox4x32-10 against the Random123
+ * known-answer vectors and cuRAND's stream semantics, the dragon.vdb asset facts (voxel
+ * count, bbox, value range, fixture regenerated from the asset), the sampler states
+ * (exactness on linear fields, point / wrap / unnormalised addressing), the octree against
+ * brute-force point location, the density look-up against a numpy trilinear reference,
+ * and the fixed-sequence log/sin/cos against libm.
  *
  * It re-uses the POD structs of include/vpt_abi.h (they restate the reference's PODs).
  * Texture handles inside those PODs are oracle handles made by orc_texture_create;
