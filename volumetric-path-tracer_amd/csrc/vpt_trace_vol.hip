@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
     const LdsF3 Li = {park + 24 * 256}, wi = {park + 27 * 256};        // estimate_sky scratch
     const LdsF light_pdf = {park + 30 * 256}, phase_pdf = {park + 31 * 256}, mis_w = {park + 32 * 256};
     const LdsF depth = {park + 33 * 256}, t_box = {park + 34 * 256};
-    const LdsI vdepth = {parki + 35 * 256}, budget = {parki + 36 * 256}, light_index = {parki + 37 * 256}, cam_draws_p = {parki + 38 * 256};
+    const LdsI budget = {parki + 36 * 256}, light_index = {parki + 37 * 256}, cam_draws_p = {parki + 38 * 256};
     uint32_t n_hist = 0;
+    int retry = 0;                 // vol_integrator's depth loop (:1737): iterations left after the sample() call being
+                                   // walked, i.e. current depth = ray_depth - retry (retries run inline, vpt_walk.h)
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
     bool more = true;
@@ -242,13 +244,13 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                         w.pos = o0 + w.dir * (q3.w + VPT_EPS);
                         L = mk3(0.0f);
                         beta = mk3(1.0f);
-                        vdepth = 1;
                         w.mi = false;
                         w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
                         n_hist = 0;
                         cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
                         // depth_calculator (:1875-1881) walks the very same segment with the same
                         // rng copy iff the box is the closest object (then t_min == t_box)
+                        retry = P.ray_depth - 1;
                         phase = obj == 1 ? VH_W_FIRST : VH_W_TRACK;
                     }
                 }
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
         rng_top_up(rng, pixel);
         if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
             const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt);
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
+                                                                   phase == VH_W_TRACK ? &retry : nullptr, pixel);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
                 else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                 w.pos = f3(org0) + w.dir * ((float)t_box + VPT_EPS);
                 w.mi = false;
                 w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                retry = P.ray_depth - 1;
                 phase = VH_W_TRACK;
             }
             if (phase == VH_T_VTRACK_DONE) {
@@ -318,14 +322,15 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                 } else if (!w.mi) {
                     // no interaction: either the walk left the root box (every later sample() is a
                     // no-op) or it stopped at the sphere / exit distance inside the box (:1654) and
-                    // the next loop iteration walks again from here
-                    vdepth++;
+                    // the next loop iteration walks again from here -- inline in walk_step for
+                    // W_TRACK walks (retry), as a new walk after the fused first one
                     f3 nmin, nmax;
                     int leaf;
-                    if ((int)vdepth > P.ray_depth || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
+                    if (retry == 0 || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
                         phase = VH_T_FINISH;
                     } else {
                         w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
+                        retry--;
                         phase = VH_W_TRACK;
                     }
                 } else {
@@ -467,9 +472,9 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                 sample_hg(w.dir, rng, draws, P.phase_g1);                           // :1746 (2 draws)
                 drew = true;
                 w.inv = rcp3(w.dir);
-                vdepth++;
-                if ((int)vdepth > P.ray_depth) phase = VH_T_FINISH;
+                if (retry == 0) phase = VH_T_FINISH;                                // depth loop exhausted
                 else {
+                    retry--;
                     w.mi = false;
                     w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
                     phase = VH_W_TRACK;

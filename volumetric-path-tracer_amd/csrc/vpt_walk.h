@@ -58,6 +58,9 @@ enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
 #ifndef VPT_SKIP_LOOP
 #define VPT_SKIP_LOOP 8
 #endif
+#ifndef VPT_RETRY_SPINS
+#define VPT_RETRY_SPINS 3
+#endif
 struct Walk {
     f3 pos, dir, inv;     // walk ray (inv = 1 / dir)
     float t;              // cumulative step (Q-list 1: never reset inside a walk)
@@ -74,9 +77,15 @@ struct WalkCounts {
 
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
 // the fused first walk (record_hist), stride 256 floats.
+// retries (vol_integrator only, else NULL): how many further `sample()` calls the integrator's depth
+// loop would make from this very position if the current one ends without an interaction at
+// t >= distance (:1654 -> :1740 next iteration).  Such a call repeats the same point location, the
+// same exit distance and sphere test and differs only in its exponential draw, so it is replayed
+// right here (one draw + one log per retry) instead of costing a pass of the walk loop each.
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
 VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
-                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c) {
+                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
+                     int* retries = nullptr, uint32_t rng_key = 0) {
     const bool is_sample = kind == WALK_SAMPLE;
     const bool is_emit = EMIT && kind == WALK_EMIT;
     // Empty-node pushes are cheap and the tracking step below is expensive, so the wave first loops
@@ -123,18 +132,29 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         }
 #endif
     }
+    int spins = 0;
+    for (;;) {
 #ifdef VPT_ABL_FASTLOG
-    const float lg = __logf(1 - rnd(rng, draws));
+        const float lg = __logf(1 - rnd(rng, draws));
 #else
-    const float lg = det_logf(1 - rnd(rng, draws));
+        const float lg = det_logf(1 - rnd(rng, draws));
 #endif
-    if (COUNT) c.n_steps++;
-    if (is_sample) w.t -= lg * K.inv_max * K.inv_dm;                          // :1652
-    else if (is_emit) w.t -= lg * K.inv_max * P.tr_depth / P.extinction[0];   // :1331
-    else w.t -= lg * K.sigma_r_inv * P.tr_depth;                              // :1231
-    if (!is_emit && w.t >= w.distance) {
-        if (is_sample && w.geo) w.obj2 = true;                                // :1654-1657
-        return true;
+        if (COUNT) c.n_steps++;
+        if (is_sample) w.t -= lg * K.inv_max * K.inv_dm;                          // :1652
+        else if (is_emit) w.t -= lg * K.inv_max * P.tr_depth / P.extinction[0];   // :1331
+        else w.t -= lg * K.sigma_r_inv * P.tr_depth;                              // :1231
+        if (!is_emit && w.t >= w.distance) {
+            if (is_sample && w.geo) w.obj2 = true;                                // :1654-1657
+            if (retries && is_sample && *retries > 0) {
+                *retries -= 1;                   // the next sample() call, same position: t = 0 again
+                w.t = 0.0f;
+                if (++spins >= VPT_RETRY_SPINS) return false;     // the rest of the wave is waiting: next pass
+                rng_top_up(rng, rng_key);
+                continue;
+            }
+            return true;
+        }
+        break;
     }
     w.pos += w.dir * w.t;                                                     // cumulative t (Q-list 1)
     if (!contains(K.root_lo, K.root_hi, w.pos)) return true;
