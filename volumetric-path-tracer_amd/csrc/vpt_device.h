@@ -7,6 +7,9 @@
 //     bits) plus a CSR list of instance indices per leaf -- child boxes are re-derived
 //     arithmetically by halving the parent box (bvh_kernels.cu:150-202 divide_bbox), which
 //     reproduces the reference's node boxes bit-for-bit without the 2.5 KB OCTNode;
+//   * density grids too large for the Infinity Cache (>= VPT_BRICK_MIN_BYTES, default 192 MiB) are
+//     re-tiled once into 4x4x4 bricks of 256 B: a trilinear footprint then touches ~2.5 cache lines
+//     instead of 4 scattered ones;
 //   * path records: one 64-byte line per pixel-sample, written once by the trace
 //     kernel, read once by the resolve kernel.
 #pragma once
@@ -27,6 +30,8 @@ struct DVolume {
     int has_emission;
     int edim[3];           // emission texture extent
     int cdim[3];           // colour texture extent
+    int bricked;           // density is stored as 4x4x4 bricks (256 B, x fastest inside a brick), bricks x fastest
+    int bdim[2];           // bricks along x and y
     int pad_;
 };
 

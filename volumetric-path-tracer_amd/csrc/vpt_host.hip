@@ -59,6 +59,7 @@ struct vpt_ctx {
     std::vector<vpt_gpu_vdb> host_volumes;
     std::vector<DVolume> host_dvolumes;
     DVolume* d_volumes = nullptr;
+    std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
     uint32_t* d_leaf_offsets = nullptr;
     uint32_t* d_leaf_indices = nullptr;
     uint32_t occ[19] = {0};
@@ -260,6 +261,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
+    for (void* b : ctx->bricked) (void)hipFree(b);
     (void)hipFree(ctx->d_volumes);
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
@@ -343,6 +345,18 @@ int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
     return VPT_OK;
 }
 
+// dense x-fastest grid -> 4x4x4 bricks (vpt_device.h); one thread per destination texel, so the 256-byte
+// brick writes are contiguous; edge bricks are padded with the clamped edge texel (never addressed)
+__global__ void brick_kernel(const float* __restrict__ src, float* __restrict__ dst, int dx, int dy, int dz, int bx, int by, size_t total) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const size_t brick = o >> 6;
+    const int in = (int)(o & 63);
+    const int b_x = (int)(brick % (size_t)bx), b_y = (int)((brick / (size_t)bx) % (size_t)by), b_z = (int)(brick / ((size_t)bx * by));
+    const int x = min(b_x * 4 + (in & 3), dx - 1), y = min(b_y * 4 + ((in >> 2) & 3), dy - 1), z = min(b_z * 4 + (in >> 4), dz - 1);
+    dst[o] = src[((size_t)z * dy + y) * dx + x];
+}
+
 // ---- scene ------------------------------------------------------------------------------------
 int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volumes) {
     if (!ctx || !volumes || num_volumes <= 0) return VPT_E_INVALID;
@@ -350,6 +364,12 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     std::vector<DVolume> dv(num_volumes);
     std::vector<Box> bounds(num_volumes);
     ctx->any_color = ctx->any_emission = false;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (void* b : ctx->bricked) (void)hipFree(b);
+    ctx->bricked.clear();
+    size_t brick_min = (size_t)192 << 20;                 // grids below this stay L2 / Infinity-Cache resident anyway
+    if (const char* e = std::getenv("VPT_BRICK_MIN_BYTES")) brick_min = (size_t)std::strtoull(e, nullptr, 10);
+    std::vector<std::pair<const float*, const float*>> brick_cache;     // instances share their file's grid
     for (int i = 0; i < num_volumes; ++i) {
         const vpt_vdb_info& vi = volumes[i].vdb_info;
         DVolume& d = dv[i];
@@ -365,6 +385,27 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             return VPT_E_INVALID;
         }
         d.density = t.data;
+        if ((size_t)t.width * t.height * t.depth * sizeof(float) >= brick_min && (size_t)t.width * t.height * t.depth < ((size_t)1 << 31)) {
+            const int bx = (t.width + 3) / 4, by = (t.height + 3) / 4, bz = (t.depth + 3) / 4;
+            const size_t total = (size_t)bx * by * bz * 64;
+            const float* tiled = nullptr;
+            for (auto& c : brick_cache)
+                if (c.first == t.data) tiled = c.second;
+            if (!tiled && total < ((size_t)1 << 32)) {
+                float* dst = nullptr;
+                HIPCHK(ctx, hipMalloc(&dst, total * sizeof(float)));
+                ctx->bricked.push_back(dst);
+                hipLaunchKernelGGL(brick_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, t.data, dst, t.width, t.height, t.depth, bx, by, total);
+                HIPCHK(ctx, hipGetLastError());
+                brick_cache.push_back({t.data, dst});
+                tiled = dst;
+            }
+            if (tiled) {
+                d.density = tiled;
+                d.bricked = 1;
+                d.bdim[0] = bx; d.bdim[1] = by;
+            }
+        }
         if (vi.has_emission) {
             if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1) {
                 set_error(ctx, "vpt_scene_set_volumes: volume %d has_emission but no f32 emission texture", i);
@@ -395,6 +436,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         d.dim[0] = vi.dim.x; d.dim[1] = vi.dim.y; d.dim[2] = vi.dim.z;
         bounds[i] = vdb_bounds(volumes[i]);
     }
+    if (!ctx->bricked.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // re-tiled grids ready for any stream
     // root node, bvh_builder.cpp:61-78
     Box root = {mk3(VPT_M_INF), mk3(-VPT_M_INF)};
     float max_ext = .0f, min_ext = VPT_M_INF;

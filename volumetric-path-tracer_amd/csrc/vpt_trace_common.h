@@ -215,6 +215,25 @@ VPT_D float fetch_f32(const float* __restrict__ g, const int* dim, const Taps& t
     const float c1 = c01 + (c11 - c01) * t.ay;
     return c0 + (c1 - c0) * t.az;
 }
+// same trilinear fetch from the bricked layout (vpt_device.h): texel (i, j, k) lives at
+//   (((k>>2) * by + (j>>2)) * bx + (i>>2)) * 64 + (k&3) * 16 + (j&3) * 4 + (i&3)
+VPT_D float fetch_f32_bricked(const float* __restrict__ g, const DVolume& v, const Taps& t) {
+    const uint32_t bx = (uint32_t)v.bdim[0], by = (uint32_t)v.bdim[1];
+    const uint32_t x0 = ((uint32_t)t.i0 >> 2) * 64u + ((uint32_t)t.i0 & 3u), x1 = ((uint32_t)t.i1 >> 2) * 64u + ((uint32_t)t.i1 & 3u);
+    const uint32_t y0 = ((uint32_t)t.j0 >> 2) * bx * 64u + (((uint32_t)t.j0 & 3u) << 2), y1 = ((uint32_t)t.j1 >> 2) * bx * 64u + (((uint32_t)t.j1 & 3u) << 2);
+    const uint32_t z0 = ((uint32_t)t.k0 >> 2) * by * bx * 64u + (((uint32_t)t.k0 & 3u) << 4), z1 = ((uint32_t)t.k1 >> 2) * by * bx * 64u + (((uint32_t)t.k1 & 3u) << 4);
+    const float c000 = g[z0 + y0 + x0], c100 = g[z0 + y0 + x1];
+    const float c010 = g[z0 + y1 + x0], c110 = g[z0 + y1 + x1];
+    const float c001 = g[z1 + y0 + x0], c101 = g[z1 + y0 + x1];
+    const float c011 = g[z1 + y1 + x0], c111 = g[z1 + y1 + x1];
+    const float c00 = c000 + (c100 - c000) * t.ax;
+    const float c10 = c010 + (c110 - c010) * t.ax;
+    const float c01 = c001 + (c101 - c001) * t.ax;
+    const float c11 = c011 + (c111 - c011) * t.ax;
+    const float c0 = c00 + (c10 - c00) * t.ay;
+    const float c1 = c01 + (c11 - c01) * t.ay;
+    return c0 + (c1 - c0) * t.az;
+}
 VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
 VPT_D f3 fetch_f4(const f4* __restrict__ g, const int* dim, const Taps& t) {
     const uint32_t dx = (uint32_t)dim[0];
@@ -240,7 +259,10 @@ VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want
     // coordinates
     if (want_density) {
         if (COUNT) n_d++;
-        if (inside) density += fetch_f32(v.density, v.dim, make_taps(v.dim, u));
+        if (inside) {
+            const Taps t = make_taps(v.dim, u);
+            density += v.bricked ? fetch_f32_bricked(v.density, v, t) : fetch_f32(v.density, v.dim, t);
+        }
     }
     if (COLOR && want_color) {
         if (!v.has_color) {
