@@ -91,3 +91,35 @@ def test_config2_sun_and_sky_parity(pkg, sky):
     # exp/log (csrc/vpt_tail.hip); its ill-conditioned geometry terms amplify those ulps to ~1e-4
     assert e <= 4e-4, e
     np.testing.assert_allclose(hb.raw.cpu().numpy()[:, :3], ob.raw[:, :3], rtol=2e-3, atol=2e-4)
+
+
+def test_camera_point_table_fast_path_matches_general_path(pkg, sky, monkeypatch):
+    """tail_resolve's camera-point scattering table (csrc/vpt_sky.h: the 4-D tables pre-interpolated at
+    the view point's r and mu_s) against the general 16-texel look-up, and the fall-back when the view
+    point varies per sample (aperture > 0)."""
+    sd = pkg.scene.dragon_scene(128, 72, "c2")
+    sd.kp.sun_mult = 0.0                                  # sky only: the table's contribution is all there is
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    fast = pkg.scene.HipBinding(sd, device=0)
+    fast.render(2); fast.sync()
+    monkeypatch.setenv("VPT_NO_CAM_TABLE", "1")
+    slow = pkg.scene.HipBinding(sd, device=0)
+    slow.render(2); slow.sync()
+    monkeypatch.delenv("VPT_NO_CAM_TABLE")
+    a, b = fast.accum.cpu().numpy(), slow.accum.cpu().numpy()
+    assert b.mean() > 1e-2 and not np.array_equal(a, b)   # a different evaluation order ...
+    assert rel_l2(a, b) <= 2e-6                           # ... of the same multilinear interpolant
+    # aperture > 0: every sample has its own origin -> general path for all, identical with or without the table
+    import ctypes as C
+    cam, _, _ = pkg.scene.frame_camera(pkg.load_library(), [sd.volumes[0][0]], 128, 72, aperture=0.6)
+    sd.camera = cam
+    x = pkg.scene.HipBinding(sd, device=0)
+    x.render(2); x.sync()
+    monkeypatch.setenv("VPT_NO_CAM_TABLE", "1")
+    y = pkg.scene.HipBinding(sd, device=0)
+    y.render(2); y.sync()
+    np.testing.assert_array_equal(x.accum.cpu().numpy(), y.accum.cpu().numpy())
+    import oracle_binding
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(2)
+    assert rel_l2(x.accum.cpu().numpy(), ob.accum) <= 1e-3

@@ -145,6 +145,9 @@ struct TraceParams {
     DTexture env_func_tex, env_cdf_tex;                    // 2-D f32, unnormalised, point
     DTexture env_marginal_func_tex, env_marginal_cdf_tex;  // 1-D f32, unnormalised, point
     int has_atmosphere;
+    int cam_tab_valid;                                     // always 0 in the tracer (estimate_sky looks from the interaction point)
+    const float4* cam_tab;
+    float cam_tab_pos[3];
     float atm_f[40];                                       // packed vpt_atmosphere_parameters scalars
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
@@ -172,7 +175,12 @@ struct ResolveParams {
     DTexture env_tex;
     // atmosphere
     int has_atmosphere;
-    float atm_f[40];       // packed vpt_atmosphere_parameters scalars (see vpt_resolve.hip)
+    // camera-point scattering table (vpt_sky.h, CamTable): the two 4-D scattering tables pre-interpolated at
+    // the r and mu_s of ONE view point -> [nu slice 8][mu row 128] x {scattering.xyz, single_mie.xyz}
+    int cam_tab_valid;
+    const float4* cam_tab;            // [8][128][2] float4
+    float cam_tab_pos[3];             // the view point (relative to the scene, as env_pos) it was built for
+    float atm_f[40];       // packed vpt_atmosphere_parameters scalars (see vpt_sky.h)
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
 

@@ -26,6 +26,7 @@ hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit,
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
+hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream);
 }  // namespace vpt
 
@@ -60,6 +61,7 @@ struct vpt_ctx {
     std::vector<DVolume> host_dvolumes;
     DVolume* d_volumes = nullptr;
     std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
+    float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
     uint32_t* d_leaf_offsets = nullptr;
     uint32_t* d_leaf_indices = nullptr;
     uint32_t occ[19] = {0};
@@ -262,6 +264,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
+    (void)hipFree(ctx->d_cam_tab);
     (void)hipFree(ctx->d_volumes);
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
@@ -800,6 +803,14 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.blue_noise = ctx->d_bn_table;
     R.records = ctx->d_records;
 
+    // camera-point scattering table (vpt_sky.h): valid for samples whose env_pos is the camera origin
+    if (R.has_atmosphere && !std::getenv("VPT_NO_CAM_TABLE")) {
+        if (!ctx->d_cam_tab) HIPCHK(ctx, hipMalloc(&ctx->d_cam_tab, sizeof(float4) * 8 * 128 * 2));
+        R.cam_tab = ctx->d_cam_tab;
+        R.cam_tab_pos[0] = cam->origin.x; R.cam_tab_pos[1] = cam->origin.y; R.cam_tab_pos[2] = cam->origin.z;
+        HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_cam_tab, stream));
+        R.cam_tab_valid = 1;
+    }
     ctx->spans.clear();
     ctx->ev_used = 0;
     ctx->last_samples = 0;

@@ -177,8 +177,12 @@ struct Sky {
             const float d_max = rho + H;
             u_mu = 0.5f + 0.5f * UnitToTex<64>(fdiv(d - d_min, d_max - d_min));
         }
+#ifdef VPT_ABL_SKYCAM
+        const float a = mu_s * 0.3f;
+#else
         const float d = DistanceToTop(bottom(), mu_s);
         const float a = (d - (top() - bottom())) * f(AF_INV_DMUS);
+#endif
         const float u_mu_s = UnitToTex<32>(fdiv(fmax_(1.0f - a * f(AF_INV_A), 0.0f), 1.0f + a));
         const float u_nu = (nu + 1.0f) * 0.5f;
         return mk4(u_nu, u_mu_s, u_mu, u_r);
@@ -224,12 +228,67 @@ struct Sky {
         single_mie = flerp3(m0, m1, lerp);            // m0 (1 - lerp) + m1 lerp
         return flerp3(s0, s1, lerp);
     }
+    // ---- camera-point fast path -------------------------------------------------------------------
+    // All but a few samples of a frame look from ONE point (env_pos is the primary-ray origin: the
+    // camera position when the aperture is 0, sphere bounces aside), so r and mu_s -- two of the four
+    // table coordinates -- are launch constants.  sky_cam_table_kernel pre-interpolates both tables
+    // along those two axes; a look-up from the view point then needs 4 table entries (2 mu rows x 2 nu
+    // slices) instead of 16 texels per table.  Multilinear interpolation commutes, so this is the same
+    // value up to rounding (value-only arithmetic).  Any other view point takes the general path.
+    VPT_D bool CamFast(f3 camera_rel_scene) const {
+        return R.cam_tab_valid && camera_rel_scene.x == R.cam_tab_pos[0] && camera_rel_scene.y == R.cam_tab_pos[1] &&
+               camera_rel_scene.z == R.cam_tab_pos[2];
+    }
+    VPT_D f3 CombinedScatteringCam(float r, float mu, float nu, bool ground, f3& single_mie) const {
+        // u_mu of ScatteringUvwz (:520-546); u_r and u_mu_s are baked into the table
+        const float H = f(AF_H);
+        const float rho = SafeSqrt(r * r - bottom() * bottom());
+        const float r_mu = r * mu;
+        const float disc = r_mu * r_mu - r * r + bottom() * bottom();
+        float u_mu;
+        if (ground) {
+            const float d = -r_mu - SafeSqrt(disc);
+            const float d_min = r - bottom();
+            const float d_max = rho;
+            u_mu = 0.5f - 0.5f * UnitToTex<64>(d_max == d_min ? 0.0f : fdiv(d - d_min, d_max - d_min));
+        } else {
+            const float d = -r_mu + SafeSqrt(disc + H * H);
+            const float d_min = top() - r;
+            const float d_max = rho + H;
+            u_mu = 0.5f + 0.5f * UnitToTex<64>(fdiv(d - d_min, d_max - d_min));
+        }
+        const float tex_coord_x = (nu + 1.0f) * 0.5f * 7.0f;
+        const float tex_x = floorf(tex_coord_x);
+        const float lerp = tex_coord_x - tex_x;
+        const uint32_t n0 = (uint32_t)tex_x, n1 = min(n0 + 1u, 7u);
+        const Tap ty = lut_tap<128, false>(u_mu);
+        const float4* __restrict__ T = R.cam_tab;
+        auto row = [&](uint32_t n, f3& sc, f3& mie) {
+            const uint32_t e0 = (n * 128u + ty.i0) * 2u, e1 = (n * 128u + ty.i1) * 2u;
+            sc = ld_f3(T, e0);
+            mie = ld_f3(T, e0 + 1u);
+            if (ty.a != 0.0f) {
+                sc = flerp3(sc, ld_f3(T, e1), ty.a);
+                mie = flerp3(mie, ld_f3(T, e1 + 1u), ty.a);
+            }
+        };
+        f3 s0, m0;
+        row(n0, s0, m0);
+        if (lerp != 0.0f) {
+            f3 s1, m1;
+            row(n1, s1, m1);
+            s0 = flerp3(s0, s1, lerp);
+            m0 = flerp3(m0, m1, lerp);
+        }
+        single_mie = m0;
+        return s0;
+    }
     VPT_D f3 Irradiance(float r, float mu_s) const {                                  // :633-654
         const float x_r = (r - bottom()) * f(AF_INV_TB);
         const float x_mu_s = ffma(mu_s, 0.5f, 0.5f);
         return lut2d(R.irradiance_tex.data, UnitToTex<256>(x_mu_s), UnitToTex<64>(x_r));
     }
-    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance) const {   // :694 (shadow_length = 0)
+    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, bool cam_fast) const {   // :694 (shadow_length = 0)
         float r = length(camera);
         float rmu = dot(camera, view_ray);
         const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
@@ -237,6 +296,7 @@ struct Sky {
             camera = camera + view_ray * dtop;
             r = top();
             rmu += dtop;
+            cam_fast = false;
         } else if (r > top()) {
             transmittance = mk3(1.0f);
             return mk3(0.0f);
@@ -248,12 +308,12 @@ struct Sky {
         const bool ground = HitsGround(r, mu);
         transmittance = ground ? mk3(0.0f) : TransmittanceToTop(r, mu);
         f3 single_mie;
-        const f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        const f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
         f3 sky = fscale_add3(single_mie, MiePhase(f(AF_MIE_G), nu), scattering * RayleighPhase(nu));
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
-    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance) const {   // :749 (shadow_length = 0)
+    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, bool cam_fast) const {   // :749 (shadow_length = 0)
         const f3 delta = point - camera;
         float d = length(delta);
         const f3 view_ray = delta * frcp(d);
@@ -265,22 +325,35 @@ struct Sky {
             r = top();
             rmu += dtop;
             d = length(point - camera);
+            cam_fast = false;
         }
         const float inv_r = frcp(r);
         const float mu = rmu * inv_r;
         const float mu_s = dot(camera, sun_direction) * inv_r;
         const float nu = dot(view_ray, sun_direction);
         const bool ground = HitsGround(r, mu);
+#ifdef VPT_ABL_T1
+        transmittance = mk3(0.99f);
+#else
         transmittance = Transmittance(r, mu, d, ground);
+#endif
         f3 single_mie;
-        f3 scattering = CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+#ifdef VPT_ABL_S1
+        f3 scattering = mk3(mu * 1e-9f); single_mie = mk3(mu_s * 1e-9f);
+#else
+        f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+#endif
         d = fmax_(d, 0.0f);
         const float r_p = ClampRadius(RadiusAt(r, mu, d));
         const float inv_rp = frcp(r_p);
         const float mu_p = (r * mu + d) * inv_rp;
         const float mu_s_p = (r * mu_s + d * nu) * inv_rp;
         f3 single_mie_p;
+#ifdef VPT_ABL_S2
+        const f3 scattering_p = mk3(mu_p * 1e-9f); single_mie_p = mk3(mu_s_p * 1e-9f);
+#else
         const f3 scattering_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, ground, single_mie_p);
+#endif
         scattering = scattering - transmittance * scattering_p;
         single_mie = single_mie - transmittance * single_mie_p;
         const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);                           // smoothstep(0, 0.01, mu_s)
@@ -298,24 +371,29 @@ struct Sky {
         const float d2 = p_dot_p - p_dot_v * p_dot_v;
         const float dist = -p_dot_v - fsqrt(earth_center.y * earth_center.y - d2);
         f3 radiance;
+        const bool cam_fast = CamFast(ray_pos);
         if (dist > 0.0f) {
             const f3 pt = ray_pos + ray_dir * dist - earth_center;
             const float r = length(pt);
             const float inv_r = frcp(r);
             const f3 normal = pt * inv_r;
             const float mu_s = dot(pt, sun_direction) * inv_r;
+#ifdef VPT_ABL_IRR
+            f3 sky_irr = mk3(mu_s), sun_irr = mk3(inv_r);
+#else
             f3 sky_irr = Irradiance(r, mu_s) * ((1.0f + dot(normal, pt) * inv_r) * 0.5f);     // :818
             f3 sun_irr = v(AF_SOLAR) * TransmittanceToSun(r, mu_s) * fmax_(dot(normal, sun_direction), 0.0f);
+#endif
             if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
             radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
             f3 tr;
-            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr);
+            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr, cam_fast);
             radiance = radiance * tr + in_scatter;
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits
         } else {
             f3 tr_sky;
-            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky);
+            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cam_fast);
             if (dot(ray_dir, sun_direction) > f(AF_COS_SUN)) radiance = radiance + tr_sky * v(AF_SOLAR_RAD);
         }
         // pow(1 - exp(-radiance / white_point * exposure), 1 / 2.2)   (:883-885)
@@ -326,5 +404,24 @@ struct Sky {
                    __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(om.z)));
     }
 };
+
+// One entry of the camera-point table: both 4-D tables interpolated along r (z) and mu_s (x within a nu
+// slice) at the view point `cam` (scene coordinates), for mu row j and nu slice n.
+template <class RP>
+VPT_D void sky_cam_table_entry(const RP& R, f3 cam, f3 sun_direction, uint32_t n, uint32_t j, f3& sc, f3& mie) {
+    const Sky<RP> sky = {R};
+    const f3 p = cam - mk3(.0f, -sky.bottom(), .0f);
+    const float r = length(p);
+    const float mu_s = dot(p, sun_direction) * frcp(r);
+    const f4 uvwz = sky.ScatteringUvwz(r, 0.0f, mu_s, 0.0f, false);          // only u_mu_s (y) and u_r (w) are used
+    const Tap tz = lut_tap<32, false>(uvwz.w);
+    const Tap tm = lut_tap<256, false>(uvwz.y * 0.125f);                       // the tap inside nu slice 0: index < 32
+    const float4* __restrict__ ps = reinterpret_cast<const float4*>(R.scattering_tex.data);
+    const float4* __restrict__ pm = reinterpret_cast<const float4*>(R.single_mie_tex.data);
+    const uint32_t x0 = n * 32u + tm.i0, x1 = n * 32u + min(tm.i1, 31u);
+    const uint32_t r0 = (tz.i0 * 128u + j) * 256u, r1 = (tz.i1 * 128u + j) * 256u;
+    sc = flerp3(flerp3(ld_f3(ps, r0 + x0), ld_f3(ps, r0 + x1), tm.a), flerp3(ld_f3(ps, r1 + x0), ld_f3(ps, r1 + x1), tm.a), tz.a);
+    mie = flerp3(flerp3(ld_f3(pm, r0 + x0), ld_f3(pm, r0 + x1), tm.a), flerp3(ld_f3(pm, r1 + x0), ld_f3(pm, r1 + x1), tm.a), tz.a);
+}
 
 }  // namespace vpt

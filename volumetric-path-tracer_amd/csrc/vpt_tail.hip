@@ -111,6 +111,20 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     }
 }
 
+// camera-point scattering table (vpt_sky.h): 8 nu slices x 128 mu rows, one thread per entry
+__global__ void sky_cam_table_kernel(const ResolveParams R, float4* out) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 8u * 128u) return;
+    f3 sc, mie;
+    sky_cam_table_entry(R, mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]), mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]), e >> 7, e & 127u, sc, mie);
+    out[2u * e] = make_float4(sc.x, sc.y, sc.z, 0.0f);
+    out[2u * e + 1u] = make_float4(mie.x, mie.y, mie.z, 0.0f);
+}
+hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_cam_table_kernel, dim3(4), dim3(256), 0, stream, R, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream) {
     hipLaunchKernelGGL(tail_resolve_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
     return hipGetLastError();
