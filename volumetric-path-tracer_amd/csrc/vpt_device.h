@@ -101,6 +101,7 @@ struct TraceParams {
     uint32_t* queue_tail;            // raygen's append cursor
     const uint32_t* queue_count;     // == queue_tail, read by the tracer
     Record* records;                 // [iter_count][n_pixels]
+    float4* heads;                   // [iter_count][n_pixels] 16-byte sample heads, or NULL (see ResolveParams)
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
@@ -157,6 +158,13 @@ struct ResolveParams {
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;
     const Record* records;
+    // 16-byte sample heads (only when every primary ray starts at the camera origin, i.e. lens_radius
+    // == 0): {dir0.xyz, w}.  w >= 0: the primary ray started no walk ("miss", 59 % of config 2) -- it
+    // is final with L = 0, beta = 1, depth = w, env_pos = cam_origin and has NO 64-byte record;
+    // w == -1: see records[]; w == -2: not rendered (value WHITE).  Cuts the record stream from 64 to
+    // ~42 B per sample.
+    const float4* heads;
+    float cam_origin[3];
     float* accum;          // float3[n_pixels]
     float* cost;           // float3[n_pixels] or NULL
     float* depth;          // float[n_pixels] or NULL

@@ -72,6 +72,7 @@ struct vpt_ctx {
     bool any_color = false, any_emission = false;
     // scratch
     Record* d_records = nullptr;
+    float4* d_heads = nullptr;             // 16-byte sample heads, same capacity as d_records
     size_t records_capacity = 0;           // in records
     float2* d_bn_table = nullptr;
     size_t bn_capacity = 0;                // in iterations
@@ -269,6 +270,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
     (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_heads);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
@@ -782,8 +784,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipStreamSynchronize(stream));
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
+        (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
         hipError_t e = hipMalloc(&ctx->d_records, chunk * per_iter * sizeof(Record));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, chunk * per_iter * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_heads, chunk * per_iter * sizeof(float4));
         if (e != hipSuccess) {
             set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", chunk * per_iter * sizeof(Record), hipGetErrorString(e));
             return VPT_E_NOMEM;
@@ -797,6 +801,12 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         ctx->bn_capacity = chunk;
     }
     P.records = ctx->d_records;
+    // compact sample heads: valid when every primary ray starts exactly at the camera origin
+    // (camera.h:131-136 with lens_radius == 0: offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0)
+    const bool compact = cam->lens_radius == 0.0f && !std::getenv("VPT_NO_HEADS");
+    P.heads = compact ? ctx->d_heads : nullptr;
+    R.heads = P.heads;
+    R.cam_origin[0] = cam->origin.x; R.cam_origin[1] = cam->origin.y; R.cam_origin[2] = cam->origin.z;
     P.queue = ctx->d_queue;
     P.queue_tail = ctx->d_work_counter + 1;
     P.queue_count = ctx->d_work_counter + 1;

@@ -134,8 +134,10 @@ struct Sky {
         const float x_r = rho * f(AF_INV_H);
         return lut2d(R.transmittance_tex.data, UnitToTex<256>(x_mu), UnitToTex<64>(x_r));
     }
-    VPT_D f3 Transmittance(float r, float mu, float d, bool ground) const {           // :472
-        const float r_d = ClampRadius(RadiusAt(r, mu, d));
+    // r_d = ClampRadius(RadiusAt(r, mu, d)) is passed in: GetSkyRadianceToPoint needs the very same
+    // value again as r_p (:781; d >= 0 there, so its max(d, 0) changes nothing) and the double-precision
+    // square root is the most expensive single operation of the ground path
+    VPT_D f3 Transmittance(float r, float mu, float d, float r_d, bool ground) const {           // :472
         const float mu_d = ClampCosine(fdiv(r * mu + d, r_d));
         f3 num, den;
         if (ground) { num = TransmittanceToTop(r_d, -mu_d); den = TransmittanceToTop(r, -mu); }
@@ -335,7 +337,8 @@ struct Sky {
 #ifdef VPT_ABL_T1
         transmittance = mk3(0.99f);
 #else
-        transmittance = Transmittance(r, mu, d, ground);
+        const float r_d = ClampRadius(RadiusAt(r, mu, d));
+        transmittance = Transmittance(r, mu, d, r_d, ground);
 #endif
         f3 single_mie;
 #ifdef VPT_ABL_S1
@@ -344,7 +347,11 @@ struct Sky {
         f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
 #endif
         d = fmax_(d, 0.0f);
+#ifdef VPT_ABL_T1
         const float r_p = ClampRadius(RadiusAt(r, mu, d));
+#else
+        const float r_p = r_d;
+#endif
         const float inv_rp = frcp(r_p);
         const float mu_p = (r * mu + d) * inv_rp;
         const float mu_s_p = (r * mu_s + d * nu) * inv_rp;

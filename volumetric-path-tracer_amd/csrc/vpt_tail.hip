@@ -46,8 +46,26 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
         const uint32_t local_it = iteration / R.iter_stride;
-        const float4* rec = reinterpret_cast<const float4*>(R.records + ((size_t)k * R.n_pixels + idx));
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        const size_t slot = (size_t)k * R.n_pixels + idx;
+        float4 q0, q1, q2, q3;
+        bool from_record = true;
+        if (R.heads) {
+            const float4 h = R.heads[slot];
+            if (h.w != -1.0f) {
+                // no 64-byte record: a primary ray that started no walk (or a sample that is not rendered)
+                const bool rendered = h.w >= 0.0f;
+                const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
+                q0 = make_float4(l, l, l, 0.0f);
+                q1 = make_float4(b, b, b, rendered ? h.w : 0.0f);
+                q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(rendered ? 1u : 0u));
+                q3 = make_float4(h.x, h.y, h.z, 0.0f);
+                from_record = false;
+            }
+        }
+        if (from_record) {
+            const float4* rec = reinterpret_cast<const float4*>(R.records + slot);
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+        }
         f3 value = mk3(q0.x, q0.y, q0.z);
         float tr = q0.w;
         const f3 beta = mk3(q1.x, q1.y, q1.z);
@@ -61,7 +79,11 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 // procedural sky, no sky_mult / sky_color, whatever environment_type says
                 value += beta * sky.sample(env_pos, dir, sun_dir);
             } else if (R.environment_type == 0) {                                   // :1838-1842
+#ifdef VPT_ABL_NOSKY
+                if (R.has_atmosphere) value += dir * beta * R.sky_mult * sky_color;
+#else
                 if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
+#endif
             } else {                                                                 // :1843-1850
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }

@@ -145,7 +145,14 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                 r3 = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), depth, t_box);
                 enqueue = true;
             }
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+            if (P.heads) {
+                // compact stream (lens_radius == 0: org0 is the camera origin for every sample): a sample
+                // that starts no walk is fully described by its 16-byte head
+                P.heads[s] = make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f));
+                if (traced) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3; }
+            } else {
+                dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+            }
         }
         const unsigned long long m = __ballot(enqueue);
         if (m != 0ull) {
