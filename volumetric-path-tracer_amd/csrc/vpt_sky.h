@@ -42,23 +42,10 @@ enum {
     AF_COUNT = 34,
 };
 
-#ifdef VPT_SKY_DBG_DIV
-VPT_D float frcp(float x) { return 1.0f / x; }
-VPT_D float fdiv(float a, float b) { return a / b; }
-#else
 VPT_D float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 VPT_D float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-#endif
-#ifdef VPT_SKY_DBG_SQRT
-VPT_D float fsqrt(float x) { return sqrtf(x); }
-#else
 VPT_D float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-#endif
-#ifdef VPT_SKY_DBG_NOFMA
-VPT_D float ffma(float a, float b, float c) { return a * b + c; }
-#else
 VPT_D float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-#endif
 VPT_D float flerp(float a, float b, float t) { return ffma(t, b - a, a); }
 VPT_D f3 flerp3(f3 a, f3 b, float t) { return mk3(flerp(a.x, b.x, t), flerp(a.y, b.y, t), flerp(a.z, b.z, t)); }
 VPT_D f3 fscale_add3(f3 a, float s, f3 b) { return mk3(ffma(a.x, s, b.x), ffma(a.y, s, b.y), ffma(a.z, s, b.z)); }
@@ -120,11 +107,7 @@ struct Sky {
     }
     VPT_D bool HitsGround(float r, float mu) const { return mu < 0.0f && Disc(r, mu, bottom()) >= 0.0; }   // :401
     template <int N>
-#ifdef VPT_SKY_DBG_UNIT
-    VPT_D static float UnitToTex(float x) { return (float)(0.5 / (double)N + (double)x * (1.0 - 1.0 / (double)N)); }
-#else
     VPT_D static float UnitToTex(float x) { return ffma(x, (float)(1.0 - 1.0 / (double)N), (float)(0.5 / (double)N)); }   // :419
-#endif
     VPT_D f3 TransmittanceToTop(float r, float mu) const {                            // :429-470
         const float rho = SafeSqrt(r * r - bottom() * bottom());
         const float d = DistanceToTop(r, mu);
@@ -179,12 +162,8 @@ struct Sky {
             const float d_max = rho + H;
             u_mu = 0.5f + 0.5f * UnitToTex<64>(fdiv(d - d_min, d_max - d_min));
         }
-#ifdef VPT_ABL_SKYCAM
-        const float a = mu_s * 0.3f;
-#else
         const float d = DistanceToTop(bottom(), mu_s);
         const float a = (d - (top() - bottom())) * f(AF_INV_DMUS);
-#endif
         const float u_mu_s = UnitToTex<32>(fdiv(fmax_(1.0f - a * f(AF_INV_A), 0.0f), 1.0f + a));
         const float u_nu = (nu + 1.0f) * 0.5f;
         return mk4(u_nu, u_mu_s, u_mu, u_r);
@@ -334,33 +313,17 @@ struct Sky {
         const float mu_s = dot(camera, sun_direction) * inv_r;
         const float nu = dot(view_ray, sun_direction);
         const bool ground = HitsGround(r, mu);
-#ifdef VPT_ABL_T1
-        transmittance = mk3(0.99f);
-#else
         const float r_d = ClampRadius(RadiusAt(r, mu, d));
         transmittance = Transmittance(r, mu, d, r_d, ground);
-#endif
         f3 single_mie;
-#ifdef VPT_ABL_S1
-        f3 scattering = mk3(mu * 1e-9f); single_mie = mk3(mu_s * 1e-9f);
-#else
         f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
-#endif
         d = fmax_(d, 0.0f);
-#ifdef VPT_ABL_T1
-        const float r_p = ClampRadius(RadiusAt(r, mu, d));
-#else
         const float r_p = r_d;
-#endif
         const float inv_rp = frcp(r_p);
         const float mu_p = (r * mu + d) * inv_rp;
         const float mu_s_p = (r * mu_s + d * nu) * inv_rp;
         f3 single_mie_p;
-#ifdef VPT_ABL_S2
-        const f3 scattering_p = mk3(mu_p * 1e-9f); single_mie_p = mk3(mu_s_p * 1e-9f);
-#else
         const f3 scattering_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, ground, single_mie_p);
-#endif
         scattering = scattering - transmittance * scattering_p;
         single_mie = single_mie - transmittance * single_mie_p;
         const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);                           // smoothstep(0, 0.01, mu_s)
@@ -385,12 +348,8 @@ struct Sky {
             const float inv_r = frcp(r);
             const f3 normal = pt * inv_r;
             const float mu_s = dot(pt, sun_direction) * inv_r;
-#ifdef VPT_ABL_IRR
-            f3 sky_irr = mk3(mu_s), sun_irr = mk3(inv_r);
-#else
             f3 sky_irr = Irradiance(r, mu_s) * ((1.0f + dot(normal, pt) * inv_r) * 0.5f);     // :818
             f3 sun_irr = v(AF_SOLAR) * TransmittanceToSun(r, mu_s) * fmax_(dot(normal, sun_direction), 0.0f);
-#endif
             if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
             radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
             f3 tr;

@@ -79,11 +79,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 // procedural sky, no sky_mult / sky_color, whatever environment_type says
                 value += beta * sky.sample(env_pos, dir, sun_dir);
             } else if (R.environment_type == 0) {                                   // :1838-1842
-#ifdef VPT_ABL_NOSKY
-                if (R.has_atmosphere) value += dir * beta * R.sky_mult * sky_color;
-#else
                 if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
-#endif
             } else {                                                                 // :1843-1850
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }

@@ -161,17 +161,18 @@ VPT_D bool to_unit(const DVolume& v, f3 p, f3& u) {
     q.x = q.x - v.bmin[0];
     q.y = q.y - v.bmin[1];
     q.z = q.z - v.bmin[2];
-#ifdef VPT_ABL_FASTDIV
-    u.x = q.x * __builtin_amdgcn_rcpf(v.fdim[0]);
-    u.y = q.y * __builtin_amdgcn_rcpf(v.fdim[1]);
-    u.z = q.z * __builtin_amdgcn_rcpf(v.fdim[2]);
-#else
     u.x = q.x / v.fdim[0];
     u.y = q.y / v.fdim[1];
     u.z = q.z / v.fdim[2];
-#endif
     return !(u.x < .0f || u.y < .0f || u.z < .0f || u.x > 1.0f || u.y > 1.0f || u.z > 1.0f);
 }
+
+// Grid pointers read from an instance descriptor in memory are generic pointers to the compiler, which
+// then emits FLAT loads (slower path, ties up both memory counters); they are global: say so.
+typedef const __attribute__((address_space(1))) float* gptr_f;
+typedef float __attribute__((ext_vector_type(4))) v4f;
+typedef const __attribute__((address_space(1))) v4f* gptr_f4;
+VPT_D f4 ld_g4(gptr_f4 g, uint32_t i) { const v4f v = g[i]; return mk4(v.x, v.y, v.z, v.w); }
 
 struct Taps {
     int i0, i1, j0, j1, k0, k1;
@@ -197,7 +198,8 @@ VPT_D Taps make_taps(const int* dim, f3 u) {
 }
 // trilinear f32 fetch: CUDA "linear, normalised, clamp" addressing, fp32 weights, nested
 // lerp x -> y -> z with lerp(a,b,t) = a + t*(b-a)
-VPT_D float fetch_f32(const float* __restrict__ g, const int* dim, const Taps& t) {
+VPT_D float fetch_f32(const float* __restrict__ g_, const int* dim, const Taps& t) {
+    const gptr_f g = (gptr_f)g_;
     const uint32_t dx = (uint32_t)dim[0];
     const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
     const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
@@ -217,7 +219,8 @@ VPT_D float fetch_f32(const float* __restrict__ g, const int* dim, const Taps& t
 }
 // same trilinear fetch from the bricked layout (vpt_device.h): texel (i, j, k) lives at
 //   (((k>>2) * by + (j>>2)) * bx + (i>>2)) * 64 + (k&3) * 16 + (j&3) * 4 + (i&3)
-VPT_D float fetch_f32_bricked(const float* __restrict__ g, const DVolume& v, const Taps& t) {
+VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, const Taps& t) {
+    const gptr_f g = (gptr_f)g_;
     const uint32_t bx = (uint32_t)v.bdim[0], by = (uint32_t)v.bdim[1];
     const uint32_t x0 = ((uint32_t)t.i0 >> 2) * 64u + ((uint32_t)t.i0 & 3u), x1 = ((uint32_t)t.i1 >> 2) * 64u + ((uint32_t)t.i1 & 3u);
     const uint32_t y0 = ((uint32_t)t.j0 >> 2) * bx * 64u + (((uint32_t)t.j0 & 3u) << 2), y1 = ((uint32_t)t.j1 >> 2) * bx * 64u + (((uint32_t)t.j1 & 3u) << 2);
@@ -235,16 +238,17 @@ VPT_D float fetch_f32_bricked(const float* __restrict__ g, const DVolume& v, con
     return c0 + (c1 - c0) * t.az;
 }
 VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
-VPT_D f3 fetch_f4(const f4* __restrict__ g, const int* dim, const Taps& t) {
+VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t) {
+    const gptr_f4 g = (gptr_f4)g_;
     const uint32_t dx = (uint32_t)dim[0];
     const uint32_t r00 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
     const uint32_t r10 = ((uint32_t)t.k0 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
     const uint32_t r01 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j0) * dx;
     const uint32_t r11 = ((uint32_t)t.k1 * (uint32_t)dim[1] + (uint32_t)t.j1) * dx;
-    const f4 c00 = lerp4(g[r00 + t.i0], g[r00 + t.i1], t.ax);
-    const f4 c10 = lerp4(g[r10 + t.i0], g[r10 + t.i1], t.ax);
-    const f4 c01 = lerp4(g[r01 + t.i0], g[r01 + t.i1], t.ax);
-    const f4 c11 = lerp4(g[r11 + t.i0], g[r11 + t.i1], t.ax);
+    const f4 c00 = lerp4(ld_g4(g, r00 + t.i0), ld_g4(g, r00 + t.i1), t.ax);
+    const f4 c10 = lerp4(ld_g4(g, r10 + t.i0), ld_g4(g, r10 + t.i1), t.ax);
+    const f4 c01 = lerp4(ld_g4(g, r01 + t.i0), ld_g4(g, r01 + t.i1), t.ax);
+    const f4 c11 = lerp4(ld_g4(g, r11 + t.i0), ld_g4(g, r11 + t.i1), t.ax);
     return xyz(lerp4(lerp4(c00, c10, t.ay), lerp4(c01, c11, t.ay), t.az));
 }
 

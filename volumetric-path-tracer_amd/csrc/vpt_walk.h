@@ -99,11 +99,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
             f3 nmin, nmax;
-#ifdef VPT_ABL_NOLOCATE
-            st = LOC_LEAF; nmin = nmax = mk3(0.0f);
-#else
             st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
-#endif
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
                 float t_min, t_max;
@@ -125,20 +121,14 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         // :1647-1651
         float t_min, t_max, geo_dist;
         box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, w.distance);
-#ifndef VPT_ABL_NOSPHERE
         if (sphere_intersect(P, w.pos, w.dir, geo_dist, t_max)) {
             w.distance = geo_dist;
             w.geo = true;
         }
-#endif
     }
     int spins = 0;
     for (;;) {
-#ifdef VPT_ABL_FASTLOG
-        const float lg = __logf(1 - rnd(rng, draws));
-#else
         const float lg = det_logf(1 - rnd(rng, draws));
-#endif
         if (COUNT) c.n_steps++;
         if (is_sample) w.t -= lg * K.inv_max * K.inv_dm;                          // :1652
         else if (is_emit) w.t -= lg * K.inv_max * P.tr_depth / P.extinction[0];   // :1331
