@@ -90,3 +90,19 @@ def test_sphere_in_view_and_viz_dof(pkg):
     sd.sphere.color = pkg.scene.Float3(0.7, 0.6, 0.5)
     sd.sphere.roughness = 0.4
     _check(pkg, sd, 3)
+
+
+def test_two_different_files_take_the_general_instance_path(pkg):
+    """instances of DIFFERENT grids (per-instance descriptors differ in more than the transform):
+    the compact single-file layout must not be used; density-only dragon + coloured smoke + a heat grid"""
+    S = pkg.scene
+    sd = S.dragon_scene(128, 96, "sun")
+    dens, cd = S.smoke_grids(20)
+    heat = (dens * dens).astype(np.float32)
+    vdb = S.make_gpu_vdb(dens, (0, 0, 0), (19, 19, 19), S._grid_matrix(dens.shape, 0.25, centre=(9.0, 3.0, 5.0)), 0.25, emission=heat, color=cd)
+    sd.volumes.append((vdb, dens, heat, cd))
+    sd.kp.emission_scale = 0.5
+    cam, _, _ = S.frame_camera(pkg.load_library(), [v[0] for v in sd.volumes], 128, 96)
+    sd.camera = cam
+    st = _check(pkg, sd, 3)
+    assert st.color_lookups > 0 and st.emission_lookups > 0

@@ -60,6 +60,8 @@ struct vpt_ctx {
     std::vector<vpt_gpu_vdb> host_volumes;
     std::vector<DVolume> host_dvolumes;
     DVolume* d_volumes = nullptr;
+    float4* d_insts = nullptr;        // compact per-instance matrices (TraceParams::insts)
+    bool single_file = false;
     std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
     float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
     uint32_t* d_leaf_offsets = nullptr;
@@ -266,6 +268,7 @@ void vpt_destroy(vpt_ctx* ctx) {
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
     (void)hipFree(ctx->d_cam_tab);
+    (void)hipFree(ctx->d_insts);
     (void)hipFree(ctx->d_volumes);
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
@@ -501,6 +504,22 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     (void)hipFree(ctx->d_leaf_indices); ctx->d_leaf_indices = nullptr;
     HIPCHK(ctx, hipMalloc(&ctx->d_volumes, sizeof(DVolume) * num_volumes));
     HIPCHK(ctx, hipMemcpy(ctx->d_volumes, dv.data(), sizeof(DVolume) * num_volumes, hipMemcpyHostToDevice));
+    {
+        // do all instances share one file (everything but the transform identical)?
+        bool same = true;
+        for (int i = 1; i < num_volumes && same; ++i) {
+            DVolume a = dv[0], b = dv[i];
+            std::memset(a.m, 0, sizeof(a.m));
+            std::memset(b.m, 0, sizeof(b.m));
+            same = std::memcmp(&a, &b, sizeof(DVolume)) == 0;
+        }
+        ctx->single_file = same;
+        std::vector<float> im((size_t)num_volumes * 16, 0.0f);
+        for (int i = 0; i < num_volumes; ++i) std::memcpy(&im[(size_t)i * 16], dv[i].m, sizeof(float) * 12);
+        (void)hipFree(ctx->d_insts); ctx->d_insts = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->d_insts, im.size() * sizeof(float)));
+        HIPCHK(ctx, hipMemcpy(ctx->d_insts, im.data(), im.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx, hipMalloc(&ctx->d_leaf_offsets, sizeof(uint32_t) * 513));
     HIPCHK(ctx, hipMemcpy(ctx->d_leaf_offsets, offsets.data(), sizeof(uint32_t) * 513, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc(&ctx->d_leaf_indices, sizeof(uint32_t) * indices.size()));
@@ -713,6 +732,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.leaf_offsets = ctx->d_leaf_offsets; P.leaf_indices = ctx->d_leaf_indices;
     P.volumes = ctx->d_volumes; P.num_volumes = (int)ctx->host_dvolumes.size();
     P.vol0 = ctx->host_dvolumes[0];
+    P.insts = ctx->d_insts;
+    P.single_file = ctx->single_file ? 1 : 0;
     st3(P.sph_center, ref_sphere->center); P.sph_radius = ref_sphere->radius;
     st3(P.sph_color, ref_sphere->color); P.sph_roughness = ref_sphere->roughness;
     P.num_lights = (int)lights->num_lights;

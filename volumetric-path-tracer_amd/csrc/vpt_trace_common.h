@@ -153,11 +153,12 @@ VPT_D int locate(const TraceParams& P, const uint32_t* occ, f3 p, f3& nmin, f3& 
 }
 
 // world -> normalised texture coordinates (render_kernel.cu:987-997)
-VPT_D bool to_unit(const DVolume& v, f3 p, f3& u) {
+// m: the instance's 3x4 world->index matrix (v.m, or the compact copy of it in TraceParams::insts)
+VPT_D bool to_unit(const float* m, const DVolume& v, f3 p, f3& u) {
     f3 q;
-    q.x = v.m[0] * p.x + v.m[1] * p.y + v.m[2] * p.z + v.m[3];
-    q.y = v.m[4] * p.x + v.m[5] * p.y + v.m[6] * p.z + v.m[7];
-    q.z = v.m[8] * p.x + v.m[9] * p.y + v.m[10] * p.z + v.m[11];
+    q.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    q.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    q.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
     q.x = q.x - v.bmin[0];
     q.y = q.y - v.bmin[1];
     q.z = q.z - v.bmin[2];
@@ -254,10 +255,10 @@ VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t) {
 
 // one volume's contribution at world position p (get_density / get_color / get_emission)
 template <bool COLOR, bool EMIT, bool COUNT>
-VPT_D void lookup_volume(const TraceParams& P, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
+VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
                          float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e) {
     f3 u;
-    const bool inside = to_unit(v, p, u);
+    const bool inside = to_unit(m, v, p, u);
     // every texture object has its own extent (the reference densifies each grid over its own
     // active bbox, gpu_vdb.cpp:179,262,343) but is addressed with the density grid's normalised
     // coordinates

@@ -152,12 +152,24 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     f3 Cd = COLOR ? mk3(0.0f) : mk3(1.0f);
     f3 em = mk3(0.0f);
     if (!MULTI) {
-        lookup_volume<COLOR, EMIT, COUNT>(P, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+        lookup_volume<COLOR, EMIT, COUNT>(P, P.vol0.m, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
     } else {
         const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
-        for (uint32_t q = b; q < e; ++q) {
-            const DVolume& v = P.volumes[P.leaf_indices[q]];
-            lookup_volume<COLOR, EMIT, COUNT>(P, v, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+        if (P.single_file) {
+            // instances of one file: 48-byte matrix per instance, the rest from vol0 (SGPRs)
+            typedef float __attribute__((ext_vector_type(4))) v4;
+            const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
+            for (uint32_t q = b; q < e; ++q) {
+                const uint32_t vi = P.leaf_indices[q] * 4u;
+                const v4 r0 = ip[vi], r1 = ip[vi + 1u], r2 = ip[vi + 2u];
+                const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                lookup_volume<COLOR, EMIT, COUNT>(P, m, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+            }
+        } else {
+            for (uint32_t q = b; q < e; ++q) {
+                const DVolume& v = P.volumes[P.leaf_indices[q]];
+                lookup_volume<COLOR, EMIT, COUNT>(P, v.m, v, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
+            }
         }
     }
     if (is_sample) {
