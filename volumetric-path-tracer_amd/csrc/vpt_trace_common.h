@@ -256,7 +256,7 @@ VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t) {
 // one volume's contribution at world position p (get_density / get_color / get_emission)
 template <bool COLOR, bool EMIT, bool COUNT>
 VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
-                         float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e) {
+                         float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e, bool count_color = false) {
     f3 u;
     const bool inside = to_unit(m, v, p, u);
     // every texture object has its own extent (the reference densifies each grid over its own
@@ -269,6 +269,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             density += v.bricked ? fetch_f32_bricked(v.density, v, t) : fetch_f32(v.density, v.dim, t);
         }
     }
+    if (COLOR && COUNT && count_color && v.has_color) n_c++;      // the reference looks the colour up here (see walk_step)
     if (COLOR && want_color) {
         if (!v.has_color) {
             color = fmax3(color, mk3(1.0f));

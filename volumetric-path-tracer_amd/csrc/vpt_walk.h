@@ -75,6 +75,32 @@ struct WalkCounts {
     uint32_t n_d, n_c, n_e, n_steps, n_skips;
 };
 
+// Calls f(matrix, descriptor) for every instance listed in octree leaf `leaf` (in list order).
+template <bool MULTI, class F>
+VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
+    if (!MULTI) {
+        f(P.vol0.m, P.vol0);
+        return;
+    }
+    const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
+    if (P.single_file) {
+        // instances of one file: 48-byte matrix per instance, the rest from vol0 (SGPRs)
+        typedef float __attribute__((ext_vector_type(4))) v4;
+        const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
+        for (uint32_t q = b; q < e; ++q) {
+            const uint32_t vi = P.leaf_indices[q] * 4u;
+            const v4 r0 = ip[vi], r1 = ip[vi + 1u], r2 = ip[vi + 2u];
+            const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            f(m, P.vol0);
+        }
+    } else {
+        for (uint32_t q = b; q < e; ++q) {
+            const DVolume& v = P.volumes[P.leaf_indices[q]];
+            f(v.m, v);
+        }
+    }
+}
+
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
 // the fused first walk (record_hist), stride 256 floats.
 // retries (vol_integrator only, else NULL): how many further `sample()` calls the integrator's depth
@@ -151,27 +177,13 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     float density = 0.0f;
     f3 Cd = COLOR ? mk3(0.0f) : mk3(1.0f);
     f3 em = mk3(0.0f);
-    if (!MULTI) {
-        lookup_volume<COLOR, EMIT, COUNT>(P, P.vol0.m, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
-    } else {
-        const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
-        if (P.single_file) {
-            // instances of one file: 48-byte matrix per instance, the rest from vol0 (SGPRs)
-            typedef float __attribute__((ext_vector_type(4))) v4;
-            const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
-            for (uint32_t q = b; q < e; ++q) {
-                const uint32_t vi = P.leaf_indices[q] * 4u;
-                const v4 r0 = ip[vi], r1 = ip[vi + 1u], r2 = ip[vi + 2u];
-                const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-                lookup_volume<COLOR, EMIT, COUNT>(P, m, P.vol0, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
-            }
-        } else {
-            for (uint32_t q = b; q < e; ++q) {
-                const DVolume& v = P.volumes[P.leaf_indices[q]];
-                lookup_volume<COLOR, EMIT, COUNT>(P, v.m, v, w.pos, !is_emit, is_sample, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e);
-            }
-        }
-    }
+    // sum_density / sum_emission over the instances of this leaf (:1003, :970).  The reference also
+    // evaluates sum_color here at every step of sample() (:1662), but its value is only used on a real
+    // collision (:1673): it is counted here and FETCHED there (8 float4 texels per instance -- most of
+    // what the texture-data path returned per step in instanced scenes).
+    for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {
+        lookup_volume<COLOR, EMIT, COUNT>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
+    });
     if (is_sample) {
         // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
         // (one correctly rounded divide by emission_pivot) and fetch are evaluated there.
@@ -181,6 +193,14 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
             n_hist++;
         }
         if (density * K.inv_max > rnd(rng, draws)) {
+            if (COLOR) {
+                uint32_t z0 = 0, z1 = 0, z2 = 0;
+                float dz = 0.0f;
+                f3 ez = mk3(0.0f);
+                for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {       // sum_color :931 (component-wise max)
+                    lookup_volume<COLOR, false, false>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
+                });
+            }
             const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
             const float* dc = P.density_color_lut + 3 * index;
             w.mi = true;
