@@ -75,20 +75,27 @@ enum : uint32_t {
 #define VPT_RAYGEN_ROWS 64        // pixel rows per raygen block (block = 64 x 4 threads, 16 passes)
 template <bool COUNT>
 __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
-    // grid: (ceil(W/64), ceil(H/64), iterations); a block sweeps a 64x64 pixel tile in 16 passes and
+    // grid: tiles x iterations (1-D, tile-major); a block sweeps a 64x64 pixel tile in 16 passes and
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
     __shared__ uint32_t s_q[64 * VPT_RAYGEN_ROWS];
     __shared__ uint32_t s_n, s_base;
     if (threadIdx.x == 0 && threadIdx.y == 0) s_n = 0;
     __syncthreads();
-    const int x = (int)(blockIdx.x * 64u + threadIdx.x);
-    const uint32_t kiter = blockIdx.z;
+    // 1-D grid in TILE-major order, the batch's iterations of one 64x64 tile back to back: the queue then
+    // holds a tile's rays of all iterations contiguously, so the rays the tracer has in flight at any time
+    // come from a few neighbouring tiles and touch a small part of the grid (L2 / Infinity Cache locality
+    // for grids that do not fit them)
+    const uint32_t tiles_x = (P.width + 63u) / 64u;
+    const uint32_t tile = blockIdx.x / P.iter_count;
+    const uint32_t kiter = blockIdx.x - tile * P.iter_count;
+    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int x = (int)(tile_x * 64u + threadIdx.x);
     const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
     const int lane = __lane_id();
     const bool rendered = iteration < P.max_interactions && P.render;
     uint32_t n_final = 0;
     for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
-        const int y = (int)(blockIdx.y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
+        const int y = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
         bool enqueue = false;
         uint32_t s = 0;
         if (x < (int)P.width && y < (int)P.height) {
@@ -542,7 +549,7 @@ static hipError_t launch_variant(const TraceParams& P, int blocks, hipStream_t s
 }
 
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream) {
-    const dim3 grid((P.width + 63u) / 64u, (P.height + VPT_RAYGEN_ROWS - 1u) / VPT_RAYGEN_ROWS, P.iter_count), block(64, 4, 1);
+    const dim3 grid(((P.width + 63u) / 64u) * ((P.height + VPT_RAYGEN_ROWS - 1u) / VPT_RAYGEN_ROWS) * P.iter_count), block(64, 4, 1);
     if (P.counters) hipLaunchKernelGGL((raygen_kernel<true>), grid, block, 0, stream, P);
     else hipLaunchKernelGGL((raygen_kernel<false>), grid, block, 0, stream, P);
     return hipGetLastError();
