@@ -96,7 +96,7 @@ struct TraceParams {
     int render;
     uint32_t regen_min;              // refill when at least this many lanes of a wave are idle
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
-    uint32_t* work_counter;          // next queue entry the tracer hands out
+    uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor
     const uint32_t* queue_count;     // == queue_tail, read by the tracer

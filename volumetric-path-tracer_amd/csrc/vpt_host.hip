@@ -78,7 +78,7 @@ struct vpt_ctx {
     size_t records_capacity = 0;           // in records
     float2* d_bn_table = nullptr;
     size_t bn_capacity = 0;                // in iterations
-    uint32_t* d_work_counter = nullptr;     // [0] tracer's dequeue cursor, [1] raygen's queue tail
+    uint32_t* d_work_counter = nullptr;     // [0] the tracer's dequeue cursor, [8] raygen's queue tail (own cache line apart)
     uint32_t* d_queue = nullptr;
     float* d_vdc = nullptr;
     Counters* d_counters = nullptr;
@@ -246,7 +246,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = (uint32_t)std::atoi(trm);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
     HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
     {
@@ -573,9 +573,9 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
     }
     out->samples = ctx->last_samples;
     {
-        uint32_t wc[2] = {0, 0};
+        uint32_t wc[9] = {0};
         HIPCHK(ctx, hipMemcpy(wc, ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
-        out->queued_rays = wc[1];
+        out->queued_rays = wc[8];
     }
     if (ctx->counting) {
         Counters c;
@@ -829,8 +829,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     R.heads = P.heads;
     R.cam_origin[0] = cam->origin.x; R.cam_origin[1] = cam->origin.y; R.cam_origin[2] = cam->origin.z;
     P.queue = ctx->d_queue;
-    P.queue_tail = ctx->d_work_counter + 1;
-    P.queue_count = ctx->d_work_counter + 1;
+    P.queue_tail = ctx->d_work_counter + 8;
+    P.queue_count = ctx->d_work_counter + 8;
     P.blue_noise = ctx->d_bn_table;
     R.records = ctx->d_records;
 
@@ -863,7 +863,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         R.iter_begin = it0; R.iter_count = n;
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 2 * sizeof(uint32_t), stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 16 * sizeof(uint32_t), stream));
         HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride, stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);

@@ -202,13 +202,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
             const unsigned long long active = __ballot(1);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
-                const int leader = __ffsll((long long)active) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(P.work_counter, (uint32_t)VPT_CHUNK);
-                base = __shfl(base, leader);
-                chunk_next = min(base, total);
-                chunk_end = min(base + (uint32_t)VPT_CHUNK, total);
-                if (chunk_end == total) more = false;
+                claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
             }
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0u && !more && idle == active) break;
