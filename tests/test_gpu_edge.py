@@ -143,3 +143,28 @@ def test_bricked_density_layout_is_bit_identical(pkg, monkeypatch, scene):
     assert a.accum.abs().max() > 0
     np.testing.assert_array_equal(a.accum.cpu().numpy(), b.accum.cpu().numpy())
     np.testing.assert_array_equal(a.depth.cpu().numpy(), b.depth.cpu().numpy())
+
+
+def test_striped_batches_spanning_chunks(pkg, monkeypatch):
+    """iteration striping (stride 3, starting at iteration 1) across several record chunks == one chunk,
+    and == the oracle rendering the same stripe"""
+    import oracle_binding
+    sd = pkg.scene.dragon_scene(72, 40, "sun")
+    phi = np.float32((1.0 + np.sqrt(np.float32(5.0))) / np.float32(2.0))
+    monkeypatch.setenv("VPT_BATCH_ITERS", "2")
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.ctx.blue_noise_advance(a.blue_noise, 1)
+    a.render(5, iter_stride=3, iteration=1)
+    a.sync()
+    monkeypatch.delenv("VPT_BATCH_ITERS")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.ctx.blue_noise_advance(b.blue_noise, 1)
+    b.render(5, iter_stride=3, iteration=1)
+    b.sync()
+    np.testing.assert_array_equal(a.accum.cpu().numpy(), b.accum.cpu().numpy())
+    np.testing.assert_array_equal(a.blue_noise.cpu().numpy(), b.blue_noise.cpu().numpy())
+    ob = oracle_binding.OracleBinding(sd)
+    ob.blue_noise[:, :] = np.fmod(ob.blue_noise + phi, np.float32(1.0))
+    ob.render(5, iter_stride=3, iteration=1)
+    assert rel_l2(a.accum.cpu().numpy(), ob.accum) <= 2e-6
+    np.testing.assert_array_equal(a.blue_noise.cpu().numpy(), ob.blue_noise)
