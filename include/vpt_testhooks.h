@@ -26,8 +26,9 @@ int vpt_test_device_product_stream(vpt_ctx *ctx, unsigned int key, unsigned int 
 /* schedule histogram of the last counted render (vpt_set_counting(ctx, 1)): wave-level sums of
  * [0] tracer loop passes, [1] walking lanes, [2] lanes parked in transition states, [3] idle lanes,
  * [4] passes that ran transitions, [5] inner transition passes, [6] lanes in them, [7] lanes that
- * executed the tracking step proper */
-int vpt_test_get_schedule(vpt_ctx *ctx, unsigned long long out[8]);
+ * executed the tracking step proper; [8..11] wave-level shader-clock cycles spent in refill, Philox
+ * top-up, the walk step and the transition states (direct tracer only) */
+int vpt_test_get_schedule(vpt_ctx *ctx, unsigned long long out[12]);
 #ifdef __cplusplus
 }
 #endif

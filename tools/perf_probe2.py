@@ -34,9 +34,16 @@ for combo in itertools.product(*vals) if vals else [()]:
 
 import ctypes as C
 hb = S.HipBinding(sd, device=0)
+hb.render(min(a.spp, 4), iteration=0); hb.sync()
+outp = (C.c_ulonglong * 12)()
+pkg.load_library().vpt_test_get_schedule(hb.ctx.h, outp)
+op = list(outp)
+if sum(op[8:12]):
+    tot = float(sum(op[8:12]))
+    print("section cycles (non-counting kernel): refill %.1f%%, philox top-up %.1f%%, walk step %.1f%%, transitions %.1f%%" % tuple(100.0 * x / tot for x in op[8:12]))
 hb.ctx.set_counting(True)
 hb.render(min(a.spp, 4), iteration=0); hb.sync()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 pkg.load_library().vpt_test_get_schedule(hb.ctx.h, out)
 o = list(out); st = hb.ctx.stats()
 if o[0]:

@@ -86,6 +86,8 @@ struct Counters {
     // [4] passes that ran transitions, [5] inner transition passes, [6] lanes in them,
     // [7] lanes that executed the tracking step proper (after the empty-node loop)
     unsigned long long sched[8];
+    // [0] refill, [1] Philox top-up, [2] walk step, [3] transitions: wave-level shader-clock cycles (s_memtime)
+    unsigned long long cycles[4];
 };
 
 struct TraceParams {
@@ -104,6 +106,7 @@ struct TraceParams {
     float4* heads;                   // [iter_count][n_pixels] 16-byte sample heads, or NULL (see ResolveParams)
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
+    Counters* prof;                  // section cycle counters of -DVPT_PROFILE_SECTIONS builds (else unused)
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera
     DCamera cam;

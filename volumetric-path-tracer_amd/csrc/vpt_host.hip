@@ -590,12 +590,13 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
     return VPT_OK;
 }
 
-int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[8]) {
+int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[12]) {
     if (!ctx || !out) return VPT_E_INVALID;
     Counters c;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memcpy(out, c.sched, sizeof(c.sched));
+    std::memcpy(out + 8, c.cycles, sizeof(c.cycles));
     return VPT_OK;
 }
 
@@ -723,6 +724,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.trans_min = ctx->trans_min;
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
+    P.prof = ctx->d_counters;
     P.vdc_tables = ctx->d_vdc;
     static_assert(sizeof(DCamera) == sizeof(vpt_camera), "camera layout");
     std::memcpy(&P.cam, cam, sizeof(DCamera));
@@ -845,7 +847,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     ctx->spans.clear();
     ctx->ev_used = 0;
     ctx->last_samples = 0;
-    if (ctx->counting) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), stream));
 
     const bool multi = P.num_volumes > 1;
     const bool color = ctx->any_color;

@@ -228,6 +228,15 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     bool more = true;
     uint32_t chunk_next = 0, chunk_end = 0;
 
+    // section timing (perf studies): only in -DVPT_PROFILE_SECTIONS builds, and only in the non-counting
+    // instantiation (the look-up counters' atomics would distort it)
+#ifdef VPT_PROFILE_SECTIONS
+    constexpr bool PROF = !COUNT;
+#else
+    constexpr bool PROF = false;
+#endif
+    unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
+#define VPT_TICK(acc) do { if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tstamp; tstamp = now_; } } while (0)
     for (;;) {
         // ==== refill idle lanes from the compacted ray queue ===================================
         // The wave owns a chunk [chunk_next, chunk_end) of queue entries at a time, so the global
@@ -240,7 +249,13 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
             }
             const uint32_t avail = chunk_end - chunk_next;
-            if (avail == 0u && !more && idle == active) break;
+            if (avail == 0u && !more && idle == active) {
+                if (PROF && lane == 0) {
+                    atomicAdd(&P.prof->cycles[0], tc0); atomicAdd(&P.prof->cycles[1], tc1);
+                    atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3);
+                }
+                break;
+            }
             if (avail != 0u && (n_idle >= regen_min || idle == active)) {
                 const uint32_t first = chunk_next;
                 chunk_next += min(n_idle, avail);
@@ -292,8 +307,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
         }
 
+        VPT_TICK(tc0);
         // ==== one tracking step for every walking lane =====================================
         rng_top_up(rng, pixel);
+        VPT_TICK(tc1);
         if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const int kind = phase <= PH_W_TRACK ? WALK_SAMPLE : (phase == PH_W_EMIT ? WALK_EMIT : WALK_TR);
             const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt);
@@ -308,6 +325,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
         }
 
+        VPT_TICK(tc2);
         // ==== transitions: integrator control flow between walks ===========================
         // States are visited in successor order, so e.g. TRACK_DONE -> OUTER_SECOND -> OUTER_TOP
         // -> FINISH resolves in a single pass.  Each state draws at most 2 random numbers.
@@ -531,7 +549,9 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
             if (start_tr) phase = tr_begin(P, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
         }
+        VPT_TICK(tc3);
     }
+#undef VPT_TICK
 }
 
 // ---- launcher -------------------------------------------------------------------------------
