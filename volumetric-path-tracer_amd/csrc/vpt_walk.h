@@ -59,7 +59,7 @@ enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
 #define VPT_SKIP_LOOP 8
 #endif
 #ifndef VPT_RETRY_SPINS
-#define VPT_RETRY_SPINS 3
+#define VPT_RETRY_SPINS 4
 #endif
 struct Walk {
     f3 pos, dir, inv;     // walk ray (inv = 1 / dir)
@@ -107,11 +107,12 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
 // loop would make from this very position if the current one ends without an interaction at
 // t >= distance (:1654 -> :1740 next iteration).  Such a call repeats the same point location, the
 // same exit distance and sphere test and differs only in its exponential draw, so it is replayed
-// right here (one draw + one log per retry) instead of costing a pass of the walk loop each.
+// right here (one draw + one log per retry, as many as the buffered Philox words allow) instead of costing
+// a pass of the walk loop each.
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
 VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                      float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
-                     int* retries = nullptr, uint32_t rng_key = 0) {
+                     int* retries = nullptr) {
     const bool is_sample = kind == WALK_SAMPLE;
     const bool is_emit = EMIT && kind == WALK_EMIT;
     // Empty-node pushes are cheap and the tracking step below is expensive, so the wave first loops
@@ -164,8 +165,10 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
             if (retries && is_sample && *retries > 0) {
                 *retries -= 1;                   // the next sample() call, same position: t = 0 again
                 w.t = 0.0f;
-                if (++spins >= VPT_RETRY_SPINS) return false;     // the rest of the wave is waiting: next pass
-                rng_top_up(rng, rng_key);
+                // a retry draws once and a step that goes on draws a second time: stay within the words
+                // buffered since the pass's refill point (vpt_rng.h), and do not hold the wave up for long
+                const uint32_t buffered = (rng.has_carry ? 1u : 0u) + (4u - rng.idx);
+                if (buffered < 2u || ++spins >= VPT_RETRY_SPINS) return false;
                 continue;
             }
             return true;
