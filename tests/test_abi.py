@@ -19,6 +19,16 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.vpt_abi_version() == 1
+    # ... and everything the other two headers declare (vpt_io.h: host-side formats, vpt_testhooks.h: probes)
+    for h, listed in (("vpt_io.h", set(pkg.io.IO_SYMBOLS)), ("vpt_testhooks.h", None)):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = set(re.findall(r"\b(vpt_[a-z_0-9]+)\s*\(", text))
+        assert names, h
+        if listed is not None:
+            assert names == listed, (h, names ^ listed)
+        for name in names:
+            assert hasattr(lib, name), (h, name)
 
 
 def test_struct_layouts_match_the_c_compiler(pkg, tmp_path):
