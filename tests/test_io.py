@@ -329,3 +329,18 @@ def test_pfm_ppm_writers(pkg, tmp_path):
 def test_io_symbols_exported(pkg):
     lib = pkg.load_library()
     assert [s for s in pkg.io.IO_SYMBOLS if not hasattr(lib, s)] == []
+
+
+def test_io_struct_layout_matches_the_c_compiler(pkg, tmp_path):
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(root, "include", "vpt_io.h"), "int main(){",
+           'printf("%zu %zu %zu %zu\\n", sizeof(vpt_io_instance), offsetof(vpt_io_instance, position), offsetof(vpt_io_instance, rotation), offsetof(vpt_io_instance, scale));',
+           "return 0;}"]
+    c = tmp_path / "l.c"
+    c.write_text("\n".join(src))
+    subprocess.run(["gcc", str(c), "-o", str(tmp_path / "l")], check=True)
+    got = [int(x) for x in subprocess.run([str(tmp_path / "l")], check=True, capture_output=True, text=True).stdout.split()]
+    I = pkg.io.Instance
+    assert got == [C.sizeof(I), I.position.offset, I.rotation.offset, I.scale.offset]
