@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
     bool more = true;
-    uint32_t chunk_next = 0, chunk_end = 0;
+    uint32_t chunk_next = 0, chunk_end = 0, chunk_base = 0;
+    uint32_t qi0 = 0, qi1 = 0, qi2 = 0, qi3 = 0;       // this wave's chunk of queue entries, 4 per lane
 
     // section timing (perf studies): only in -DVPT_PROFILE_SECTIONS builds, and only in the non-counting
     // instantiation (the look-up counters' atomics would distort it)
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 #else
     constexpr bool PROF = false;
 #endif
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;       // transitions, split (PROF builds)
     unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
 #define VPT_TICK(acc) do { if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tstamp; tstamp = now_; } } while (0)
     for (;;) {
@@ -247,22 +249,36 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
                 claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
+                // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
+                // memory latency (the ray record) instead of two dependent ones
+                chunk_base = chunk_next;
+                qi0 = chunk_base + (uint32_t)lane < chunk_end ? P.queue[chunk_base + (uint32_t)lane] : 0u;
+                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 64u + (uint32_t)lane] : 0u;
+                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 128u + (uint32_t)lane] : 0u;
+                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 192u + (uint32_t)lane] : 0u;
             }
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0u && !more && idle == active) {
                 if (PROF && lane == 0) {
                     atomicAdd(&P.prof->cycles[0], tc0); atomicAdd(&P.prof->cycles[1], tc1);
-                    atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3);
+                    atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3 + ts0 + ts1 + ts2 + ts3 + ts4);
+                    atomicAdd(&P.prof->sched[0], ts0); atomicAdd(&P.prof->sched[1], ts1); atomicAdd(&P.prof->sched[2], ts2);
+                    atomicAdd(&P.prof->sched[3], ts3); atomicAdd(&P.prof->sched[4], ts4);
                 }
                 break;
             }
             if (avail != 0u && (n_idle >= regen_min || idle == active)) {
                 const uint32_t first = chunk_next;
                 chunk_next += min(n_idle, avail);
+                // entry e of the chunk sits in word (e >> 6) of lane (e & 63); all lanes take part in the exchange
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t rel = first + rank - chunk_base;
+                const int src_lane = (int)(rel & 63u);
+                const uint32_t e0 = __shfl(qi0, src_lane), e1 = __shfl(qi1, src_lane), e2 = __shfl(qi2, src_lane), e3 = __shfl(qi3, src_lane);
                 if (phase == PH_IDLE) {
-                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (rank < avail) {
-                        const uint32_t slot = P.queue[first + rank];
+                        const uint32_t word = rel >> 6;
+                        const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
                         kiter = slot / P.n_pixels;
                         pixel = slot - kiter * P.n_pixels;
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
@@ -390,6 +406,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 gco_obj = -1;
                 phase = PH_T_OUTER_TOP;
             }
+            VPT_TICK(ts0);                       // pass entry + FIRST_DONE / REPLAY
             if (phase == PH_T_TRACK_DONE) {
                 // :1789-1796
                 beta *= w.wgt;
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     phase = PH_T_OUTER_SECOND;
                 }
             }
+            VPT_TICK(ts1);                       // TRACK_DONE .. EMIT / SPH
             if (phase == PH_T_OUTER_SECOND) {
                 if (gco_obj < 0) gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t); // :1806
                 if (gco_obj == 2) {
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     }
                 }
             }
+            VPT_TICK(ts2);                       // OUTER_SECOND + OUTER_TOP
             if (phase == PH_T_FINISH) {
                 const f3 od = w.dir, oL = L, ob = beta, oe = env_pos;
                 float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
@@ -546,8 +565,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 phase = PH_IDLE;
             }
 
+            VPT_TICK(ts3);                       // FINISH
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
             if (start_tr) phase = tr_begin(P, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
+            VPT_TICK(ts4);                       // Tr prologue
         }
         VPT_TICK(tc3);
     }

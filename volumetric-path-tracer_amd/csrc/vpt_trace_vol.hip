@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
     bool more = true;
-    uint32_t chunk_next = 0, chunk_end = 0;
+    uint32_t chunk_next = 0, chunk_end = 0, chunk_base = 0;
+    uint32_t qi0 = 0, qi1 = 0, qi2 = 0, qi3 = 0;       // this wave's chunk of queue entries, 4 per lane
 
     for (;;) {
         // ==== refill idle lanes from the compacted ray queue (as in vpt_trace.hip) ============
@@ -203,16 +204,28 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
                 claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
+                // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
+                // memory latency (the ray record) instead of two dependent ones
+                chunk_base = chunk_next;
+                qi0 = chunk_base + (uint32_t)lane < chunk_end ? P.queue[chunk_base + (uint32_t)lane] : 0u;
+                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 64u + (uint32_t)lane] : 0u;
+                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 128u + (uint32_t)lane] : 0u;
+                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 192u + (uint32_t)lane] : 0u;
             }
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0u && !more && idle == active) break;
             if (avail != 0u && (n_idle >= regen_min || idle == active)) {
                 const uint32_t first = chunk_next;
                 chunk_next += min(n_idle, avail);
+                // entry e of the chunk sits in word (e >> 6) of lane (e & 63); all lanes take part in the exchange
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t rel = first + rank - chunk_base;
+                const int src_lane = (int)(rel & 63u);
+                const uint32_t e0 = __shfl(qi0, src_lane), e1 = __shfl(qi1, src_lane), e2 = __shfl(qi2, src_lane), e3 = __shfl(qi3, src_lane);
                 if (phase == VH_IDLE) {
-                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (rank < avail) {
-                        const uint32_t slot = P.queue[first + rank];
+                        const uint32_t word = rel >> 6;
+                        const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
                         kiter = slot / P.n_pixels;
                         pixel = slot - kiter * P.n_pixels;
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
