@@ -108,7 +108,7 @@ def main():
         hb.blue_noise.copy_(bn0)
         tstream.synchronize()                           # torch's stream -> visible to the ctx stream
         if bn_pre:
-            hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre)
+            hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre, sd.width * sd.height)
         hb.render(spp, iter_stride=stride, iteration=first_it)
         if world > 1:
             hb.sync()                                   # ctx stream -> visible to torch's stream

@@ -288,9 +288,11 @@ int  vpt_render_batch(vpt_ctx *ctx, const vpt_camera *cam, const vpt_light_list 
                       unsigned int iter_stride, void *stream);
 
 /* advance a 256x256 float3 blue-noise buffer by `steps` golden-ratio increments
- * (render_kernel.cu:2320-2325), e.g. to position rank g of a striped render */
+ * (render_kernel.cu:2320-2325), e.g. to position rank g of a striped render.  As in the
+ * reference, a launch only advances the entries its pixels own: the first
+ * min(num_pixels, 65536) (`if (idx < 256*256)` with idx < W*H); pass num_pixels = W*H. */
 int  vpt_blue_noise_advance(vpt_ctx *ctx, vpt_float3 *blue_noise_buffer, unsigned int steps,
-                            void *stream);
+                            unsigned int num_pixels, void *stream);
 
 /* per-launch statistics of the last render call (device counters, read back after a
  * sync): look-up counts feeding the algorithmic-bytes roofline */

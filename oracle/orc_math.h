@@ -10,7 +10,7 @@
 //   * logf / sinf / cosf on the decision path are the deterministic Cephes-style
 //     single-precision routines below (orc_logf, orc_sinf, orc_cosf), because the
 //     reference's `--use_fast_math` intrinsics (source/CMakeLists.txt:133) are not
-//     reproducible off an NVIDIA GPU ("parity unpinned").  They are
+//     reproducible off an NVIDIA GPU (oracle/_ref is built with the same routines).  They are
 //     checked against glibc in tests/test_oracle_math.py.
 #ifndef ORC_MATH_H_
 #define ORC_MATH_H_

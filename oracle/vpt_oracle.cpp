@@ -3,7 +3,8 @@
 // calls.  One C++ thread = one CUDA thread of the reference; control flow, operand
 // order and the quirks listed in SURVEY.md 8a ("Q-list") are kept on purpose.
 //
-// PARITY UNPINNED (see vpt_oracle.h).  Only tests/, __graft_entry__.smoke() and
+// PARITY PINNED on the reference's own kernel source compiled for the CPU (oracle/_ref, see vpt_oracle.h and
+// tests/test_oracle_vs_ref.py).  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may build, load or call this file.
 //
 // Third-party arithmetic that is not under /root/reference and is restated here:
@@ -1445,7 +1446,9 @@ int orc_render(const vpt_camera* cam, const vpt_light_list* lights, const vpt_gp
         if (iter_tot.max_draws_per_sample > total.max_draws_per_sample) total.max_draws_per_sample = iter_tot.max_draws_per_sample;
         // :2320-2325, applied after the launch (iter_stride launches' worth for striping)
         for (unsigned int s = 0; s < iter_stride; ++s) {
-            for (int i = 0; i < 256 * 256; ++i) {
+            // `if (idx < 256*256)` runs for idx < W*H only: smaller images advance just their first W*H entries
+            const int live = (long long)W * H < 256 * 256 ? W * H : 256 * 256;
+            for (int i = 0; i < live; ++i) {
                 vpt_float3 v = kp.blue_noise_buffer[i];
                 const float phi = (1.0f + sqrtf(5.0f)) / 2.0f;
                 v.x = std::fmod(v.x + phi, 1.0f);

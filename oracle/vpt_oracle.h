@@ -5,14 +5,22 @@
  * the checker for the HIP path and the "CPU ray-marching baseline" of bench.py.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *
- * PARITY UNPINNED: the reference ships no tests, golden images or known answers for
- * this path and cannot be built here (CUDA/OpenVDB/Windows deps).
- * What is pinned (tests/test_oracle_pins.py): Philox4x32-10 against the Random123
- * known-answer vectors and cuRAND's stream semantics, the dragon.vdb asset facts (voxel
- * count, bbox, value range, fixture regenerated from the asset), the sampler states
- * (exactness on linear fields, point / wrap / unnormalised addressing), the octree against
- * brute-force point location, the density look-up against a numpy trilinear reference,
- * and the fixed-sequence log/sin/cos against libm.
+ * PARITY PINNED against the reference's own code: oracle/_ref/libvptref.so is the reference's
+ * source/render_kernel.cu (+ source/bvh/octree.cpp) compiled unmodified for the CPU where it lies
+ * (recipe: `make -C oracle ref`, stand-in CUDA headers in oracle/ref_shim/), and
+ * tests/test_oracle_vs_ref.py requires orc_render's buffers to equal that library's BIT FOR BIT on
+ * 13 scenes covering both integrators, point light / sun / sky / HDRI, emission, colour grids, 16
+ * instances, thin lens + viz_dof, max_interactions and render=false -- live where the library
+ * exists, and against tests/golden/ref_golden.npz (written from it) everywhere else.  Inside that
+ * library only the texture fetch and the Philox block function are this oracle's; they are pinned on
+ * their own (tests/test_oracle_pins.py): Philox4x32-10 against the Random123 known-answer vectors
+ * and cuRAND's stream semantics, the sampler states on exact cases (linear fields, point / wrap /
+ * unnormalised addressing), plus the dragon.vdb asset facts, the octree against brute-force point
+ * location, the density look-up against a numpy trilinear reference and the fixed-sequence
+ * log/sin/cos against libm.  (The reference ships no tests or golden images of its own)
+ * Not covered by the pin: the atmosphere tables' CONTENT (GPU precompute, checked separately) and
+ * the arithmetic of nvcc's default FMA contraction / approximate intrinsics -- both sides are built
+ * with -ffp-contract=off and correctly rounded division/sqrt, see DESIGN.md "arithmetic contract".
  *
  * It re-uses the POD structs of include/vpt_abi.h (they restate the reference's PODs).
  * Texture handles inside those PODs are oracle handles made by orc_texture_create;

@@ -1,0 +1,82 @@
+"""Scenes on which the oracle is pinned against the reference's own kernel (oracle/_ref) -- TEST INFRASTRUCTURE.
+
+Shared by tests/test_oracle_vs_ref.py (live comparison where oracle/_ref/libvptref.so exists) and
+tests/golden/make_ref_golden.py (writes tests/golden/ref_golden.npz from the compiled reference, so that the pin also
+holds where /root/reference does not exist).  Every case covers a different part of volume_rt_kernel:
+"""
+import numpy as np
+
+from oracle_binding import pkg
+from ref_binding import attach_synthetic_atmosphere
+
+S = pkg.scene
+
+
+def _dragon(cfg, w=96, h=54, **kw):
+    def make():
+        sd = S.dragon_scene(w, h, cfg)
+        for k, v in kw.items():
+            setattr(sd.kp, k, v)
+        return sd
+    return make
+
+
+def _dragon_dof():
+    sd = S.dragon_scene(64, 36, "sun")
+    cam, _, _ = S.frame_camera(pkg.host.load_library(), [sd.volumes[0][0]], 64, 36, aperture=3.0)
+    sd.camera = cam
+    sd.camera.viz_dof = 1
+    return sd
+
+
+def _cloud(integrator, sky):
+    def make():
+        sd = S.cloud_scene(48, 32, shape=(38, 22, 32), env=(64, 32), integrator=integrator)
+        if sky:
+            sd.kp.environment_type = 0
+            sd.env_map = None
+            sd.env_cdf = pkg.host.env_cdf_build(sd.kp)
+        return sd
+    return make
+
+
+def _two_files():
+    """two different grids (one with emission, one with colour) + a point light: the multi-file path"""
+    sd = S.fireball_scene(56, 40, n=32)
+    other = S.instanced_scene(56, 40, n=20, grid=2)
+    sd.volumes += other.volumes
+    vols = [v for v, _, _, _ in sd.volumes]
+    sd.camera, center, dist = S.frame_camera(pkg.host.load_library(), vols, 56, 40)
+    pl = pkg.abi.PointLight()
+    pl.pos = S.f3(center + np.array([0, dist, 0], np.float32))
+    pl.color = pkg.abi.Float3(1.0, 0.8, 0.6)
+    pl.power = float(dist * dist)
+    sd.lights.append(pl)
+    return sd
+
+
+# name -> (scene factory, iterations)
+CASES = {
+    "dragon_point_light": (_dragon("c1"), 3),                       # point-light NEE, direct_integrator
+    "dragon_sun": (_dragon("sun"), 3),                              # sun NEE through the atmosphere tables
+    "dragon_sun_sky": (_dragon("c2"), 3),                           # + sky tail (GetSkyRadiance) on every path
+    "dragon_hg_forward": (_dragon("sun", phase_g1=0.7, ray_depth=6, tr_depth=0.5), 2),
+    "dragon_max_interactions": (_dragon("sun", max_interactions=2), 4),   # iterations >= max_interactions stop accumulating
+    "dragon_no_render": (_dragon("sun", render=0), 2),
+    "dragon_dof_viz": (_dragon_dof, 2),                             # thin lens (van der Corput rejection) + viz_dof
+    "fireball_emission": (lambda: S.fireball_scene(64, 40, n=48), 2),    # estimate_emission + blackbody table
+    "instanced_colour": (lambda: S.instanced_scene(64, 40, n=24, grid=4), 2),  # 16 instances, Cd grids, octree with empty nodes
+    "two_files_point_light": (_two_files, 2),
+    "cloud_vol_hdri": (_cloud(1, False), 2),                        # vol_integrator, HDRI background
+    "cloud_direct_hdri": (_cloud(0, False), 2),                     # direct_integrator on the HDRI
+    "cloud_vol_sky_cdf": (_cloud(1, True), 2),                      # vol_integrator, estimate_sky over the CDF tables
+}
+
+BUFFERS = ("accum", "depth", "raw", "display", "blue_noise")
+
+
+def build(name):
+    make, iters = CASES[name]
+    sd = make()
+    attach_synthetic_atmosphere(sd)
+    return sd, iters

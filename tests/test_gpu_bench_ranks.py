@@ -39,7 +39,7 @@ def test_striped_ranks_equal_single_rank(pkg):
         first, stride, pre = pkg.dist.stripe(rank, 2)
         hb = pkg.scene.HipBinding(sd, device=0)
         if pre:
-            hb.ctx.blue_noise_advance(hb.blue_noise, pre)
+            hb.ctx.blue_noise_advance(hb.blue_noise, pre, sd.width * sd.height)
         hb.render(4, iter_stride=stride, iteration=first)
         hb.sync()
         parts.append(hb.accum.clone())

@@ -153,12 +153,12 @@ def test_striped_batches_spanning_chunks(pkg, monkeypatch):
     phi = np.float32((1.0 + np.sqrt(np.float32(5.0))) / np.float32(2.0))
     monkeypatch.setenv("VPT_BATCH_ITERS", "2")
     a = pkg.scene.HipBinding(sd, device=0)
-    a.ctx.blue_noise_advance(a.blue_noise, 1)
+    a.ctx.blue_noise_advance(a.blue_noise, 1, sd.width * sd.height)
     a.render(5, iter_stride=3, iteration=1)
     a.sync()
     monkeypatch.delenv("VPT_BATCH_ITERS")
     b = pkg.scene.HipBinding(sd, device=0)
-    b.ctx.blue_noise_advance(b.blue_noise, 1)
+    b.ctx.blue_noise_advance(b.blue_noise, 1, sd.width * sd.height)
     b.render(5, iter_stride=3, iteration=1)
     b.sync()
     np.testing.assert_array_equal(a.accum.cpu().numpy(), b.accum.cpu().numpy())

@@ -173,7 +173,7 @@ def test_iteration_striping_two_ranks(pkg, ob_mod):
     parts = []
     for r in range(2):
         hb = pkg.scene.HipBinding(sd, device=0)
-        hb.ctx.blue_noise_advance(hb.blue_noise, r)
+        hb.ctx.blue_noise_advance(hb.blue_noise, r, sd.width * sd.height)
         hb.render(4, iter_stride=2, iteration=r)
         hb.sync()
         parts.append(hb.accum.double() * 4)

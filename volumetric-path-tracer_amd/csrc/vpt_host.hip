@@ -27,7 +27,7 @@ hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool e
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream);
-hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, hipStream_t stream);
+hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
 
 using namespace vpt;
@@ -866,7 +866,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 16 * sizeof(uint32_t), stream));
-        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride, stream));
+        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride,
+                                      (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull), stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
         if (blocks < 1) blocks = 1;
@@ -897,12 +898,12 @@ int vpt_render(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* lights
     return vpt_render_batch(ctx, cam, lights, ref_sphere, atmosphere, kernel_params, 1, 1, stream);
 }
 
-int vpt_blue_noise_advance(vpt_ctx* ctx, vpt_float3* blue_noise_buffer, unsigned int steps, void* stream_v) {
+int vpt_blue_noise_advance(vpt_ctx* ctx, vpt_float3* blue_noise_buffer, unsigned int steps, unsigned int num_pixels, void* stream_v) {
     if (!ctx || !blue_noise_buffer) return VPT_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     if (steps == 0) return VPT_OK;
-    HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(blue_noise_buffer), nullptr, 1, steps, stream));
+    HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(blue_noise_buffer), nullptr, 1, steps, std::min(num_pixels, 65536u), stream));
     return VPT_OK;
 }
 

@@ -67,7 +67,7 @@ def load_library(path=None):
     render_args = [vp, C.POINTER(Camera), C.POINTER(LightList), C.POINTER(Sphere), C.POINTER(AtmosphereParameters), C.POINTER(KernelParams)]
     lib.vpt_render.argtypes = render_args + [vp]
     lib.vpt_render_batch.argtypes = render_args + [C.c_uint, C.c_uint, vp]
-    lib.vpt_blue_noise_advance.argtypes = [vp, vp, C.c_uint, vp]
+    lib.vpt_blue_noise_advance.argtypes = [vp, vp, C.c_uint, C.c_uint, vp]
     lib.vpt_set_counting.argtypes = [vp, C.c_int]
     lib.vpt_get_stats.argtypes = [vp, C.POINTER(RenderStats)]
     lib.vpt_camera_update.argtypes = [C.POINTER(Camera), Float3, Float3, Float3, C.c_float, C.c_float, C.c_float]
@@ -203,6 +203,7 @@ class Context:
         self._chk(self.lib.vpt_render_batch(self.h, C.byref(cam), C.byref(lights), C.byref(sphere), C.byref(atmosphere), C.byref(kp),
                                             int(iter_count), int(iter_stride), C.c_void_p(stream) if stream else None), "vpt_render_batch")
 
-    def blue_noise_advance(self, bn_tensor, steps, stream=None):
-        self._chk(self.lib.vpt_blue_noise_advance(self.h, C.c_void_p(bn_tensor.data_ptr()), int(steps),
+    def blue_noise_advance(self, bn_tensor, steps, num_pixels, stream=None):
+        """num_pixels = W*H of the render being positioned (only min(W*H, 65536) entries advance per launch)."""
+        self._chk(self.lib.vpt_blue_noise_advance(self.h, C.c_void_p(bn_tensor.data_ptr()), int(steps), int(num_pixels),
                                                   C.c_void_p(stream) if stream else None), "vpt_blue_noise_advance")
