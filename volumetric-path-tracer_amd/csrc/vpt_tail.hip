@@ -14,9 +14,12 @@
 
 namespace vpt {
 
-// IEEE divide regardless of this translation unit's relaxed flags (the accumulation below is
-// order- and rounding-sensitive: it is the running mean of the reference, :2278-2287)
-VPT_D f3 div_rn(f3 a, float b) { return mk3(__fdiv_rn(a.x, b), __fdiv_rn(a.y, b), __fdiv_rn(a.z, b)); }
+// IEEE binary32 divide regardless of this translation unit's relaxed flags (the running means of the
+// reference, :2278-2287, are compared bit for bit): the quotient is formed in binary64, whose 53 bits
+// (>= 2*24+2) make the second rounding innocuous, so (float)((double)a / b) IS the correctly rounded
+// binary32 quotient.  __fdiv_rn is just `a / b` in HIP and follows the approximate-divide flag.
+VPT_D float div1_rn(float a, float b) { return (float)((double)a / (double)b); }
+VPT_D f3 div_rn(f3 a, float b) { return mk3(div1_rn(a.x, b), div1_rn(a.y, b), div1_rn(a.z, b)); }
 VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
     f3 a = v * (v + 0.0245786f) - 0.000090537f;
     f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
@@ -102,8 +105,10 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         } else if (iteration < R.max_interactions) {
             const float n = (float)(local_it + 1);
             acc = acc + div_rn(value - acc, n);
-            cst = cst + div_rn(mk3(0.0f) - cst, n);
-            dep = dep + __fdiv_rn(depth - dep, n);
+            // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
+            if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+            else cst = cst + div_rn(mk3(0.0f) - cst, n);
+            dep = dep + div1_rn(depth - dep, n);
         }
         tr_last = tr;
     }
