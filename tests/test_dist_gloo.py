@@ -68,7 +68,8 @@ def _worker_oracle(rank, world, port, spp, out_dir):
     first, stride, pre = pkg.dist.stripe(rank, world)
     phi = np.float32((1.0 + np.sqrt(np.float32(5.0))) / np.float32(2.0))
     for _ in range(pre):                                   # blue noise pre-advanced `rank` steps (:2320-2325)
-        ob.blue_noise[:, :] = np.fmod(ob.blue_noise + phi, np.float32(1.0))
+        live = min(sd.width * sd.height, 65536)            # a launch advances only the entries its pixels own
+        ob.blue_noise[:live, :] = np.fmod(ob.blue_noise[:live] + phi, np.float32(1.0))
     n_local = len(range(first, spp, stride))
     ob.render(n_local, iter_stride=stride, iteration=first, nthreads=1)
     acc = torch.from_numpy(ob.accum.copy())
