@@ -59,6 +59,13 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y =
 static inline uint3 make_uint3(unsigned x, unsigned y, unsigned z) { uint3 r; r.x = x; r.y = y; r.z = z; return r; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
+// helper_math.h declares unary minus on NON-CONST lvalue references (`operator-(float3 &a)`); the reference negates
+// temporaries, which nvcc's MSVC-compatible front end lets bind to them.  Standard C++ needs these for rvalues
+// (lvalues still pick helper_math.h's own overloads: a non-const reference is the better match).
+static inline float2 operator-(const float2& a) { return make_float2(-a.x, -a.y); }
+static inline float3 operator-(const float3& a) { return make_float3(-a.x, -a.y, -a.z); }
+static inline float4 operator-(const float4& a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+
 // launch indices: the driver runs one "thread" at a time
 extern thread_local uint3 blockIdx, threadIdx;
 extern thread_local dim3 blockDim, gridDim;

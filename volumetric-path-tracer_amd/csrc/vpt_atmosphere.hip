@@ -11,7 +11,11 @@
 // Bruneton's 2017 reference implementation.  The reference's port deviates from it in ways that
 // change the tables, and those are kept because the tables are INPUTS of the hot path:
 //   D1  look-ups during precomputation are nearest-texel reads of the linear buffers
-//       (atmosphere_kernels.cu:157-169, 375-395, 604-616), not filtered fetches;
+//       (atmosphere_kernels.cu:157-169, 375-395, 604-616), not filtered fetches.  They are not
+//       bounds-checked there: a coordinate equal to 1 indexes past the end of a table, and from the
+//       third order on ~1/3 of the scattering texels depend on such reads (measured with guard
+//       regions around the reference's own kernels, tests/test_gpu_atmosphere_vs_ref.py).  Here the
+//       index is clamped into the table -- a definition of what the reference leaves undefined;
 //   D2  orders >= 3 of the scattering density read `scattering_buffer` (the previous order's
 //       result already divided by the Rayleigh phase) instead of the delta-multiple-scattering
 //       buffer (:398-408), and GetIrradiance reads `irradiance_buffer` (:604-616);
