@@ -267,3 +267,47 @@ extern "C" void ref_curand_uniform_stream(unsigned long long seed, unsigned long
     curand_init(seed, 0, offset, &s);
     for (int i = 0; i < n; ++i) out[i] = curand_uniform(&s);
 }
+
+// ---- host-side helpers of the reference, for pinning the product's restatements (vpt_camera_update,
+// vpt_gpu_vdb_bounds, vpt_instance_xform) ----------------------------------------------------------------------------
+extern "C" void ref_camera_update(vpt_camera* out, const float lookfrom[3], const float lookat[3], const float vup[3],
+                                  float vfov, float aspect, float aperture) {
+    camera c;                                                  // the reference's default constructor, then its method
+    c.update_camera(make_float3(lookfrom[0], lookfrom[1], lookfrom[2]), make_float3(lookat[0], lookat[1], lookat[2]),
+                    make_float3(vup[0], vup[1], vup[2]), vfov, aspect, aperture);
+    auto st = [](vpt_float3& d, float3 v) { d.x = v.x; d.y = v.y; d.z = v.z; };
+    out->time1 = c.time1; out->time0 = c.time0;
+    st(out->origin, c.origin);
+    out->focus_dist = c.focus_dist;
+    st(out->lower_left_corner, c.lower_left_corner);
+    st(out->horizontal, c.horizontal);
+    st(out->vertical, c.vertical);
+    st(out->u, c.u); st(out->v, c.v); st(out->w, c.w);
+    out->lens_radius = c.lens_radius;
+}
+
+extern "C" void ref_gpu_vdb_bounds(const vpt_gpu_vdb* v, float pmin[3], float pmax[3]) {
+    GPU_VDB g;
+    g.vdb_info.bmin = cv(v->vdb_info.bmin);
+    g.vdb_info.bmax = cv(v->vdb_info.bmax);
+    mat4 m;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) m.m[c][r] = v->xform[c][r];
+    g.set_xform(m);
+    const AABB b = g.Bounds();
+    pmin[0] = b.pmin.x; pmin[1] = b.pmin.y; pmin[2] = b.pmin.z;
+    pmax[0] = b.pmax.x; pmax[1] = b.pmax.y; pmax[2] = b.pmax.z;
+}
+
+// the calls the reference's .ins loader makes on a file's matrix for one instance (source/main.cpp:1060-1095), on the
+// reference's own mat4 (matrix_math.h)
+extern "C" void ref_instance_xform(const float base[4][4], const double position[3], const double rotation[4], double scale,
+                                   float out[4][4]) {
+    mat4 xform;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) xform.m[c][r] = base[c][r];
+    xform.translate(-xform.extract_translate());
+    xform.scale(make_float3(scale));
+    mat4 rotation_matrix = quaternion_to_mat4(rotation[0], rotation[1], rotation[2], rotation[3]);
+    xform = rotation_matrix * xform;
+    xform.translate(make_float3(position[0], position[1], position[2]));
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) out[c][r] = xform.m[c][r];
+}

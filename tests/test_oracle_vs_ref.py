@@ -80,3 +80,71 @@ def test_curand_stand_in_matches_oracle_stream():
         o.orc_curand_uniform_stream(seed, offset, 37, a.ctypes.data)
         r.ref_curand_uniform_stream(seed, offset, 37, b.ctypes.data)
         assert np.array_equal(a, b)
+
+
+# ---- the product's host-side restatements against the reference's own classes (camera, GPU_VDB, mat4) ------------
+def _host_cases():
+    rng = np.random.default_rng(2024)
+    out = []
+    for _ in range(24):
+        out.append(dict(lookfrom=rng.uniform(-50, 50, 3).astype(np.float32), lookat=rng.uniform(-5, 5, 3).astype(np.float32),
+                        vup=np.array([0, 1, 0], np.float32) if rng.random() < 0.5 else rng.normal(size=3).astype(np.float32),
+                        vfov=float(np.float32(rng.uniform(10, 90))), aspect=float(np.float32(rng.uniform(0.5, 2.5))),
+                        aperture=float(np.float32(rng.uniform(0, 4))),
+                        base=(np.diag([0.1, 0.1, 0.1, 1.0]) + np.pad(rng.normal(size=(3, 3)) * 0.02, ((0, 1), (0, 1)))
+                              + np.vstack([np.zeros((3, 4)), np.append(rng.uniform(-3, 3, 3), 0.0)])).astype(np.float32),
+                        pos=rng.uniform(-40, 40, 3), rot=rng.normal(size=4), scale=float(rng.uniform(0.2, 3.0)),
+                        bmin=rng.uniform(-120, 0, 3).astype(np.float32), bmax=rng.uniform(1, 150, 3).astype(np.float32)))
+    return out
+
+
+@needs_ref
+def test_host_helpers_match_reference_classes():
+    import ctypes as C
+    pkg = oracle_binding.pkg
+    abi = pkg.abi
+    lib = pkg.host.load_library()
+    r = ref_binding.load_ref()
+    F3 = C.c_float * 3
+    F44 = (C.c_float * 4) * 4
+    r.ref_camera_update.argtypes = [C.POINTER(abi.Camera), F3, F3, F3, C.c_float, C.c_float, C.c_float]
+    r.ref_camera_update.restype = None
+    r.ref_gpu_vdb_bounds.argtypes = [C.POINTER(abi.GpuVdb), F3, F3]
+    r.ref_gpu_vdb_bounds.restype = None
+    r.ref_instance_xform.argtypes = [C.POINTER(F44), C.POINTER(C.c_double * 3), C.POINTER(C.c_double * 4), C.c_double, C.POINTER(F44)]
+    r.ref_instance_xform.restype = None
+    cam_fields = ("time1", "time0", "origin", "focus_dist", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius")
+
+    def flat(cam):
+        vals = []
+        for f in cam_fields:
+            v = getattr(cam, f)
+            vals += [v.x, v.y, v.z] if hasattr(v, "x") else [v]
+        return np.array(vals, np.float32)
+
+    for c in _host_cases():
+        a = abi.Camera()
+        lib.vpt_camera_default(C.byref(a))
+        lib.vpt_camera_update(C.byref(a), abi.Float3(*c["lookfrom"]), abi.Float3(*c["lookat"]), abi.Float3(*c["vup"]), c["vfov"], c["aspect"], c["aperture"])
+        b = abi.Camera()
+        r.ref_camera_update(C.byref(b), F3(*c["lookfrom"]), F3(*c["lookat"]), F3(*c["vup"]), c["vfov"], c["aspect"], c["aperture"])
+        np.testing.assert_array_equal(flat(a).view(np.uint32), flat(b).view(np.uint32))
+
+        base = F44(*[(C.c_float * 4)(*row) for row in c["base"]])
+        got, want = F44(), F44()
+        pos = (C.c_double * 3)(*c["pos"])
+        rot = (C.c_double * 4)(*c["rot"])
+        lib.vpt_instance_xform(C.byref(base), C.byref(pos), C.byref(rot), c["scale"], C.byref(got))
+        r.ref_instance_xform(C.byref(base), C.byref(pos), C.byref(rot), c["scale"], C.byref(want))
+        np.testing.assert_array_equal(np.array(got, np.float32).view(np.uint32), np.array(want, np.float32).view(np.uint32))
+
+        v = abi.GpuVdb()
+        C.memmove(C.byref(v.xform), C.byref(want), C.sizeof(want))
+        v.vdb_info.bmin = abi.Float3(*c["bmin"])
+        v.vdb_info.bmax = abi.Float3(*c["bmax"])
+        p0, p1 = abi.Float3(), abi.Float3()
+        lib.vpt_gpu_vdb_bounds(C.byref(v), C.byref(p0), C.byref(p1))
+        q0, q1 = F3(), F3()
+        r.ref_gpu_vdb_bounds(C.byref(v), q0, q1)
+        np.testing.assert_array_equal(np.array([p0.x, p0.y, p0.z, p1.x, p1.y, p1.z], np.float32).view(np.uint32),
+                                      np.array(list(q0) + list(q1), np.float32).view(np.uint32))
