@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="iterations per rank and step (default: the config's own)")
     ap.add_argument("--grid-scale", type=float, default=1.0, help="c4: linear scale of the 1024x704x1216 cloud grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=32)
     args = ap.parse_args()
 
     import numpy as np
@@ -189,13 +189,20 @@ def main():
         if not args.no_cpu_baseline and world == 1 and host_grids:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding
-            ob = oracle_binding.OracleBinding(sd)
+            import ref_binding
             cores = os.cpu_count() or 1
+            # the reference's own kernel source compiled for the CPU (oracle/_ref/libvptref.so, shipped prebuilt) when it
+            # is there, else the oracle restatement; both produce the same image bit for bit (tests/test_oracle_vs_ref.py)
+            use_ref = ref_binding.have_ref()
+            ob = ref_binding.RefBinding(sd) if use_ref else oracle_binding.OracleBinding(sd)
             tc = time.perf_counter()
             ob.render(args.cpu_iters, nthreads=cores)
             dtc = time.perf_counter() - tc
-            cpu = {"value": round(W * H * args.cpu_iters / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                   "sample": "%d of %d iterations of the same %dx%d frame, oracle (OpenMP over rows), %.1f s" % (args.cpu_iters, spp, W, H, dtc)}
+            what = ("reference render_kernel.cu built for the host (oracle/_ref, %d threads over pixels)" % cores) if use_ref \
+                else "oracle (OpenMP over rows)"
+            cpu = {"value": round(W * H * args.cpu_iters / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                   "kind": "reference" if use_ref else "port",
+                   "sample": "%d of %d iterations of the same %dx%d frame, %s, %.1f s" % (args.cpu_iters, spp, W, H, what, dtc)}
         out = {
             "metric": "Msamples/s (W*H*spp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -17,6 +17,14 @@ _synthetic = {}
 
 
 def have_ref():
+    """True when the compiled reference is available; builds it first where the reference tree exists."""
+    if not os.path.exists(REF_PATH) and os.path.isdir("/root/reference/source") and "VPT_REF_PATH" not in os.environ:
+        try:
+            import __graft_entry__ as ge
+            ge.build_oracle()
+            ge.build_ref()
+        except Exception:
+            return False
     return os.path.exists(REF_PATH)
 
 
