@@ -52,7 +52,8 @@ struct vpt_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu = 3;
-    uint32_t regen_min = 8;
+    uint32_t regen_min = 8;        // direct_integrator tracer: refill once >= 8 lanes are idle
+    uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 32;
     std::string last_error;
     std::vector<TexEntry> textures;
@@ -242,7 +243,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     const char* bpc = std::getenv("VPT_BLOCKS_PER_CU");
     if (bpc && std::atoi(bpc) > 0) ctx->blocks_per_cu = std::atoi(bpc);
     const char* rgm = std::getenv("VPT_REGEN_MIN");
-    if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = (uint32_t)std::atoi(rgm);
+    if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = (uint32_t)std::atoi(trm);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -720,7 +721,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.iter_stride = iter_stride;
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;
-    P.regen_min = ctx->regen_min;
+    P.regen_min = kp->integrator != 0 ? ctx->regen_min_vol : ctx->regen_min;
     P.trans_min = ctx->trans_min;
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
