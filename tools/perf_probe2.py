@@ -41,6 +41,7 @@ op = list(outp)
 if sum(op[8:12]):
     tot = float(sum(op[8:12]))
     print("section cycles (non-counting kernel): refill %.1f%%, philox top-up %.1f%%, walk step %.1f%%, transitions %.1f%%" % tuple(100.0 * x / tot for x in op[8:12]))
+    print("  of the walk step, the empty-node skip loop: %.1f%% of all cycles" % (100.0 * op[5] / tot))
     print("  transitions split: entry+FIRST_DONE %.1f%%, TRACK_DONE..EMIT %.1f%%, OUTER_SECOND/TOP %.1f%%, FINISH %.1f%%, Tr prologue %.1f%% (of all cycles)" % tuple(100.0 * x / tot for x in op[0:5]))
 hb.ctx.set_counting(True)
 hb.render(min(a.spp, 4), iteration=0); hb.sync()

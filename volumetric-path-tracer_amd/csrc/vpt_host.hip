@@ -54,7 +54,8 @@ struct vpt_ctx {
     int blocks_per_cu = 3;
     uint32_t regen_min = 8;        // direct_integrator tracer: refill once >= 8 lanes are idle
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
-    uint32_t trans_min = 32;
+    uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
+    uint32_t trans_min_vol = 32;   // vol_integrator tracer
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene
@@ -245,7 +246,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     const char* rgm = std::getenv("VPT_REGEN_MIN");
     if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
-    if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = (uint32_t)std::atoi(trm);
+    if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = ctx->trans_min_vol = (uint32_t)std::atoi(trm);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
@@ -722,7 +723,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;
     P.regen_min = kp->integrator != 0 ? ctx->regen_min_vol : ctx->regen_min;
-    P.trans_min = ctx->trans_min;
+    P.trans_min = kp->integrator != 0 ? ctx->trans_min_vol : ctx->trans_min;
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
     P.prof = ctx->d_counters;

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     constexpr bool PROF = false;
 #endif
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;       // transitions, split (PROF builds)
+    unsigned long long tskip = 0;                                         // skip loop inside the walk step (PROF builds)
     unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
 #define VPT_TICK(acc) do { if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tstamp; tstamp = now_; } } while (0)
     for (;;) {
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3 + ts0 + ts1 + ts2 + ts3 + ts4);
                     atomicAdd(&P.prof->sched[0], ts0); atomicAdd(&P.prof->sched[1], ts1); atomicAdd(&P.prof->sched[2], ts2);
                     atomicAdd(&P.prof->sched[3], ts3); atomicAdd(&P.prof->sched[4], ts4);
+                    atomicAdd(&P.prof->sched[5], tskip + cnt.n_skips);
                 }
                 break;
             }
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         beta = mk3(1.0f);
                         w.mi = false;
                         rd = 1;
+                        if (PROF) tskip += cnt.n_skips;
                         cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
                         if (gco_obj == 1) {
                             w.pos += w.dir * (gco_t + VPT_EPS);

@@ -122,21 +122,21 @@ VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min)
 enum { LOC_LEAF = 0, LOC_EMPTY = 1, LOC_OUTSIDE = 2 };
 VPT_D int locate(const TraceParams& P, const uint32_t* occ, f3 p, f3& nmin, f3& nmax, int& leaf) {
     f3 lo = ld3(P.root_pmin), hi = ld3(P.root_pmax);
+    // The eight children tile their parent's closed box, so "the first child whose closed box contains p" needs a
+    // containment test only once, against the root (the union of its children); below that, one comparison per axis
+    // and level picks the half.  A point ON a splitting plane lies in both halves and the lower child index wins:
+    // the low half in x and z, the HIGH half in y (children 0,1,4,5).  NaN positions fail the root test.
+    if (!(p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z)) return LOC_OUTSIDE;
     int path = 0;
 #pragma unroll
     for (int level = 0; level < 3; ++level) {
         const float hx = (lo.x + hi.x) * 0.5f;
         const float hy = (lo.y + hi.y) * 0.5f;
         const float hz = (lo.z + hi.z) * 0.5f;
-        const uint32_t mx = ((p.x >= lo.x && p.x <= hx) ? 0x55u : 0u) | ((p.x >= hx && p.x <= hi.x) ? 0xAAu : 0u);
-        const uint32_t my = ((p.y >= hy && p.y <= hi.y) ? 0x33u : 0u) | ((p.y >= lo.y && p.y <= hy) ? 0xCCu : 0u);
-        const uint32_t mz = ((p.z >= lo.z && p.z <= hz) ? 0x0Fu : 0u) | ((p.z >= hz && p.z <= hi.z) ? 0xF0u : 0u);
-        const uint32_t m = mx & my & mz;
-        if (m == 0) return LOC_OUTSIDE;
-        const int c = __ffs((int)m) - 1;
-        const bool xh = (c & 1) != 0;
-        const bool yh = (c & 2) == 0;
-        const bool zh = (c & 4) != 0;
+        const bool xh = !(p.x <= hx);
+        const bool yh = p.y >= hy;
+        const bool zh = !(p.z <= hz);
+        const int c = (xh ? 1 : 0) | (yh ? 0 : 2) | (zh ? 4 : 0);
         lo.x = xh ? hx : lo.x; hi.x = xh ? hi.x : hx;
         lo.y = yh ? hy : lo.y; hi.y = yh ? hi.y : hy;
         lo.z = zh ? hz : lo.z; hi.z = zh ? hi.z : hz;

@@ -122,6 +122,9 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     // operations is unchanged.
     int leaf = 0;
     int st = LOC_EMPTY;
+#ifdef VPT_PROFILE_SECTIONS
+    const unsigned long long tp0_ = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
@@ -138,6 +141,9 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         }
         if (!__any(st == LOC_EMPTY)) break;
     }
+#ifdef VPT_PROFILE_SECTIONS
+    if (!COUNT) c.n_skips += (uint32_t)(__builtin_readcyclecounter() - tp0_);      // cycles of the skip loop (perf study)
+#endif
     if (st == LOC_EMPTY) return false;           // still crossing empty nodes: next pass
     if (st == LOC_OUTSIDE) return true;
     if (COUNT) {
