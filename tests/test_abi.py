@@ -1,6 +1,8 @@
 """The C-ABI library loads, exports every symbol include/vpt_abi.h declares, and the ctypes
 mirrors have the C layouts (no compute calls: runs without a GPU)."""
 import ctypes as C
+
+import numpy as np
 import os
 import re
 import subprocess
@@ -101,3 +103,20 @@ def test_render_fails_loudly_without_gpu(pkg):
         pytest.skip("GPU present")
     with pytest.raises(pkg.VptError):
         pkg.Context(0)
+
+
+def test_sqrt_free_thresholds():
+    """csrc/vpt_math.h replaces `sqrtf(x) < c` by `x < T`: T must be the smallest float whose correctly rounded root
+    reaches c (then the two tests agree for EVERY x >= 0, NaN and inf included)."""
+    import re
+    src = open(os.path.join(ROOT, "volumetric-path-tracer_amd", "csrc", "vpt_math.h")).read()
+    for name, c in (("VPT_SQ_OF_FLT_EPSILON", np.float32(1.192092896e-07)), ("VPT_SQ_OF_EPS", np.float32(0.001))):
+        lit = re.search(r"#define %s (\S+)f\s" % name, src).group(1)
+        t = np.float32(float.fromhex(lit))
+        assert float(t) == float.fromhex(lit)                                   # the literal is a float32
+        below = np.nextafter(t, np.float32(0))
+        assert np.sqrt(t, dtype=np.float32) >= c and np.sqrt(below, dtype=np.float32) < c
+        # and on a dense neighbourhood + the extremes
+        x = np.concatenate([t * (1 + np.arange(-4096, 4097, dtype=np.float64) * 2.0 ** -24), [0.0, 1e-45, 1e30, np.inf, np.nan]]).astype(np.float32)
+        with np.errstate(invalid="ignore"):
+            np.testing.assert_array_equal(np.sqrt(x, dtype=np.float32) < c, x < t)

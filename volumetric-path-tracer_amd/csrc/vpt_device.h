@@ -93,6 +93,7 @@ struct Counters {
 struct TraceParams {
     // work distribution
     uint32_t width, height, n_pixels;
+    float inv_n_pixels;              // 1 / n_pixels (fp32), see split_slot
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;
     int render;
@@ -164,6 +165,7 @@ struct TraceParams {
 
 struct ResolveParams {
     uint32_t width, height, n_pixels;
+    float inv_n_pixels;              // 1 / n_pixels (fp32), see split_slot
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;
     const Record* records;

@@ -719,6 +719,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     TraceParams P;
     std::memset(&P, 0, sizeof(P));
     P.width = W; P.height = H; P.n_pixels = n_pixels;
+    P.inv_n_pixels = 1.0f / (float)n_pixels;
     P.iter_stride = iter_stride;
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;

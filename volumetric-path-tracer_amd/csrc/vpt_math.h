@@ -66,7 +66,11 @@ VPT_HD float smoothstep(float a, float b, float x) {
     float y = clampf((x - a) / (b - a), 0.0f, 1.0f);
     return (y * y * (3.0f - (2.0f * y)));
 }
-VPT_HD bool is_black(f3 v) { return length(v) < 1.192092896e-07F; }                 // helper_math.h:1520
+// sqrt-free forms of `sqrtf(x) < c`: a correctly rounded square root is monotone, so RN(sqrt(x)) < c  <=>  x < T with
+// T the smallest float whose rounded root reaches c (tests/test_abi.py::test_sqrt_free_thresholds re-derives both)
+#define VPT_SQ_OF_FLT_EPSILON 0x1p-46f          /* c = FLT_EPSILON (1.192092896e-07F) */
+#define VPT_SQ_OF_EPS 0x1.0c6f7ap-20f           /* c = 0.001f */
+VPT_HD bool is_black(f3 v) { return dot(v, v) < VPT_SQ_OF_FLT_EPSILON; }            // helper_math.h:1520: length(v) < FLT_EPSILON
 
 #define VPT_PI    3.14159265358979323846f
 #define VPT_PI_4  0.785398163397448309616f

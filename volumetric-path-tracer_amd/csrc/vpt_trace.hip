@@ -281,8 +281,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     if (rank < avail) {
                         const uint32_t word = rel >> 6;
                         const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
-                        kiter = slot / P.n_pixels;
-                        pixel = slot - kiter * P.n_pixels;
+                        split_slot(P, slot, kiter, pixel);
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
                         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];

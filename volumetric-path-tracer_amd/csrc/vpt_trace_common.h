@@ -168,6 +168,17 @@ VPT_D bool to_unit(const float* m, const DVolume& v, f3 p, f3& u) {
     return !(u.x < .0f || u.y < .0f || u.z < .0f || u.x > 1.0f || u.y > 1.0f || u.z > 1.0f);
 }
 
+// slot = kiter * n_pixels + pixel with kiter < 64 and slot < 2^31 (record chunks are capped at 16 GiB): the quotient
+// is estimated in fp32 (off by at most one) and corrected exactly, instead of a 40-instruction u32 division
+VPT_D void split_slot(const TraceParams& P, uint32_t slot, uint32_t& kiter, uint32_t& pixel) {
+    uint32_t k = (uint32_t)((float)slot * P.inv_n_pixels);
+    int r = (int)(slot - k * P.n_pixels);
+    if (r < 0) { k -= 1u; r += (int)P.n_pixels; }
+    else if (r >= (int)P.n_pixels) { k += 1u; r -= (int)P.n_pixels; }
+    kiter = k;
+    pixel = (uint32_t)r;
+}
+
 // ---- work distribution ---------------------------------------------------------------------------------
 // The compacted ray queue is in tile-major order (raygen_kernel); a wave claims VPT_CHUNK consecutive
 // entries with one leader atomic on a single global cursor, so the rays in flight across the whole GPU

@@ -221,7 +221,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     } else {
         w.trw *= 1 - ((density - K.sigma_c) * K.sigma_r_inv);                 // :1239
         const float s2 = w.trw * w.trw;
-        if (sqrtf(s2 + s2 + s2) < VPT_EPS) return true;                       // :1261
+        if ((s2 + s2 + s2) < VPT_SQ_OF_EPS) return true;                      // :1261 length(tr) < EPS, without the root
     }
     return false;
 }
