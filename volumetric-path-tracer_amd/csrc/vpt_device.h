@@ -32,7 +32,7 @@ struct DVolume {
     int cdim[3];           // colour texture extent
     int bricked;           // density is stored as 4x4x4 bricks (256 B, x fastest inside a brick), bricks x fastest
     int bdim[2];           // bricks along x and y
-    int pad_;
+    int addr24;            // every texel-index product of this volume's grids fits the 24-bit multiplier (see imul)
 };
 
 struct DTexture {          // CUDA sampler state restated

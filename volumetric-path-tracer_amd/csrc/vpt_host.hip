@@ -436,6 +436,14 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             d.has_color = 1;
             ctx->any_color = true;
         }
+        {
+            // 24-bit index arithmetic (imul in vpt_trace_common.h): x extent, y*z rows and the brick strides below 2^24
+            auto fits = [](const int* g) { return g[0] == 0 || ((long long)g[0] < (1 << 24) && (long long)g[1] * g[2] < (1 << 24)); };
+            const int ddim[3] = {vi.dim.x, vi.dim.y, vi.dim.z};
+            bool ok = fits(ddim) && fits(d.edim) && fits(d.cdim);
+            if (d.bricked) ok = ok && (long long)d.bdim[0] * d.bdim[1] * 64 < (1 << 24);
+            d.addr24 = ok ? 1 : 0;
+        }
         // xform.transpose().inverse(), evaluated once with the operand order of
         // matrix_math.h:214-253 so it carries the bits of the per-lookup inverse (:987)
         const mat4 w2i = mat4_inverse(mat4_transpose(load_xform(volumes[i])));
