@@ -145,6 +145,23 @@ def test_bricked_density_layout_is_bit_identical(pkg, monkeypatch, scene):
     np.testing.assert_array_equal(a.depth.cpu().numpy(), b.depth.cpu().numpy())
 
 
+@pytest.mark.parametrize("bricks", [False, True])
+def test_24_bit_index_arithmetic_is_bit_identical(pkg, monkeypatch, bricks):
+    """texel indices are formed with the 24-bit multiplier where the grid extents allow it (vpt_trace_common.h imul);
+    the 32-bit path (VPT_NO_ADDR24, what a >16.7 M-row grid would take) must give the same bits, bricked or not"""
+    if bricks:
+        monkeypatch.setenv("VPT_BRICK_MIN_BYTES", "0")
+    sd = pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.render(3); a.sync()
+    monkeypatch.setenv("VPT_NO_ADDR24", "1")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.render(3); b.sync()
+    assert a.accum.abs().max() > 0
+    np.testing.assert_array_equal(a.accum.cpu().numpy(), b.accum.cpu().numpy())
+    np.testing.assert_array_equal(a.depth.cpu().numpy(), b.depth.cpu().numpy())
+
+
 def test_striped_batches_spanning_chunks(pkg, monkeypatch):
     """iteration striping (stride 3, starting at iteration 1) across several record chunks == one chunk,
     and == the oracle rendering the same stripe"""

@@ -442,6 +442,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             const int ddim[3] = {vi.dim.x, vi.dim.y, vi.dim.z};
             bool ok = fits(ddim) && fits(d.edim) && fits(d.cdim);
             if (d.bricked) ok = ok && (long long)d.bdim[0] * d.bdim[1] * 64 < (1 << 24);
+            if (std::getenv("VPT_NO_ADDR24")) ok = false;        // tests: force the 32-bit index arithmetic
             d.addr24 = ok ? 1 : 0;
         }
         // xform.transpose().inverse(), evaluated once with the operand order of
