@@ -105,6 +105,7 @@ def main():
     tstream = torch.cuda.current_stream(dev)
 
     def one_step():
+        hb.sync()                                       # the previous step's kernels are done with the blue-noise table
         hb.blue_noise.copy_(bn0)
         tstream.synchronize()                           # torch's stream -> visible to the ctx stream
         if bn_pre:
