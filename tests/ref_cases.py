@@ -55,6 +55,55 @@ def _two_files():
     return sd
 
 
+def _sphere_in_view():
+    """the reference sphere inside the frame: sphere bounce, BLACK shadow rays, depth from the sphere hit"""
+    sd = S.dragon_scene(96, 72, "sun")
+    sd.sphere.center = S.Float3(6.0, 1.5, 4.0)
+    sd.sphere.radius = 1.2
+    sd.sphere.color = S.Float3(0.7, 0.6, 0.5)
+    sd.sphere.roughness = 0.4
+    return sd
+
+
+def _vol_three_lights():
+    """vol_integrator: 2 point lights + sun + HDRI, anisotropic phase: every branch of uniform_sample_one_light"""
+    sd = S.dragon_scene(96, 72, "c2")
+    sd.kp.integrator = 1
+    sd.kp.environment_type = 1
+    sd.env_map = S.hdri_map(64, 32)
+    sd.kp.phase_g1 = 0.4
+    sd.kp.ray_depth = 8
+    sd.kp.density_mult = 3.0
+    for k in range(2):
+        pl = S.PointLight()
+        pl.pos = S.f3(np.array([2.0 + 5.0 * k, 8.0, 5.0], np.float32))
+        pl.color = S.Float3(1.0, 0.7, 0.4 + 0.5 * k)
+        pl.power = 40.0
+        sd.lights.append(pl)
+    return sd
+
+
+def _vol_emission_sphere():
+    """vol_integrator over the fireball (emission at every interaction) with the sphere in the way"""
+    sd = S.fireball_scene(64, 48, n=32)
+    sd.kp.integrator = 1
+    sd.kp.ray_depth = 5
+    sd.kp.emission_scale = 0.7
+    sd.sphere.center = S.Float3(4.0, 2.0, 3.0)
+    sd.sphere.radius = 1.5
+    return sd
+
+
+def _multi_bounce():
+    """volume_depth 3: several delta-tracking walks per outer bounce with HG scattering in between"""
+    sd = S.dragon_scene(96, 54, "sun")
+    sd.kp.volume_depth = 3
+    sd.kp.phase_g1 = -0.3
+    sd.kp.density_mult = 4.0
+    sd.kp.ray_depth = 4
+    return sd
+
+
 # name -> (scene factory, iterations)
 CASES = {
     "dragon_point_light": (_dragon("c1"), 3),                       # point-light NEE, direct_integrator
@@ -70,6 +119,10 @@ CASES = {
     "cloud_vol_hdri": (_cloud(1, False), 2),                        # vol_integrator, HDRI background
     "cloud_direct_hdri": (_cloud(0, False), 2),                     # direct_integrator on the HDRI
     "cloud_vol_sky_cdf": (_cloud(1, True), 2),                      # vol_integrator, estimate_sky over the CDF tables
+    "dragon_sphere_in_view": (_sphere_in_view, 3),
+    "dragon_vol_three_lights": (_vol_three_lights, 2),
+    "fireball_vol_emission_sphere": (_vol_emission_sphere, 2),
+    "dragon_multi_bounce_back_scatter": (_multi_bounce, 2),
 }
 
 BUFFERS = ("accum", "depth", "raw", "display", "blue_noise")
