@@ -104,6 +104,32 @@ def _multi_bounce():
     return sd
 
 
+def _xform_soup():
+    """the reference's second asset (assets/dragon_with_xform.vdb: rotated + sheared AffineMap, 141x99x63) under
+    non-default everything: coloured albedo / extinction, tr_depth, density_mult, energy_inject, sun position,
+    exposure, a wide lens"""
+    lib = pkg.host.load_library()
+    g = S.load_golden("dragon_xform_dense.npz")
+    sd = S.dragon_scene(80, 60, "c2")
+    vdb = S.make_gpu_vdb(g["density"], g["bbox_min"], g["bbox_max"], g["matrix"], g["voxel_size"])
+    sd.volumes = [(vdb, np.ascontiguousarray(g["density"], np.float32), None, None)]
+    sd.camera, _, _ = S.frame_camera(lib, [vdb], 80, 60, fov=40.0, aperture=1.0)
+    kp = sd.kp
+    kp.albedo = S.Float3(0.9, 0.7, 0.5)
+    kp.extinction = S.Float3(1.0, 1.2, 1.5)
+    kp.tr_depth = 0.6
+    kp.density_mult = 2.5
+    kp.energy_inject = 1.3
+    kp.azimuth = 250.0
+    kp.elevation = 12.0
+    kp.exposure_scale = 1.7
+    kp.sun_color = S.Float3(1.0, 0.85, 0.7)
+    kp.sun_mult = 2.0
+    kp.sky_mult = 0.6
+    kp.ray_depth = 7
+    return sd
+
+
 # name -> (scene factory, iterations)
 CASES = {
     "dragon_point_light": (_dragon("c1"), 3),                       # point-light NEE, direct_integrator
@@ -123,6 +149,7 @@ CASES = {
     "dragon_vol_three_lights": (_vol_three_lights, 2),
     "fireball_vol_emission_sphere": (_vol_emission_sphere, 2),
     "dragon_multi_bounce_back_scatter": (_multi_bounce, 2),
+    "dragon_xform_parameter_soup": (_xform_soup, 2),
 }
 
 BUFFERS = ("accum", "depth", "raw", "display", "blue_noise")
