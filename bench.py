@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (guides/MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -105,6 +105,11 @@ def main():
     tstream = torch.cuda.current_stream(dev)
 
     def one_step():
+        if world == 1:
+            # the next `spp` iterations of the progressive render (iteration indices, blue-noise table and running means
+            # carry on from the previous step, as consecutive frames of the reference do): no host round trip between steps
+            hb.render(spp)
+            return
         hb.sync()                                       # the previous step's kernels are done with the blue-noise table
         hb.blue_noise.copy_(bn0)
         tstream.synchronize()                           # torch's stream -> visible to the ctx stream
@@ -122,6 +127,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     torch.cuda.synchronize(dev)
+    hb.kp.iteration = first_it
     for _ in range(args.warmup):
         one_step()
     fence()
