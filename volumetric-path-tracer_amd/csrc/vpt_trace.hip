@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     WalkCounts cnt;
     cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
     bool more = true;
+    int no_retry = 0;              // walk_step's retry count is the vol tracer's
     uint32_t chunk_next = 0, chunk_end = 0, chunk_base = 0;
     uint32_t qi0 = 0, qi1 = 0, qi2 = 0, qi3 = 0;       // this wave's chunk of queue entries, 4 per lane
 
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         VPT_TICK(tc1);
         if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const int kind = phase <= PH_W_TRACK ? WALK_SAMPLE : (phase == PH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt);
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;

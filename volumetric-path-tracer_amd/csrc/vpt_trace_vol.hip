@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
         if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
             const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
             const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
-                                                                   phase == VH_W_TRACK ? &retry : nullptr);
+                                                                   retry, phase == VH_W_TRACK);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
                 else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;

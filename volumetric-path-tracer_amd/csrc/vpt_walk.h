@@ -103,7 +103,7 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
 
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
 // the fused first walk (record_hist), stride 256 floats.
-// retries (vol_integrator only, else NULL): how many further `sample()` calls the integrator's depth
+// retries (vol_integrator only: use_retries): how many further `sample()` calls the integrator's depth
 // loop would make from this very position if the current one ends without an interaction at
 // t >= distance (:1654 -> :1740 next iteration).  Such a call repeats the same point location, the
 // same exit distance and sphere test and differs only in its exponential draw, so it is replayed
@@ -112,7 +112,7 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
 VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                      float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
-                     int* retries = nullptr) {
+                     int& retries, bool use_retries) {
     const bool is_sample = kind == WALK_SAMPLE;
     const bool is_emit = EMIT && kind == WALK_EMIT;
     // Empty-node pushes are cheap and the tracking step below is expensive, so the wave first loops
@@ -168,8 +168,8 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         else w.t -= lg * K.sigma_r_inv * P.tr_depth;                              // :1231
         if (!is_emit && w.t >= w.distance) {
             if (is_sample && w.geo) w.obj2 = true;                                // :1654-1657
-            if (retries && is_sample && *retries > 0) {
-                *retries -= 1;                   // the next sample() call, same position: t = 0 again
+            if (use_retries && is_sample && retries > 0) {
+                retries -= 1;                    // the next sample() call, same position: t = 0 again
                 w.t = 0.0f;
                 // a retry draws once and a step that goes on draws a second time: stay within the words
                 // buffered since the pass's refill point (vpt_rng.h), and do not hold the wave up for long
