@@ -55,7 +55,7 @@ struct vpt_ctx {
     uint32_t regen_min = 8;        // direct_integrator tracer: refill once >= 8 lanes are idle
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
-    uint32_t trans_min_vol = 32;   // vol_integrator tracer
+    uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene
