@@ -123,7 +123,7 @@ struct TraceParams {
     // textures into every instance and changes only the transform): the per-instance descriptor is then
     // just the 3x4 world->index matrix, 48 bytes in insts[] (stride 64), and everything else is vol0 in
     // SGPRs -- a quarter of the bytes the texture-data path has to return per instance visited
-    const float4* insts;             // [num_volumes][4]: matrix rows, {0,0,0,0}
+    const float4* insts;             // [leaf-list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
     int single_file;
     DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs
     // reference sphere

@@ -525,8 +525,10 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             same = std::memcmp(&a, &b, sizeof(DVolume)) == 0;
         }
         ctx->single_file = same;
-        std::vector<float> im((size_t)num_volumes * 16, 0.0f);
-        for (int i = 0; i < num_volumes; ++i) std::memcpy(&im[(size_t)i * 16], dv[i].m, sizeof(float) * 12);
+        // one 64-byte matrix slot per LEAF-LIST ENTRY (not per instance): the tracer then reads a candidate's matrix
+        // at the list position itself instead of through the index stored there (one dependent load less per candidate)
+        std::vector<float> im(std::max<size_t>(indices.size(), 1) * 16, 0.0f);
+        for (size_t q = 0; q < indices.size(); ++q) std::memcpy(&im[q * 16], dv[indices[q]].m, sizeof(float) * 12);
         (void)hipFree(ctx->d_insts); ctx->d_insts = nullptr;
         HIPCHK(ctx, hipMalloc(&ctx->d_insts, im.size() * sizeof(float)));
         HIPCHK(ctx, hipMemcpy(ctx->d_insts, im.data(), im.size() * sizeof(float), hipMemcpyHostToDevice));

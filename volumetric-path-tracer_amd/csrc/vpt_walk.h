@@ -84,12 +84,16 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
     }
     const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
     if (P.single_file) {
-        // instances of one file: 48-byte matrix per instance, the rest from vol0 (SGPRs)
+        // instances of one file: 48-byte matrix per list entry, the rest from vol0 (SGPRs)
         typedef float __attribute__((ext_vector_type(4))) v4;
         const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
+        // insts[] is in leaf-list order (vpt_scene_set_volumes): entry q's matrix sits at q, no index to chase, and the
+        // next entry's matrix is requested before the current one is used, so its latency overlaps the transform / fetch
+        v4 n0, n1, n2;
+        if (b < e) { n0 = ip[b * 4u]; n1 = ip[b * 4u + 1u]; n2 = ip[b * 4u + 2u]; }
         for (uint32_t q = b; q < e; ++q) {
-            const uint32_t vi = P.leaf_indices[q] * 4u;
-            const v4 r0 = ip[vi], r1 = ip[vi + 1u], r2 = ip[vi + 2u];
+            const v4 r0 = n0, r1 = n1, r2 = n2;
+            if (q + 1u < e) { const uint32_t vi = (q + 1u) * 4u; n0 = ip[vi]; n1 = ip[vi + 1u]; n2 = ip[vi + 2u]; }
             const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
             f(m, P.vol0);
         }
