@@ -105,6 +105,7 @@ struct TraceParams {
     const uint32_t* queue_count;     // == queue_tail, read by the tracer
     Record* records;                 // [iter_count][n_pixels]
     float4* heads;                   // [iter_count][n_pixels] 16-byte sample heads, or NULL (see ResolveParams)
+    float4* head_org;                // ray origins of the heads when lens_radius != 0, else NULL (origin = camera)
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
     Counters* prof;                  // section cycle counters of -DVPT_PROFILE_SECTIONS builds (else unused)
@@ -175,6 +176,7 @@ struct ResolveParams {
     // w == -1: see records[]; w == -2: not rendered (value WHITE).  Cuts the record stream from 64 to
     // ~42 B per sample.
     const float4* heads;
+    const float4* head_org;          // origin of a head's ray when the lens is open (thin-lens offset), else NULL: cam_origin
     float cam_origin[3];
     float* accum;          // float3[n_pixels]
     float* cost;           // float3[n_pixels] or NULL

@@ -77,6 +77,8 @@ struct vpt_ctx {
     // scratch
     Record* d_records = nullptr;
     float4* d_heads = nullptr;             // 16-byte sample heads, same capacity as d_records
+    float4* d_head_org = nullptr;          // ray origins of the heads (thin lens: lens_radius != 0), allocated on first use
+    size_t head_org_capacity = 0;
     size_t records_capacity = 0;           // in records
     float2* d_bn_table = nullptr;
     size_t bn_capacity = 0;                // in iterations
@@ -276,6 +278,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_leaf_indices);
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_heads);
+    (void)hipFree(ctx->d_head_org);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
@@ -838,11 +841,23 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         ctx->bn_capacity = chunk;
     }
     P.records = ctx->d_records;
-    // compact sample heads: valid when every primary ray starts exactly at the camera origin
-    // (camera.h:131-136 with lens_radius == 0: offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0)
-    const bool compact = cam->lens_radius == 0.0f && !std::getenv("VPT_NO_HEADS");
+    // compact sample heads: a sample whose primary ray starts no walk needs its direction and depth only -- plus its
+    // origin when the lens is open; with lens_radius == 0 every primary ray starts exactly at the camera origin
+    // (camera.h:131-136: offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0)
+    const bool compact = !std::getenv("VPT_NO_HEADS");
     P.heads = compact ? ctx->d_heads : nullptr;
+    P.head_org = nullptr;
+    if (compact && cam->lens_radius != 0.0f) {
+        if (ctx->head_org_capacity < ctx->records_capacity) {
+            HIPCHK(ctx, hipStreamSynchronize(stream));
+            (void)hipFree(ctx->d_head_org); ctx->d_head_org = nullptr; ctx->head_org_capacity = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_head_org, ctx->records_capacity * sizeof(float4)));
+            ctx->head_org_capacity = ctx->records_capacity;
+        }
+        P.head_org = ctx->d_head_org;
+    }
     R.heads = P.heads;
+    R.head_org = P.head_org;
     R.cam_origin[0] = cam->origin.x; R.cam_origin[1] = cam->origin.y; R.cam_origin[2] = cam->origin.z;
     P.queue = ctx->d_queue;
     P.queue_tail = ctx->d_work_counter + 8;

@@ -60,7 +60,12 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
                 q0 = make_float4(l, l, l, 0.0f);
                 q1 = make_float4(b, b, b, rendered ? h.w : 0.0f);
-                q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(rendered ? 1u : 0u));
+                if (R.head_org) {
+                    const float4 o = R.head_org[slot];
+                    q2 = make_float4(o.x, o.y, o.z, __uint_as_float(rendered ? 1u : 0u));
+                } else {
+                    q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(rendered ? 1u : 0u));
+                }
                 q3 = make_float4(h.x, h.y, h.z, 0.0f);
                 from_record = false;
             }

@@ -153,9 +153,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                 enqueue = true;
             }
             if (P.heads) {
-                // compact stream (lens_radius == 0: org0 is the camera origin for every sample): a sample
-                // that starts no walk is fully described by its 16-byte head
+                // compact stream: a sample that starts no walk is fully described by its 16-byte head {dir0, depth} --
+                // plus its origin when the lens is open (lens_radius == 0: org0 is the camera origin for every sample)
                 P.heads[s] = make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f));
+                if (P.head_org && !traced) P.head_org[s] = make_float4(org0.x, org0.y, org0.z, 0.0f);
                 if (traced) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3; }
             } else {
                 dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
