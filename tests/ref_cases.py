@@ -130,6 +130,14 @@ def _xform_soup():
     return sd
 
 
+def _cloud_vol_dof():
+    """vol_integrator behind an open lens (untraced samples carry their own origin)"""
+    sd = S.cloud_scene(48, 32, shape=(38, 22, 32), env=(64, 32), integrator=1)
+    vols = [v for v, _, _, _ in sd.volumes]
+    sd.camera, _, _ = S.frame_camera(pkg.host.load_library(), vols, 48, 32, aperture=4.0)
+    return sd
+
+
 # name -> (scene factory, iterations)
 CASES = {
     "dragon_point_light": (_dragon("c1"), 3),                       # point-light NEE, direct_integrator
@@ -150,6 +158,7 @@ CASES = {
     "fireball_vol_emission_sphere": (_vol_emission_sphere, 2),
     "dragon_multi_bounce_back_scatter": (_multi_bounce, 2),
     "dragon_xform_parameter_soup": (_xform_soup, 2),
+    "cloud_vol_hdri_open_lens": (_cloud_vol_dof, 2),
 }
 
 BUFFERS = ("accum", "depth", "raw", "display", "blue_noise")
