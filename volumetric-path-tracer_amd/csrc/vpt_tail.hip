@@ -46,14 +46,19 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
     const Sky<ResolveParams> sky = {R};
 
+    // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
+    const uint32_t local_it0 = R.iter_begin / R.iter_stride;
+    // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
+    float4 h_next = R.heads ? R.heads[idx] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
-        const uint32_t local_it = iteration / R.iter_stride;
+        const uint32_t local_it = local_it0 + k;
         const size_t slot = (size_t)k * R.n_pixels + idx;
         float4 q0, q1, q2, q3;
         bool from_record = true;
         if (R.heads) {
-            const float4 h = R.heads[slot];
+            const float4 h = h_next;
+            if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
             if (h.w != -1.0f) {
                 // no 64-byte record: a primary ray that started no walk (or a sample that is not rendered)
                 const bool rendered = h.w >= 0.0f;
