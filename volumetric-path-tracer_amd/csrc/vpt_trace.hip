@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         // resolved right here instead of costing a pass of the walk loop.
                         f3 nmin, nmax;
                         int leaf;
-                        phase = locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE ? PH_T_TRACK_DONE : PH_W_TRACK;
+                        const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
+                        phase = locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE ? PH_T_TRACK_DONE : PH_W_TRACK;
                     } else if (gco_obj == 0) {
                         // nothing ahead: the second get_closest_object (:1806) sees the same ray, so
                         // this and every later iteration is a no-op -> finish (exact)

@@ -120,7 +120,8 @@ VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min)
 //   z: low half for i < 4, high half otherwise
 // and the first child (index order) whose CLOSED box contains p wins.
 enum { LOC_LEAF = 0, LOC_EMPTY = 1, LOC_OUTSIDE = 2 };
-VPT_D int locate(const TraceParams& P, const uint32_t* occ, f3 p, f3& nmin, f3& nmax, int& leaf) {
+struct OccTop { uint32_t w0, w1, w2; };          // occupancy words of octree levels 1 and 2 (occ[0..2])
+VPT_D int locate(const TraceParams& P, const uint32_t* occ, const OccTop& o, f3 p, f3& nmin, f3& nmax, int& leaf) {
     f3 lo = ld3(P.root_pmin), hi = ld3(P.root_pmax);
     // The eight children tile their parent's closed box, so "the first child whose closed box contains p" needs a
     // containment test only once, against the root (the union of its children); below that, one comparison per axis
@@ -141,8 +142,12 @@ VPT_D int locate(const TraceParams& P, const uint32_t* occ, f3 p, f3& nmin, f3& 
         lo.y = yh ? hy : lo.y; hi.y = yh ? hi.y : hy;
         lo.z = zh ? hz : lo.z; hi.z = zh ? hi.z : hz;
         path = path * 8 + c;
-        const int bit = (level == 0 ? 0 : (level == 1 ? 32 : 96)) + path;
-        if (((occ[bit >> 5] >> (bit & 31)) & 1u) == 0) {
+        // occupancy bit of the node: level 1 and 2 words (8 + 64 bits) come in registers, level 3 (512 bits) from LDS
+        uint32_t word;
+        if (level == 0) word = o.w0;
+        else if (level == 1) word = path < 32 ? o.w1 : o.w2;
+        else word = occ[(96 + path) >> 5];
+        if (((word >> (path & 31)) & 1u) == 0) {
             nmin = lo;
             nmax = hi;
             return LOC_EMPTY;

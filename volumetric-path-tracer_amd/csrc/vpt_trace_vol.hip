@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                     // W_TRACK walks (retry), as a new walk after the fused first one
                     f3 nmin, nmax;
                     int leaf;
-                    if (retry == 0 || locate(P, s_occ, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
+                    const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
+                    if (retry == 0 || locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
                         phase = VH_T_FINISH;
                     } else {
                         w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);

@@ -126,6 +126,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     // operations is unchanged.
     int leaf = 0;
     int st = LOC_EMPTY;
+    const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
 #ifdef VPT_PROFILE_SECTIONS
     const unsigned long long tp0_ = __builtin_readcyclecounter();
 #endif
@@ -133,7 +134,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
             f3 nmin, nmax;
-            st = locate(P, s_occ, w.pos, nmin, nmax, leaf);
+            st = locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf);
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
                 float t_min, t_max;
