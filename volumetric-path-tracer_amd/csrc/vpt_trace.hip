@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     __shared__ float s_hist[VPT_HIST_CAP * 256];      // [entry][thread]: densities seen by the fused first walk
     __shared__ float s_park[30 * 256];                // [field][thread]: path-level state parked in LDS
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
+    if (EMIT) stage_emission_lut(P);
     __syncthreads();
 
     const uint32_t total = *P.queue_count;          // rays that entered the volume box / hit the sphere
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         VPT_TICK(tc1);
         if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const int kind = phase <= PH_W_TRACK ? WALK_SAMPLE : (phase == PH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;

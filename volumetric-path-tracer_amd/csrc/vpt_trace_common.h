@@ -291,8 +291,17 @@ VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t, bool
     return xyz(lerp4(lerp4(c00, c10, t.ay), lerp4(c01, c11, t.ay), t.az));
 }
 
+// The 256-entry blackbody table (kernel_params.emission_texture) of the emission march, copied to LDS by the kernels
+// that can emit and have the LDS to spare (template ELDS: the direct tracer): its three dwords are read right after the emission texel they depend on, at every
+// step of estimate_emission -- from LDS that is one short round trip instead of a second global one.
+static __shared__ float s_emission_lut[768];
+VPT_D void stage_emission_lut(const TraceParams& P) {
+    if (P.emission_lut)
+        for (uint32_t i = threadIdx.x; i < 768u; i += blockDim.x) s_emission_lut[i] = P.emission_lut[i];
+}
+
 // one volume's contribution at world position p (get_density / get_color / get_emission)
-template <bool COLOR, bool EMIT, bool COUNT>
+template <bool COLOR, bool EMIT, bool COUNT, bool ELDS = false>
 VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
                          float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e, bool count_color = false) {
     f3 u;
@@ -324,8 +333,9 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             if (inside) {
                 float index = fetch_f32(v.emission, v.edim, make_taps(v.edim, u), a24);
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
-                const float* e = P.emission_lut + 3 * (int)index;
-                emission += mk3(e[0], e[1], e[2]) * P.emission_scale;
+                const int e = 3 * (int)index;
+                if (ELDS) emission += mk3(s_emission_lut[e], s_emission_lut[e + 1], s_emission_lut[e + 2]) * P.emission_scale;
+                else emission += mk3(P.emission_lut[e], P.emission_lut[e + 1], P.emission_lut[e + 2]) * P.emission_scale;
             }
         }
     }
