@@ -162,6 +162,21 @@ def test_24_bit_index_arithmetic_is_bit_identical(pkg, monkeypatch, bricks):
     np.testing.assert_array_equal(a.depth.cpu().numpy(), b.depth.cpu().numpy())
 
 
+@pytest.mark.parametrize("aperture", [0.0, 2.0])
+def test_sample_heads_are_bit_identical_to_full_records(pkg, monkeypatch, aperture):
+    """untraced samples travel as 16-byte heads (+ a 16-byte origin when the lens is open) instead of 64-byte records
+    (record stream); VPT_NO_HEADS restores the full records: same bits either way"""
+    sd = pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=aperture)
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.render(3); a.sync()
+    monkeypatch.setenv("VPT_NO_HEADS", "1")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.render(3); b.sync()
+    assert a.accum.abs().max() > 0
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())
+
+
 def test_striped_batches_spanning_chunks(pkg, monkeypatch):
     """iteration striping (stride 3, starting at iteration 1) across several record chunks == one chunk,
     and == the oracle rendering the same stripe"""
