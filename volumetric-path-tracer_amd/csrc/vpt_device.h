@@ -126,6 +126,7 @@ struct TraceParams {
     // SGPRs -- a quarter of the bytes the texture-data path has to return per instance visited
     const float4* insts;             // [leaf-list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
     int single_file;
+    int addr24;                      // every volume has DVolume::addr24: the tracer's A24 instantiation is launched
     DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs
     // reference sphere
     float sph_center[3];

@@ -753,6 +753,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.vol0 = ctx->host_dvolumes[0];
     P.insts = ctx->d_insts;
     P.single_file = ctx->single_file ? 1 : 0;
+    P.addr24 = 1;
+    for (const DVolume& hv : ctx->host_dvolumes) P.addr24 &= hv.addr24;
     st3(P.sph_center, ref_sphere->center); P.sph_radius = ref_sphere->radius;
     st3(P.sph_color, ref_sphere->color); P.sph_roughness = ref_sphere->roughness;
     P.num_lights = (int)lights->num_lights;

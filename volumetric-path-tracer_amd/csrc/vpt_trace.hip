@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
 #ifndef VPT_TRACE_WAVES_PER_EU
 #define VPT_TRACE_WAVES_PER_EU 3
 #endif
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT>
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool A24>
 __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[VPT_HIST_CAP * 256];      // [entry][thread]: densities seen by the fused first walk
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         VPT_TICK(tc1);
         if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const int kind = phase <= PH_W_TRACK ? WALK_SAMPLE : (phase == PH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;
@@ -584,8 +584,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 // ---- launcher -------------------------------------------------------------------------------
 template <bool MULTI, bool COLOR, bool EMIT>
 static hipError_t launch_variant(const TraceParams& P, int blocks, hipStream_t stream) {
-    if (P.counters) hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, true>), dim3(blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, false>), dim3(blocks), dim3(256), 0, stream, P);
+    // A24: every volume's texel indices fit the 24-bit multiplier (vpt_scene_set_volumes), see imul
+    if (P.addr24) {
+        if (P.counters) hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, true, true>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, false, true>), dim3(blocks), dim3(256), 0, stream, P);
+    } else {
+        if (P.counters) hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, true, false>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<MULTI, COLOR, EMIT, false, false>), dim3(blocks), dim3(256), 0, stream, P);
+    }
     return hipGetLastError();
 }
 

@@ -208,8 +208,9 @@ VPT_D f4 ld_g4(gptr_f4 g, uint32_t i) { const v4f v = g[i]; return mk4(v.x, v.y,
 
 // Texel index arithmetic.  32-bit integer multiplies issue at a quarter of the rate of the 24-bit ones on CDNA; the
 // host sets DVolume::addr24 when every product below has operands under 2^24 and a result under 2^32 (true for any
-// grid whose y*z slice count and x extent are below 16.7 M: config 4's 1024x704x1216 included), else the 32-bit path runs.
-VPT_D uint32_t imul(bool a24, uint32_t a, uint32_t b) { return a24 ? __umul24(a, b) : a * b; }
+// grid whose y*z slice count and x extent are below 16.7 M: config 4's 1024x704x1216 included); when that holds for
+// every volume of the scene the A24 instantiation of the tracer is launched, else the 32-bit one.
+template <bool A24> VPT_D uint32_t imul(uint32_t a, uint32_t b) { return A24 ? __umul24(a, b) : a * b; }
 
 struct Taps {
     int i0, i1, j0, j1, k0, k1;
@@ -235,14 +236,15 @@ VPT_D Taps make_taps(const int* dim, f3 u) {
 }
 // trilinear f32 fetch: CUDA "linear, normalised, clamp" addressing, fp32 weights, nested
 // lerp x -> y -> z with lerp(a,b,t) = a + t*(b-a)
-VPT_D float fetch_f32(const float* __restrict__ g_, const int* dim, const Taps& t, bool a24) {
+template <bool A24>
+VPT_D float fetch_f32(const float* __restrict__ g_, const int* dim, const Taps& t) {
     const gptr_f g = (gptr_f)g_;
     const uint32_t dx = (uint32_t)dim[0];
-    const uint32_t s0 = imul(a24, (uint32_t)t.k0, (uint32_t)dim[1]), s1 = imul(a24, (uint32_t)t.k1, (uint32_t)dim[1]);
-    const uint32_t r00 = imul(a24, s0 + (uint32_t)t.j0, dx);
-    const uint32_t r10 = imul(a24, s0 + (uint32_t)t.j1, dx);
-    const uint32_t r01 = imul(a24, s1 + (uint32_t)t.j0, dx);
-    const uint32_t r11 = imul(a24, s1 + (uint32_t)t.j1, dx);
+    const uint32_t s0 = imul<A24>((uint32_t)t.k0, (uint32_t)dim[1]), s1 = imul<A24>((uint32_t)t.k1, (uint32_t)dim[1]);
+    const uint32_t r00 = imul<A24>(s0 + (uint32_t)t.j0, dx);
+    const uint32_t r10 = imul<A24>(s0 + (uint32_t)t.j1, dx);
+    const uint32_t r01 = imul<A24>(s1 + (uint32_t)t.j0, dx);
+    const uint32_t r11 = imul<A24>(s1 + (uint32_t)t.j1, dx);
     const float c000 = g[r00 + t.i0], c100 = g[r00 + t.i1];
     const float c010 = g[r10 + t.i0], c110 = g[r10 + t.i1];
     const float c001 = g[r01 + t.i0], c101 = g[r01 + t.i1];
@@ -257,12 +259,13 @@ VPT_D float fetch_f32(const float* __restrict__ g_, const int* dim, const Taps& 
 }
 // same trilinear fetch from the bricked layout (vpt_device.h): texel (i, j, k) lives at
 //   (((k>>2) * by + (j>>2)) * bx + (i>>2)) * 64 + (k&3) * 16 + (j&3) * 4 + (i&3)
-VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, const Taps& t, bool a24) {
+template <bool A24>
+VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, const Taps& t) {
     const gptr_f g = (gptr_f)g_;
     const uint32_t row = (uint32_t)v.bdim[0] * 64u, slab = (uint32_t)v.bdim[1] * row;       // floats per brick row / brick slab
     const uint32_t x0 = (((uint32_t)t.i0 >> 2) << 6) + ((uint32_t)t.i0 & 3u), x1 = (((uint32_t)t.i1 >> 2) << 6) + ((uint32_t)t.i1 & 3u);
-    const uint32_t y0 = imul(a24, (uint32_t)t.j0 >> 2, row) + (((uint32_t)t.j0 & 3u) << 2), y1 = imul(a24, (uint32_t)t.j1 >> 2, row) + (((uint32_t)t.j1 & 3u) << 2);
-    const uint32_t z0 = imul(a24, (uint32_t)t.k0 >> 2, slab) + (((uint32_t)t.k0 & 3u) << 4), z1 = imul(a24, (uint32_t)t.k1 >> 2, slab) + (((uint32_t)t.k1 & 3u) << 4);
+    const uint32_t y0 = imul<A24>((uint32_t)t.j0 >> 2, row) + (((uint32_t)t.j0 & 3u) << 2), y1 = imul<A24>((uint32_t)t.j1 >> 2, row) + (((uint32_t)t.j1 & 3u) << 2);
+    const uint32_t z0 = imul<A24>((uint32_t)t.k0 >> 2, slab) + (((uint32_t)t.k0 & 3u) << 4), z1 = imul<A24>((uint32_t)t.k1 >> 2, slab) + (((uint32_t)t.k1 & 3u) << 4);
     const float c000 = g[z0 + y0 + x0], c100 = g[z0 + y0 + x1];
     const float c010 = g[z0 + y1 + x0], c110 = g[z0 + y1 + x1];
     const float c001 = g[z1 + y0 + x0], c101 = g[z1 + y0 + x1];
@@ -276,14 +279,15 @@ VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, co
     return c0 + (c1 - c0) * t.az;
 }
 VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
-VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t, bool a24) {
+template <bool A24>
+VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t) {
     const gptr_f4 g = (gptr_f4)g_;
     const uint32_t dx = (uint32_t)dim[0];
-    const uint32_t s0 = imul(a24, (uint32_t)t.k0, (uint32_t)dim[1]), s1 = imul(a24, (uint32_t)t.k1, (uint32_t)dim[1]);
-    const uint32_t r00 = imul(a24, s0 + (uint32_t)t.j0, dx);
-    const uint32_t r10 = imul(a24, s0 + (uint32_t)t.j1, dx);
-    const uint32_t r01 = imul(a24, s1 + (uint32_t)t.j0, dx);
-    const uint32_t r11 = imul(a24, s1 + (uint32_t)t.j1, dx);
+    const uint32_t s0 = imul<A24>((uint32_t)t.k0, (uint32_t)dim[1]), s1 = imul<A24>((uint32_t)t.k1, (uint32_t)dim[1]);
+    const uint32_t r00 = imul<A24>(s0 + (uint32_t)t.j0, dx);
+    const uint32_t r10 = imul<A24>(s0 + (uint32_t)t.j1, dx);
+    const uint32_t r01 = imul<A24>(s1 + (uint32_t)t.j0, dx);
+    const uint32_t r11 = imul<A24>(s1 + (uint32_t)t.j1, dx);
     const f4 c00 = lerp4(ld_g4(g, r00 + t.i0), ld_g4(g, r00 + t.i1), t.ax);
     const f4 c10 = lerp4(ld_g4(g, r10 + t.i0), ld_g4(g, r10 + t.i1), t.ax);
     const f4 c01 = lerp4(ld_g4(g, r01 + t.i0), ld_g4(g, r01 + t.i1), t.ax);
@@ -301,12 +305,11 @@ VPT_D void stage_emission_lut(const TraceParams& P) {
 }
 
 // one volume's contribution at world position p (get_density / get_color / get_emission)
-template <bool COLOR, bool EMIT, bool COUNT, bool ELDS = false>
+template <bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24>
 VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
                          float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e, bool count_color = false) {
     f3 u;
     const bool inside = to_unit(m, v, p, u);
-    const bool a24 = v.addr24 != 0;
     // every texture object has its own extent (the reference densifies each grid over its own
     // active bbox, gpu_vdb.cpp:179,262,343) but is addressed with the density grid's normalised
     // coordinates
@@ -314,7 +317,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (COUNT) n_d++;
         if (inside) {
             const Taps t = make_taps(v.dim, u);
-            density += v.bricked ? fetch_f32_bricked(v.density, v, t, a24) : fetch_f32(v.density, v.dim, t, a24);
+            density += v.bricked ? fetch_f32_bricked<A24>(v.density, v, t) : fetch_f32<A24>(v.density, v.dim, t);
         }
     }
     if (COLOR && COUNT && count_color && v.has_color) n_c++;      // the reference looks the colour up here (see walk_step)
@@ -323,7 +326,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             color = fmax3(color, mk3(1.0f));
         } else {
             if (COUNT) n_c++;
-            f3 c = inside ? fetch_f4(v.color, v.cdim, make_taps(v.cdim, u), a24) : mk3(0.0f);
+            f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, u)) : mk3(0.0f);
             color = fmax3(color, c);
         }
     }
@@ -331,7 +334,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (v.has_emission) {
             if (COUNT) n_e++;
             if (inside) {
-                float index = fetch_f32(v.emission, v.edim, make_taps(v.edim, u), a24);
+                float index = fetch_f32<A24>(v.emission, v.edim, make_taps(v.edim, u));
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
                 const int e = 3 * (int)index;
                 if (ELDS) emission += mk3(s_emission_lut[e], s_emission_lut[e + 1], s_emission_lut[e + 2]) * P.emission_scale;

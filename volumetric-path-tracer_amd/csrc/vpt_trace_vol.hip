@@ -147,7 +147,7 @@ VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
     return mk3(o[0], o[1], o[2]);
 }
 
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT>
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT, bool A24>
 __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) {
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[VPT_HIST_CAP * 256];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
         rng_top_up(rng, pixel);
         if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
             const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
                                                                    retry, phase == VH_W_TRACK);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
@@ -521,8 +521,13 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
 
 template <bool GENERIC, bool SKYLUT>
 static hipError_t launch_vol_variant(const TraceParams& P, int blocks, hipStream_t stream) {
-    if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, true, SKYLUT>), dim3(blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, false, SKYLUT>), dim3(blocks), dim3(256), 0, stream, P);
+    if (P.addr24) {              // every volume's texel indices fit the 24-bit multiplier, see imul
+        if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, true, SKYLUT, true>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, false, SKYLUT, true>), dim3(blocks), dim3(256), 0, stream, P);
+    } else {
+        if (P.counters) hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, true, SKYLUT, false>), dim3(blocks), dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((trace_vol_kernel<GENERIC, GENERIC, GENERIC, false, SKYLUT, false>), dim3(blocks), dim3(256), 0, stream, P);
+    }
     return hipGetLastError();
 }
 

@@ -113,7 +113,7 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
 // same exit distance and sphere test and differs only in its exponential draw, so it is replayed
 // right here (one draw + one log per retry, as many as the buffered Philox words allow) instead of costing
 // a pass of the walk loop each.
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS = false>
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24>
 VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                      float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
                      int& retries, bool use_retries) {
@@ -196,7 +196,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     // collision (:1673): it is counted here and FETCHED there (8 float4 texels per instance -- most of
     // what the texture-data path returned per step in instanced scenes).
     for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {
-        lookup_volume<COLOR, EMIT, COUNT, ELDS>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
+        lookup_volume<COLOR, EMIT, COUNT, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
     });
     if (is_sample) {
         // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
@@ -212,7 +212,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
                 float dz = 0.0f;
                 f3 ez = mk3(0.0f);
                 for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {       // sum_color :931 (component-wise max)
-                    lookup_volume<COLOR, false, false>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
+                    lookup_volume<COLOR, false, false, false, A24>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
                 });
             }
             const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
