@@ -9,7 +9,7 @@
  * source/render_kernel.cu (+ source/bvh/octree.cpp) compiled unmodified for the CPU where it lies
  * (recipe: `make -C oracle ref`, stand-in CUDA headers in oracle/ref_shim/), and
  * tests/test_oracle_vs_ref.py requires orc_render's buffers to equal that library's BIT FOR BIT on
- * 19 scenes covering both integrators, point light / sun / sky / HDRI, emission, colour grids, 16
+ * 23 scenes covering both integrators, point light / sun / sky / HDRI, emission, colour grids, 16
  * instances, thin lens + viz_dof, the sphere bounce, volume_depth 3, max_interactions and render=false -- live where the library
  * exists, and against tests/golden/ref_golden.npz (written from it) everywhere else.  Inside that
  * library only the texture fetch and the Philox block function are this oracle's; they are pinned on

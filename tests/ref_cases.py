@@ -4,6 +4,8 @@ Shared by tests/test_oracle_vs_ref.py (live comparison where oracle/_ref/libvptr
 tests/golden/make_ref_golden.py (writes tests/golden/ref_golden.npz from the compiled reference, so that the pin also
 holds where /root/reference does not exist).  Every case covers a different part of volume_rt_kernel:
 """
+import ctypes as C
+
 import numpy as np
 
 from oracle_binding import pkg
@@ -138,6 +140,63 @@ def _cloud_vol_dof():
     return sd
 
 
+def _camera(sd, lookfrom, lookat, fov, w, h):
+    cam = pkg.abi.Camera()
+    lib = pkg.host.load_library()
+    lib.vpt_camera_default(C.byref(cam))
+    lib.vpt_camera_update(C.byref(cam), S.Float3(*lookfrom), S.Float3(*lookat), S.Float3(0, 1, 0), fov, float(w) / float(h), 0.0)
+    sd.camera = cam
+
+
+def _camera_inside():
+    """camera INSIDE the root box: AABB::Intersect's "origin inside => tmin := tmax" rule moves every primary ray to the
+    box's far side before the first walk, so the reference renders the background only (a quirk worth pinning)"""
+    sd = S.dragon_scene(48, 32, "c2")
+    _camera(sd, (5.0, 2.5, 5.0), (4.0, 2.0, 4.6), 70.0, 48, 32)
+    return sd
+
+
+def _three_point_lights():
+    """close camera, strong forward scattering, three point lights: the light_budget loop runs its 11 Tr walks and adds
+    Le for the last three (estimate_point_light :1445-1475)"""
+    sd = S.dragon_scene(72, 48, "sun")
+    _camera(sd, (10.5, 6.5, 9.0), (5.0, 2.5, 5.0), 45.0, 72, 48)
+    sd.kp.phase_g1 = 0.85
+    sd.kp.density_mult = 6.0
+    sd.kp.ray_depth = 5
+    for k in range(3):
+        pl = S.PointLight()
+        pl.pos = S.f3(np.array([1.0 + 3.0 * k, 6.0 - k, 2.0 + 2.0 * k], np.float32))
+        pl.color = S.Float3(0.3 + 0.3 * k, 1.0, 1.0 - 0.3 * k)
+        pl.power = 25.0
+        sd.lights.append(pl)
+    return sd
+
+
+def _sphere_through_volume():
+    """the reference sphere INTERSECTING the volume: walks that end on the sphere (obj = 2 inside sample()), shadow rays
+    blocked by it, rough bounce"""
+    sd = S.dragon_scene(80, 56, "c2")
+    sd.sphere.center = S.Float3(4.6, 2.2, 4.8)
+    sd.sphere.radius = 0.9
+    sd.sphere.color = S.Float3(0.9, 0.4, 0.3)
+    sd.sphere.roughness = 0.85
+    sd.kp.density_mult = 3.0
+    return sd
+
+
+def _thin_and_extreme():
+    """energy_inject 0 (beta turns black: isBlack break), tr_depth 3, exposure 0.2, ray_depth 1, nearly empty medium"""
+    sd = S.dragon_scene(64, 40, "c2")
+    sd.kp.energy_inject = 0.0
+    sd.kp.tr_depth = 3.0
+    sd.kp.exposure_scale = 0.2
+    sd.kp.ray_depth = 1
+    sd.kp.density_mult = 0.25
+    sd.kp.phase_g1 = -0.95
+    return sd
+
+
 # name -> (scene factory, iterations)
 CASES = {
     "dragon_point_light": (_dragon("c1"), 3),                       # point-light NEE, direct_integrator
@@ -159,6 +218,10 @@ CASES = {
     "dragon_multi_bounce_back_scatter": (_multi_bounce, 2),
     "dragon_xform_parameter_soup": (_xform_soup, 2),
     "cloud_vol_hdri_open_lens": (_cloud_vol_dof, 2),
+    "dragon_camera_inside_root_box": (_camera_inside, 2),
+    "dragon_three_point_lights_forward": (_three_point_lights, 2),
+    "dragon_sphere_through_volume": (_sphere_through_volume, 3),
+    "dragon_black_beta_extremes": (_thin_and_extreme, 2),
 }
 
 BUFFERS = ("accum", "depth", "raw", "display", "blue_noise")

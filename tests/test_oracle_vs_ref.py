@@ -38,7 +38,7 @@ def test_oracle_matches_reference_golden(name):
     assert np.array_equal(_bits(o.depth.reshape(h, w)), _bits(g[name + "/depth"]))
     assert np.array_equal(_bits(o.raw[:, 3].reshape(h, w)), _bits(g[name + "/alpha"]))
     assert np.array_equal(o.display.reshape(h, w), g[name + "/display"])
-    if name != "dragon_no_render":
+    if name not in ("dragon_no_render", "dragon_camera_inside_root_box"):
         assert np.count_nonzero(g[name + "/depth"]) > 50        # the case is not vacuous: rays hit the volume
 
 
