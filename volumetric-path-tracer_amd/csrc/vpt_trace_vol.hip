@@ -283,7 +283,24 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
         // ==== transitions ===================================================================
         const unsigned long long tmask = __ballot(phase >= VH_T_FIRST);
         const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= VH_W_FIRST && phase <= VH_W_LAST));
+        if (COUNT) {                     // schedule statistics (vpt_test_get_schedule), as in trace_kernel
+            const unsigned long long wm = __ballot(phase >= VH_W_FIRST && phase <= VH_W_LAST), im = __ballot(phase == VH_IDLE);
+            if (lane == 0) {
+                atomicAdd(&P.counters->sched[0], 1ull);
+                atomicAdd(&P.counters->sched[1], (unsigned long long)__popcll(wm));
+                atomicAdd(&P.counters->sched[2], (unsigned long long)__popcll(tmask));
+                atomicAdd(&P.counters->sched[3], (unsigned long long)__popcll(im));
+                if (run_trans) atomicAdd(&P.counters->sched[4], 1ull);
+            }
+        }
         while (run_trans && __any(phase >= VH_T_FIRST)) {
+            if (COUNT) {
+                const unsigned long long tm = __ballot(phase >= VH_T_FIRST);
+                if (lane == 0) {
+                    atomicAdd(&P.counters->sched[5], 1ull);
+                    atomicAdd(&P.counters->sched[6], (unsigned long long)__popcll(tm));
+                }
+            }
             rng_top_up(rng, pixel);
             bool drew = false;            // this lane consumed / peeked random numbers in this pass
             bool start_tr = false;
