@@ -616,7 +616,7 @@ int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[12]) {
     return VPT_OK;
 }
 
-// ---- atmosphere packing (indices: enum AF_* in vpt_resolve.hip) -------------------------------------
+// ---- atmosphere packing (indices: enum AF_* in vpt_sky.h) ------------------------------------------
 static void pack_atmosphere(const vpt_atmosphere_parameters* a, float* f) {
     std::memset(f, 0, sizeof(float) * 40);
     f[0] = a->bottom_radius; f[1] = a->top_radius; f[2] = (float)a->use_luminance; f[3] = a->mie_phase_function_g;

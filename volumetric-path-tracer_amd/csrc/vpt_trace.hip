@@ -7,7 +7,7 @@
 // tracking (`Tr` :1138), Henyey-Greenstein scattering (`sample_hg` :306), sun /
 // point-light next-event estimation (:1478, :1445), emission (:1275) and the reference
 // sphere bounce (:1807-1834).  The environment tail, accumulation and tonemap live in
-// vpt_resolve.hip.
+// vpt_tail.hip (tail_resolve_kernel).
 //
 // How it is organised (nothing like the reference's one-thread-per-pixel megakernel):
 //   * persistent waves; every lane runs a path STATE MACHINE whose heavy state is "do
