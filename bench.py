@@ -190,6 +190,10 @@ def main():
                 launches = -(-spp // ipl)
                 roofline["traffic"] = round(per_sample * samples_per_step_rank / launches / 1e9, 4)
                 roofline["launches_per_step"] = launches
+                vk = (tj.get("valu") or {}).get(kernel_name)
+                if vk:      # what bounds this kernel in practice: vector-instruction issue, at this many active lanes
+                    roofline["valu_issue_busy"] = vk["valu_issue_busy"]
+                    roofline["active_lanes_per_valu_instruction"] = vk["active_lanes_per_valu_instruction"]
                 roofline["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
         cpu = None
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)

@@ -40,5 +40,30 @@ d = json.load(open(out_path)) if os.path.exists(out_path) else {}
 d[cfg] = {"width": w, "height": h, "iterations_per_launch": ipl, "samples_per_launch": w * h * ipl,
           "fetch_size_counter": fetch, "write_size_counter": write, "bytes_per_launch": bytes_per_launch,
           "source": os.path.basename(path)}
+
+# VALU issue utilisation of the three hot kernels from the same file's SQ passes: a wave64 VALU instruction occupies a
+# SIMD for 4 cycles, so busy = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel time x 2.4 GHz); lanes = SQ_THREAD_CYCLES_VALU /
+# SQ_INSTS_VALU (bench.py reports the dominant kernel's pair next to the HBM roofline)
+cur = None
+sq = {}
+for line in txt.splitlines():
+    m = re.match(r"^(\S.*?)\s*\(dispatches: (\d+), avg duration ([\d.]+) us\)", line)
+    if m:
+        cur = (m.group(1), float(m.group(3)))
+        continue
+    m = re.match(r"^\s+(SQ_INSTS_VALU|SQ_THREAD_CYCLES_VALU)\s+\d+\s+per-dispatch\s+([\d.]+)", line)
+    if m and cur:
+        sq.setdefault(cur[0], {})[m.group(1)] = (float(m.group(2)), cur[1])
+valu = {}
+for k, v in sq.items():
+    name = k.split("(")[0].replace("void ", "").split("<")[0].strip()
+    counting = "true>" in k.split("(")[0][-8:]
+    if len(v) == 2 and not counting and name.startswith("vpt::") and v["SQ_INSTS_VALU"][1] > 100.0:
+        n, dur = v["SQ_INSTS_VALU"]
+        valu[name] = {"valu_wave_instructions_per_launch": n, "kernel_us": dur,
+                      "valu_issue_busy": round(n * 4 / (1024 * dur * 1e-6 * 2.4e9), 3),
+                      "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"][0] / n, 1)}
+if valu:
+    d[cfg]["valu"] = valu
 json.dump(d, open(out_path, "w"), indent=1, sort_keys=True)
 print(cfg, "FETCH_SIZE", fetch, "WRITE_SIZE", write, "-> %.3f GB per launch, %.1f B per sample" % (bytes_per_launch / 1e9, bytes_per_launch / (w * h * ipl)))
