@@ -124,7 +124,9 @@ struct TraceParams {
     // textures into every instance and changes only the transform): the per-instance descriptor is then
     // just the 3x4 world->index matrix, 48 bytes in insts[] (stride 64), and everything else is vol0 in
     // SGPRs -- a quarter of the bytes the texture-data path has to return per instance visited
-    const float4* insts;             // [leaf-list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
+    const float4* insts;             // [sub-cell list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
+    const uint32_t* sub_offsets;     // [512 leaves * 64 sub-cells + 1]: CSR of the refined candidate lists (vpt_scene_set_volumes)
+    float sub_inv[3];                // 4 / leaf extent: (p - leaf_lo) * sub_inv -> sub-cell coordinate in [0, 4)
     int single_file;
     int addr24;                      // every volume has DVolume::addr24: the tracer's A24 instantiation is launched
     DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs

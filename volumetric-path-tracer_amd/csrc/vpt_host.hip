@@ -68,6 +68,8 @@ struct vpt_ctx {
     float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
     uint32_t* d_leaf_offsets = nullptr;
     uint32_t* d_leaf_indices = nullptr;
+    uint32_t* d_sub_offsets = nullptr;     // single-file scenes: candidate lists per 4x4x4 sub-cell of every leaf (512 * 64 + 1)
+    float sub_inv[3] = {0.0f, 0.0f, 0.0f}; // 4 / leaf extent per axis
     uint32_t occ[19] = {0};
     Box root = {{0, 0, 0}, {0, 0, 0}};
     float max_ext = 0.0f, min_ext = 0.0f;
@@ -276,6 +278,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_volumes);
     (void)hipFree(ctx->d_leaf_offsets);
     (void)hipFree(ctx->d_leaf_indices);
+    (void)hipFree(ctx->d_sub_offsets);
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_heads);
     (void)hipFree(ctx->d_head_org);
@@ -528,10 +531,41 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             same = std::memcmp(&a, &b, sizeof(DVolume)) == 0;
         }
         ctx->single_file = same;
-        // one 64-byte matrix slot per LEAF-LIST ENTRY (not per instance): the tracer then reads a candidate's matrix
-        // at the list position itself instead of through the index stored there (one dependent load less per candidate)
-        std::vector<float> im(std::max<size_t>(indices.size(), 1) * 16, 0.0f);
-        for (size_t q = 0; q < indices.size(); ++q) std::memcpy(&im[q * 16], dv[indices[q]].m, sizeof(float) * 12);
+        // Candidate lists of the instance loop.  A leaf's list (every instance whose bounds overlap the leaf, as the
+        // reference builds it) is refined per 4x4x4 SUB-CELL of the leaf: an instance that does not contain the look-up
+        // point contributes nothing (get_density returns 0 outside, :997), so visiting only the instances whose bounds
+        // overlap the point's sub-cell gives the same sums, in the same order, with a third of the candidates.  The
+        // sub-cell boxes are grown by 1e-3 of their size, far more than the rounding of the device's cell index and of
+        // the bounds themselves, so every instance that can contain a point of the cell is listed.  One 64-byte matrix
+        // slot per LIST ENTRY, in list order: a candidate's matrix is read at the list position itself.
+        std::vector<uint32_t> sub_offsets(512 * 64 + 1, 0);
+        std::vector<uint32_t> sub_entries;
+        for (int p3 = 0; p3 < 512; ++p3) {
+            const Box b3 = child_box(child_box(child_box(root, p3 >> 6), (p3 >> 3) & 7), p3 & 7);
+            const double w[3] = {(double)b3.hi.x - b3.lo.x, (double)b3.hi.y - b3.lo.y, (double)b3.hi.z - b3.lo.z};
+            for (int c = 0; c < 64; ++c) {
+                if (same && offsets[p3 + 1] != offsets[p3]) {
+                    const int cx = c & 3, cy = (c >> 2) & 3, cz = c >> 4;
+                    const double grow = 1e-3;
+                    const double lo[3] = {b3.lo.x + w[0] * (cx - grow) / 4, b3.lo.y + w[1] * (cy - grow) / 4, b3.lo.z + w[2] * (cz - grow) / 4};
+                    const double hi[3] = {b3.lo.x + w[0] * (cx + 1 + grow) / 4, b3.lo.y + w[1] * (cy + 1 + grow) / 4, b3.lo.z + w[2] * (cz + 1 + grow) / 4};
+                    for (uint32_t q = offsets[p3]; q < offsets[p3 + 1]; ++q) {
+                        const Box& bb = bounds[indices[q]];
+                        if (bb.lo.x <= hi[0] && bb.hi.x >= lo[0] && bb.lo.y <= hi[1] && bb.hi.y >= lo[1] && bb.lo.z <= hi[2] && bb.hi.z >= lo[2])
+                            sub_entries.push_back(indices[q]);
+                    }
+                }
+                sub_offsets[(size_t)p3 * 64 + c + 1] = (uint32_t)sub_entries.size();
+            }
+        }
+        ctx->sub_inv[0] = 32.0f / (root.hi.x - root.lo.x);       // a leaf is 1/8 of the root per axis, a sub-cell 1/32
+        ctx->sub_inv[1] = 32.0f / (root.hi.y - root.lo.y);
+        ctx->sub_inv[2] = 32.0f / (root.hi.z - root.lo.z);
+        (void)hipFree(ctx->d_sub_offsets); ctx->d_sub_offsets = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->d_sub_offsets, sub_offsets.size() * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMemcpy(ctx->d_sub_offsets, sub_offsets.data(), sub_offsets.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<float> im(std::max<size_t>(sub_entries.size(), 1) * 16, 0.0f);
+        for (size_t q = 0; q < sub_entries.size(); ++q) std::memcpy(&im[q * 16], dv[sub_entries[q]].m, sizeof(float) * 12);
         (void)hipFree(ctx->d_insts); ctx->d_insts = nullptr;
         HIPCHK(ctx, hipMalloc(&ctx->d_insts, im.size() * sizeof(float)));
         HIPCHK(ctx, hipMemcpy(ctx->d_insts, im.data(), im.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -752,6 +786,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.volumes = ctx->d_volumes; P.num_volumes = (int)ctx->host_dvolumes.size();
     P.vol0 = ctx->host_dvolumes[0];
     P.insts = ctx->d_insts;
+    P.sub_offsets = ctx->d_sub_offsets;
+    P.sub_inv[0] = ctx->sub_inv[0]; P.sub_inv[1] = ctx->sub_inv[1]; P.sub_inv[2] = ctx->sub_inv[2];
     P.single_file = ctx->single_file ? 1 : 0;
     P.addr24 = 1;
     for (const DVolume& hv : ctx->host_dvolumes) P.addr24 &= hv.addr24;

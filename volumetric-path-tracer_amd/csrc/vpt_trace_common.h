@@ -154,6 +154,8 @@ VPT_D int locate(const TraceParams& P, const uint32_t* occ, const OccTop& o, f3 
         }
     }
     leaf = path;
+    nmin = lo;                 // the leaf's own box (the instance loop refines its candidate list per sub-cell of it)
+    nmax = hi;
     return LOC_LEAF;
 }
 

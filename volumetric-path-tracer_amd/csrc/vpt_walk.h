@@ -76,14 +76,18 @@ struct WalkCounts {
 };
 
 // Calls f(matrix, descriptor) for every instance listed in octree leaf `leaf` (in list order).
+// `cell`: index of the point's 4x4x4 sub-cell inside the leaf (sub_cell below); only the single-file path uses it.
 template <bool MULTI, class F>
-VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
+VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
     if (!MULTI) {
         f(P.vol0.m, P.vol0);
         return;
     }
-    const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
     if (P.single_file) {
+        // refined candidate list of the sub-cell (vpt_scene_set_volumes): a subset of the leaf's list in the same order;
+        // the instances left out cannot contain the point and would add nothing
+        const uint32_t sc = (uint32_t)leaf * 64u + (uint32_t)cell;
+        const uint32_t b = P.sub_offsets[sc], e = P.sub_offsets[sc + 1u];
         // instances of one file: 48-byte matrix per list entry, the rest from vol0 (SGPRs)
         typedef float __attribute__((ext_vector_type(4))) v4;
         const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
@@ -98,11 +102,20 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, F&& f) {
             f(m, P.vol0);
         }
     } else {
+        const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
         for (uint32_t q = b; q < e; ++q) {
             const DVolume& v = P.volumes[P.leaf_indices[q]];
             f(v.m, v);
         }
     }
+}
+// sub-cell of p inside its leaf box [lo, hi]: 4 x 4 x 4, x fastest.  The index may be off by one for a point within
+// rounding of a cell plane; the host lists are built over boxes grown by 1e-3 of a cell, which covers it.
+VPT_D int sub_cell(const TraceParams& P, f3 lo, f3 p) {
+    const int ix = min(max((int)((p.x - lo.x) * P.sub_inv[0]), 0), 3);
+    const int iy = min(max((int)((p.y - lo.y) * P.sub_inv[1]), 0), 3);
+    const int iz = min(max((int)((p.z - lo.z) * P.sub_inv[2]), 0), 3);
+    return (iz * 4 + iy) * 4 + ix;
 }
 
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
@@ -130,10 +143,10 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
 #ifdef VPT_PROFILE_SECTIONS
     const unsigned long long tp0_ = __builtin_readcyclecounter();
 #endif
+    f3 nmin = mk3(0.0f), nmax = mk3(0.0f);       // box of the node found: an empty node's (to push through) or the leaf's
 #pragma unroll 1
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
-            f3 nmin, nmax;
             st = locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf);
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
@@ -195,9 +208,25 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
     // evaluates sum_color here at every step of sample() (:1662), but its value is only used on a real
     // collision (:1673): it is counted here and FETCHED there (8 float4 texels per instance -- most of
     // what the texture-data path returned per step in instanced scenes).
-    for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {
-        lookup_volume<COLOR, EMIT, COUNT, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
-    });
+    // NOTE the reference looks up at the NEW position with the leaf found at the OLD one (:1659-1662); so does this, and
+    // the sub-cell is the new position's inside that leaf's box (clamped: the point may have left the leaf)
+    const bool refined = MULTI && P.single_file;
+    const int cell = refined ? sub_cell(P, nmin, w.pos) : 0;
+    if (refined && COUNT) {
+        // the reference visits (and SURVEY 8d counts) every instance of the LEAF's list, whatever is skipped here
+        const uint32_t n_leaf = P.leaf_offsets[leaf + 1] - P.leaf_offsets[leaf];
+        if (!is_emit) c.n_d += n_leaf;
+        if (COLOR && is_sample && P.vol0.has_color) c.n_c += n_leaf;
+        if (EMIT && is_emit && P.vol0.has_emission) c.n_e += n_leaf;
+        uint32_t z0 = 0, z1 = 0, z2 = 0;
+        for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) {
+            lookup_volume<COLOR, EMIT, false, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, z0, z1, z2, false);
+        });
+    } else {
+        for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) {
+            lookup_volume<COLOR, EMIT, COUNT, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
+        });
+    }
     if (is_sample) {
         // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
         // (one correctly rounded divide by emission_pivot) and fetch are evaluated there.
@@ -211,7 +240,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
                 uint32_t z0 = 0, z1 = 0, z2 = 0;
                 float dz = 0.0f;
                 f3 ez = mk3(0.0f);
-                for_each_instance<MULTI>(P, leaf, [&](const float* m, const DVolume& v) {       // sum_color :931 (component-wise max)
+                for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) { // sum_color :931 (component-wise max)
                     lookup_volume<COLOR, false, false, false, A24>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
                 });
             }
