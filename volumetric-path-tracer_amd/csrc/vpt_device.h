@@ -90,6 +90,11 @@ struct Counters {
     unsigned long long cycles[4];
 };
 
+#ifndef VPT_SUB
+#define VPT_SUB 4            // sub-cells per leaf and axis of the refined candidate lists (host builder and tracer agree on it)
+#endif
+#define VPT_SUB3 (VPT_SUB * VPT_SUB * VPT_SUB)
+
 struct TraceParams {
     // work distribution
     uint32_t width, height, n_pixels;
@@ -125,8 +130,8 @@ struct TraceParams {
     // just the 3x4 world->index matrix, 48 bytes in insts[] (stride 64), and everything else is vol0 in
     // SGPRs -- a quarter of the bytes the texture-data path has to return per instance visited
     const float4* insts;             // [sub-cell list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
-    const uint32_t* sub_offsets;     // [512 leaves * 64 sub-cells + 1]: CSR of the refined candidate lists (vpt_scene_set_volumes)
-    float sub_inv[3];                // 4 / leaf extent: (p - leaf_lo) * sub_inv -> sub-cell coordinate in [0, 4)
+    const uint32_t* sub_offsets;     // [512 leaves * VPT_SUB3 sub-cells + 1]: CSR of the refined candidate lists (vpt_scene_set_volumes)
+    float sub_inv[3];                // VPT_SUB / leaf extent: (p - leaf_lo) * sub_inv -> sub-cell coordinate in [0, VPT_SUB)
     int single_file;
     int addr24;                      // every volume has DVolume::addr24: the tracer's A24 instantiation is launched
     DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs

@@ -68,8 +68,8 @@ struct vpt_ctx {
     float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
     uint32_t* d_leaf_offsets = nullptr;
     uint32_t* d_leaf_indices = nullptr;
-    uint32_t* d_sub_offsets = nullptr;     // single-file scenes: candidate lists per 4x4x4 sub-cell of every leaf (512 * 64 + 1)
-    float sub_inv[3] = {0.0f, 0.0f, 0.0f}; // 4 / leaf extent per axis
+    uint32_t* d_sub_offsets = nullptr;     // single-file scenes: candidate lists per sub-cell of every leaf (512 * VPT_SUB3 + 1)
+    float sub_inv[3] = {0.0f, 0.0f, 0.0f}; // VPT_SUB / leaf extent per axis
     uint32_t occ[19] = {0};
     Box root = {{0, 0, 0}, {0, 0, 0}};
     float max_ext = 0.0f, min_ext = 0.0f;
@@ -532,35 +532,35 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         }
         ctx->single_file = same;
         // Candidate lists of the instance loop.  A leaf's list (every instance whose bounds overlap the leaf, as the
-        // reference builds it) is refined per 4x4x4 SUB-CELL of the leaf: an instance that does not contain the look-up
+        // reference builds it) is refined per SUB-CELL of the leaf (VPT_SUB^3 of them, 4x4x4): an instance that does not contain the look-up
         // point contributes nothing (get_density returns 0 outside, :997), so visiting only the instances whose bounds
         // overlap the point's sub-cell gives the same sums, in the same order, with a third of the candidates.  The
         // sub-cell boxes are grown by 1e-3 of their size, far more than the rounding of the device's cell index and of
         // the bounds themselves, so every instance that can contain a point of the cell is listed.  One 64-byte matrix
         // slot per LIST ENTRY, in list order: a candidate's matrix is read at the list position itself.
-        std::vector<uint32_t> sub_offsets(512 * 64 + 1, 0);
+        std::vector<uint32_t> sub_offsets((size_t)512 * VPT_SUB3 + 1, 0);
         std::vector<uint32_t> sub_entries;
         for (int p3 = 0; p3 < 512; ++p3) {
             const Box b3 = child_box(child_box(child_box(root, p3 >> 6), (p3 >> 3) & 7), p3 & 7);
             const double w[3] = {(double)b3.hi.x - b3.lo.x, (double)b3.hi.y - b3.lo.y, (double)b3.hi.z - b3.lo.z};
-            for (int c = 0; c < 64; ++c) {
+            for (int c = 0; c < VPT_SUB3; ++c) {
                 if (same && offsets[p3 + 1] != offsets[p3]) {
-                    const int cx = c & 3, cy = (c >> 2) & 3, cz = c >> 4;
+                    const int cx = c % VPT_SUB, cy = (c / VPT_SUB) % VPT_SUB, cz = c / (VPT_SUB * VPT_SUB);
                     const double grow = 1e-3;
-                    const double lo[3] = {b3.lo.x + w[0] * (cx - grow) / 4, b3.lo.y + w[1] * (cy - grow) / 4, b3.lo.z + w[2] * (cz - grow) / 4};
-                    const double hi[3] = {b3.lo.x + w[0] * (cx + 1 + grow) / 4, b3.lo.y + w[1] * (cy + 1 + grow) / 4, b3.lo.z + w[2] * (cz + 1 + grow) / 4};
+                    const double lo[3] = {b3.lo.x + w[0] * (cx - grow) / VPT_SUB, b3.lo.y + w[1] * (cy - grow) / VPT_SUB, b3.lo.z + w[2] * (cz - grow) / VPT_SUB};
+                    const double hi[3] = {b3.lo.x + w[0] * (cx + 1 + grow) / VPT_SUB, b3.lo.y + w[1] * (cy + 1 + grow) / VPT_SUB, b3.lo.z + w[2] * (cz + 1 + grow) / VPT_SUB};
                     for (uint32_t q = offsets[p3]; q < offsets[p3 + 1]; ++q) {
                         const Box& bb = bounds[indices[q]];
                         if (bb.lo.x <= hi[0] && bb.hi.x >= lo[0] && bb.lo.y <= hi[1] && bb.hi.y >= lo[1] && bb.lo.z <= hi[2] && bb.hi.z >= lo[2])
                             sub_entries.push_back(indices[q]);
                     }
                 }
-                sub_offsets[(size_t)p3 * 64 + c + 1] = (uint32_t)sub_entries.size();
+                sub_offsets[(size_t)p3 * VPT_SUB3 + c + 1] = (uint32_t)sub_entries.size();
             }
         }
-        ctx->sub_inv[0] = 32.0f / (root.hi.x - root.lo.x);       // a leaf is 1/8 of the root per axis, a sub-cell 1/32
-        ctx->sub_inv[1] = 32.0f / (root.hi.y - root.lo.y);
-        ctx->sub_inv[2] = 32.0f / (root.hi.z - root.lo.z);
+        ctx->sub_inv[0] = (8.0f * VPT_SUB) / (root.hi.x - root.lo.x);       // a leaf is 1/8 of the root per axis
+        ctx->sub_inv[1] = (8.0f * VPT_SUB) / (root.hi.y - root.lo.y);
+        ctx->sub_inv[2] = (8.0f * VPT_SUB) / (root.hi.z - root.lo.z);
         (void)hipFree(ctx->d_sub_offsets); ctx->d_sub_offsets = nullptr;
         HIPCHK(ctx, hipMalloc(&ctx->d_sub_offsets, sub_offsets.size() * sizeof(uint32_t)));
         HIPCHK(ctx, hipMemcpy(ctx->d_sub_offsets, sub_offsets.data(), sub_offsets.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -76,7 +76,7 @@ struct WalkCounts {
 };
 
 // Calls f(matrix, descriptor) for every instance listed in octree leaf `leaf` (in list order).
-// `cell`: index of the point's 4x4x4 sub-cell inside the leaf (sub_cell below); only the single-file path uses it.
+// `cell`: index of the point's sub-cell inside the leaf (sub_cell below); only the single-file path uses it.
 template <bool MULTI, class F>
 VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
     if (!MULTI) {
@@ -86,7 +86,7 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
     if (P.single_file) {
         // refined candidate list of the sub-cell (vpt_scene_set_volumes): a subset of the leaf's list in the same order;
         // the instances left out cannot contain the point and would add nothing
-        const uint32_t sc = (uint32_t)leaf * 64u + (uint32_t)cell;
+        const uint32_t sc = (uint32_t)leaf * (uint32_t)VPT_SUB3 + (uint32_t)cell;
         const uint32_t b = P.sub_offsets[sc], e = P.sub_offsets[sc + 1u];
         // instances of one file: 48-byte matrix per list entry, the rest from vol0 (SGPRs)
         typedef float __attribute__((ext_vector_type(4))) v4;
@@ -109,13 +109,13 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
         }
     }
 }
-// sub-cell of p inside its leaf box [lo, hi]: 4 x 4 x 4, x fastest.  The index may be off by one for a point within
+// sub-cell of p inside its leaf box [lo, hi]: VPT_SUB^3 of them, x fastest.  The index may be off by one for a point within
 // rounding of a cell plane; the host lists are built over boxes grown by 1e-3 of a cell, which covers it.
 VPT_D int sub_cell(const TraceParams& P, f3 lo, f3 p) {
-    const int ix = min(max((int)((p.x - lo.x) * P.sub_inv[0]), 0), 3);
-    const int iy = min(max((int)((p.y - lo.y) * P.sub_inv[1]), 0), 3);
-    const int iz = min(max((int)((p.z - lo.z) * P.sub_inv[2]), 0), 3);
-    return (iz * 4 + iy) * 4 + ix;
+    const int ix = min(max((int)((p.x - lo.x) * P.sub_inv[0]), 0), VPT_SUB - 1);
+    const int iy = min(max((int)((p.y - lo.y) * P.sub_inv[1]), 0), VPT_SUB - 1);
+    const int iz = min(max((int)((p.z - lo.z) * P.sub_inv[2]), 0), VPT_SUB - 1);
+    return (iz * VPT_SUB + iy) * VPT_SUB + ix;
 }
 
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
