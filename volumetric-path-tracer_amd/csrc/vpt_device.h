@@ -132,6 +132,7 @@ struct TraceParams {
     const float4* insts;             // [sub-cell list entry][4]: matrix rows of that entry's instance, {0,0,0,0}
     const uint32_t* sub_offsets;     // [512 leaves * VPT_SUB3 sub-cells + 1]: CSR of the refined candidate lists (vpt_scene_set_volumes)
     float sub_inv[3];                // VPT_SUB / leaf extent: (p - leaf_lo) * sub_inv -> sub-cell coordinate in [0, VPT_SUB)
+    int octree_full_single;          // one volume and no empty octree node: point location is the root test alone
     int single_file;
     int addr24;                      // every volume has DVolume::addr24: the tracer's A24 instantiation is launched
     DVolume vol0;                    // copy of volumes[0]: single-volume fast path reads it from SGPRs

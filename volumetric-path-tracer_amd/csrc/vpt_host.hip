@@ -789,6 +789,11 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.sub_offsets = ctx->d_sub_offsets;
     P.sub_inv[0] = ctx->sub_inv[0]; P.sub_inv[1] = ctx->sub_inv[1]; P.sub_inv[2] = ctx->sub_inv[2];
     P.single_file = ctx->single_file ? 1 : 0;
+    {
+        bool full = ctx->host_dvolumes.size() == 1 && (ctx->occ[0] & 0xFFu) == 0xFFu;
+        for (int i = 1; i < 19 && full; ++i) full = ctx->occ[i] == 0xFFFFFFFFu;
+        P.octree_full_single = full ? 1 : 0;
+    }
     P.addr24 = 1;
     for (const DVolume& hv : ctx->host_dvolumes) P.addr24 &= hv.addr24;
     st3(P.sph_center, ref_sphere->center); P.sph_radius = ref_sphere->radius;
@@ -949,6 +954,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
+        // the root-only point location is for instantiations that ignore the leaf index (MULTI = false): the direct tracer
+        // with one volume, the vol tracer's non-generic variant
+        const bool kernel_multi = kp->integrator != 0 ? (multi || color || emit) : multi;
+        if (kernel_multi) P.octree_full_single = 0;
         if (kp->integrator != 0) HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
         else HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));

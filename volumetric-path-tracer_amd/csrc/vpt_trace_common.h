@@ -128,6 +128,14 @@ VPT_D int locate(const TraceParams& P, const uint32_t* occ, const OccTop& o, f3 
     // and level picks the half.  A point ON a splitting plane lies in both halves and the lower child index wins:
     // the low half in x and z, the HIGH half in y (children 0,1,4,5).  NaN positions fail the root test.
     if (!(p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z)) return LOC_OUTSIDE;
+    // One volume whose bounds touch every leaf (a dense grid: configs 3 and 4): no node is empty and the single-volume
+    // look-up does not use the leaf index, so "inside the root" is the whole answer.
+    if (P.octree_full_single) {
+        leaf = 0;
+        nmin = lo;
+        nmax = hi;
+        return LOC_LEAF;
+    }
     int path = 0;
 #pragma unroll
     for (int level = 0; level < 3; ++level) {
