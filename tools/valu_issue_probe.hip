@@ -1,0 +1,296 @@
+// valu_issue_probe.hip -- how many shader cycles does ONE wave64 vector instruction occupy a gfx950 SIMD's issue port?
+//
+// DESIGN.md section 4 prices the tracer kernels' "VALU issue busy" figure with a cycles-per-wave-instruction constant.
+// This probe measures that constant per instruction class instead of assuming it:
+//   * every wave runs REPS x UNROLL instances of one instruction on CHAINS independent register chains (so the
+//     dependent-issue latency does not limit a single wave more than necessary), bracketed by s_memtime;
+//   * W waves per SIMD (W = 1, 2, 4, 8; block = 256 threads = one wave per SIMD, W blocks per CU, one CU's worth of
+//     blocks per CU so every SIMD holds exactly W waves);
+//   * reported: cycles per wave-instruction per SIMD = (max over waves of the s_memtime span) / (instructions per
+//     wave x W), i.e. the reciprocal issue throughput of the SIMD once it has W waves to choose from.
+// Also run with a partial EXEC mask (lanes 0-31 only, lanes 0-15 only, every other lane): does the hardware skip the
+// idle half of a wave?  (It decides whether compacting walkers to the low lanes could pay.)
+//
+// Build + run (GPU box):  hipcc --offload-arch=gfx950 -O2 tools/valu_issue_probe.hip -o /tmp/valu_probe && /tmp/valu_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int REPS = 2000;
+constexpr int UNROLL = 32;       // instructions per loop body (8 chains x 4)
+
+// one body = 32 instructions over 8 independent chains; `dep` variants use a single chain
+#define BODY8(OP)                                                                                                     \
+    asm volatile(".rept 4\n" OP("0") OP("1") OP("2") OP("3") OP("4") OP("5") OP("6") OP("7") ".endr\n"                 \
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)                      \
+                 : "v"(a), "v"(b), "s"(sa));
+#define BODY1(OP) asm volatile(".rept 32\n" OP("0") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa));
+
+#define OP_FMA(i) "v_fma_f32 %" i ", %" i ", %8, %9\n"
+#define OP_ADDF(i) "v_add_f32 %" i ", %" i ", %8\n"
+#define OP_MULF(i) "v_mul_f32 %" i ", %" i ", %8\n"
+#define OP_MAXF(i) "v_max_f32 %" i ", %" i ", %8\n"
+#define OP_ADDU(i) "v_add_u32 %" i ", %" i ", %8\n"
+#define OP_AND(i) "v_and_b32 %" i ", %" i ", %8\n"
+#define OP_LSHL(i) "v_lshlrev_b32 %" i ", 1, %" i "\n"
+#define OP_MOV(i) "v_mov_b32 %" i ", %8\n"
+#define OP_MULLO(i) "v_mul_lo_u32 %" i ", %" i ", %8\n"
+#define OP_MULHI(i) "v_mul_hi_u32 %" i ", %" i ", %8\n"
+#define OP_MUL24(i) "v_mul_u32_u24 %" i ", %" i ", %8\n"
+#define OP_MAD24(i) "v_mad_u32_u24 %" i ", %" i ", %8, %9\n"
+#define OP_CNDMASK(i) "v_cndmask_b32 %" i ", %" i ", %8, vcc\n"
+#define OP_CMP(i) "v_cmp_lt_f32 vcc, %" i ", %8\n"
+#define OP_RCP(i) "v_rcp_f32 %" i ", %" i "\n"
+#define OP_SQRT(i) "v_sqrt_f32 %" i ", %" i "\n"
+#define OP_LOG(i) "v_log_f32 %" i ", %" i "\n"
+#define OP_EXP(i) "v_exp_f32 %" i ", %" i "\n"
+#define OP_CVT(i) "v_cvt_f32_u32 %" i ", %" i "\n"
+#define OP_FLOOR(i) "v_floor_f32 %" i ", %" i "\n"
+#define OP_PKFMA(i) "v_pk_fma_f32 %" i ", %" i ", %8, %9\n"       /* only valid on 64-bit operands: see kernel below */
+#define OP_DIVFIX(i) "v_div_fixup_f32 %" i ", %" i ", %8, %9\n"
+#define OP_FMAS(i) "v_fma_f32 %" i ", %" i ", %10, %9\n"          /* one SGPR operand */
+#define OP_MED3(i) "v_med3_f32 %" i ", %" i ", %8, %9\n"
+#define OP_BFE(i) "v_bfe_u32 %" i ", %" i ", 3, 5\n"
+#define OP_PERM(i) "v_mov_b32_dpp %" i ", %" i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define OP_READLANE(i) "v_readfirstlane_b32 s20, %" i "\n"
+#define OP_CND64(i) "v_cndmask_b32_e64 %" i ", %" i ", %8, s[20:21]\n"
+#define OP_CMP64(i) "v_cmp_lt_f32_e64 s[20:21], %" i ", %8\n"
+#define OP_CMP64R(i) "v_cmp_lt_f32_e64 s[2" i "*2+20:2" i "*2+21], %" i ", %8\n"
+#define OP_CMPCND(i) "v_cmp_lt_f32_e32 vcc, %" i ", %8\n v_cndmask_b32_e32 %" i ", %" i ", %8, vcc\n"
+#define OP_ADDCO(i) "v_add_co_u32_e32 %" i ", vcc, %" i ", %8\n"
+#define OP_CMPU(i) "v_cmp_lt_u32_e32 vcc, %" i ", %8\n"
+#define OP_MINF(i) "v_min_f32 %" i ", %" i ", %8\n"
+#define OP_SUBF(i) "v_sub_f32 %" i ", %" i ", %8\n"
+#define OP_FMAC(i) "v_fmac_f32 %" i ", %8, %9\n"
+#define OP_MADF(i) "v_mul_legacy_f32 %" i ", %" i ", %8\n"
+#define OP_XOR(i) "v_xor_b32 %" i ", %" i ", %8\n"
+#define OP_LSHLADD(i) "v_lshl_add_u32 %" i ", %" i ", 2, %8\n"
+#define OP_ADD3(i) "v_add3_u32 %" i ", %" i ", %8, %9\n"
+#define OP_CVTI(i) "v_cvt_i32_f32 %" i ", %" i "\n"
+#define OP_MULLIT(i) "v_mul_f32 %" i ", 0x3f000001, %" i "\n"
+#define OP_ADDK(i) "v_add_f32 %" i ", 1.0, %" i "\n"
+#define OP_CMPFMA(i) "v_cmp_lt_f32_e32 vcc, %" i ", %8\n v_fma_f32 %" i ", %" i ", %8, %9\n v_fma_f32 %" i ", %" i ", %8, %9\n v_fma_f32 %" i ", %" i ", %8, %9\n"
+#define OP_SALU(i) "s_add_u32 s20, s20, 1\n"
+#define OP_SAND64(i) "s_and_b64 s[20:21], s[20:21], exec\n"
+
+enum {
+    K_FMA, K_FMA_DEP, K_ADDF, K_MULF, K_MAXF, K_ADDU, K_AND, K_LSHL, K_MOV, K_MULLO, K_MULHI, K_MUL24, K_MAD24, K_CNDMASK, K_CMP,
+    K_RCP, K_SQRT, K_LOG, K_EXP, K_CVT, K_FLOOR, K_DIVFIX, K_FMAS, K_MED3, K_BFE, K_DPP, K_READFIRST, K_FMA64, K_PKFMA, K_DSREAD, K_CND64, K_CMP64, K_CMPCND, K_ADDCO, K_CMPU, K_MINF, K_SUBF, K_FMAC, K_MADF, K_XOR, K_LSHLADD, K_ADD3, K_CVTI, K_MULLIT, K_ADDK, K_CMPFMA, K_SALU, K_SAND64, K_P1, K_P2, K_P3, K_P4, K_P5, K_P6, K_P7, K_COUNT
+};
+static const char* kNames[K_COUNT] = {
+    "v_fma_f32 (8 chains)", "v_fma_f32 (1 dependent chain)", "v_add_f32", "v_mul_f32", "v_max_f32", "v_add_u32", "v_and_b32", "v_lshlrev_b32",
+    "v_mov_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_cndmask_b32", "v_cmp_lt_f32", "v_rcp_f32", "v_sqrt_f32",
+    "v_log_f32", "v_exp_f32", "v_cvt_f32_u32", "v_floor_f32", "v_div_fixup_f32", "v_fma_f32 (SGPR operand)", "v_med3_f32", "v_bfe_u32",
+    "v_mov_b32_dpp quad_perm", "v_readfirstlane_b32", "v_fma_f64", "v_pk_fma_f32", "ds_read_b32 (conflict-free)",
+    "v_cndmask_b32_e64 (s[20:21])", "v_cmp_lt_f32_e64 -> s[20:21]", "v_cmp vcc + v_cndmask vcc (per pair)", "v_add_co_u32 (vcc out)", "v_cmp_lt_u32 vcc",
+    "v_min_f32", "v_sub_f32", "v_fmac_f32", "v_mul_legacy_f32", "v_xor_b32", "v_lshl_add_u32", "v_add3_u32", "v_cvt_i32_f32", "v_mul_f32 (32-bit literal)",
+    "v_add_f32 (inline const)", "v_cmp + 3 v_fma (per 4)", "s_add_u32", "s_and_b64",
+    "P1: v_cmp_f32 vcc + 3 v_cndmask vcc (per 4)", "P2: s_mov vcc once; v_cndmask vcc x32", "P3: 2 v_cmp_f32 vcc + 2 v_fma (per 4)", "P4: 2 v_cndmask vcc + 2 v_fma (per 4)",
+    "P5: v_cmp_e64 sgpr + 3 v_cndmask_e64 (per 4)", "P6: v_cmp_f32 vcc x32, other data", "P7: v_cmp_lt_u32 vcc + 3 v_cndmask (per 4)"};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void probe(unsigned long long* spans, float* sink, uint64_t exec_mask, float fa, float fb) {
+    __shared__ float lds[256];
+    lds[threadIdx.x] = fa;
+    __syncthreads();
+    float a = fa, b = fb;
+    float sa = fa;
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    double d0 = r0, d1 = r1, d2 = r2, d3 = r3, d4 = r4, d5 = r5, d6 = r6, d7 = r7;
+    const double da = fa, db = fb;
+    const uint32_t lds_addr = (uint32_t)(threadIdx.x * 4u);
+    const int lane = threadIdx.x & 63;
+    const bool on = (exec_mask >> lane) & 1ull;
+    unsigned long long t0 = 0, t1 = 0;
+    if (on) {
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int rep = 0; rep < REPS; ++rep) {
+            if (KIND == K_FMA) { BODY8(OP_FMA) }
+            else if (KIND == K_FMA_DEP) { BODY1(OP_FMA) }
+            else if (KIND == K_ADDF) { BODY8(OP_ADDF) }
+            else if (KIND == K_MULF) { BODY8(OP_MULF) }
+            else if (KIND == K_MAXF) { BODY8(OP_MAXF) }
+            else if (KIND == K_ADDU) { BODY8(OP_ADDU) }
+            else if (KIND == K_AND) { BODY8(OP_AND) }
+            else if (KIND == K_LSHL) { BODY8(OP_LSHL) }
+            else if (KIND == K_MOV) { BODY8(OP_MOV) }
+            else if (KIND == K_MULLO) { BODY8(OP_MULLO) }
+            else if (KIND == K_MULHI) { BODY8(OP_MULHI) }
+            else if (KIND == K_MUL24) { BODY8(OP_MUL24) }
+            else if (KIND == K_MAD24) { BODY8(OP_MAD24) }
+            else if (KIND == K_CNDMASK) { BODY8(OP_CNDMASK) }
+            else if (KIND == K_CMP) { BODY8(OP_CMP) }
+            else if (KIND == K_RCP) { BODY8(OP_RCP) }
+            else if (KIND == K_SQRT) { BODY8(OP_SQRT) }
+            else if (KIND == K_LOG) { BODY8(OP_LOG) }
+            else if (KIND == K_EXP) { BODY8(OP_EXP) }
+            else if (KIND == K_CVT) { BODY8(OP_CVT) }
+            else if (KIND == K_FLOOR) { BODY8(OP_FLOOR) }
+            else if (KIND == K_DIVFIX) { BODY8(OP_DIVFIX) }
+            else if (KIND == K_FMAS) { BODY8(OP_FMAS) }
+            else if (KIND == K_MED3) { BODY8(OP_MED3) }
+            else if (KIND == K_BFE) { BODY8(OP_BFE) }
+            else if (KIND == K_DPP) { BODY8(OP_PERM) }
+            else if (KIND == K_CND64) { asm volatile("s_mov_b64 s[20:21], exec\n" ::: "s20", "s21"); asm volatile(".rept 4\n" OP_CND64("0") OP_CND64("1") OP_CND64("2") OP_CND64("3") OP_CND64("4") OP_CND64("5") OP_CND64("6") OP_CND64("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20", "s21"); }
+            else if (KIND == K_CMP64) { asm volatile(".rept 4\n" OP_CMP64("0") OP_CMP64("1") OP_CMP64("2") OP_CMP64("3") OP_CMP64("4") OP_CMP64("5") OP_CMP64("6") OP_CMP64("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20", "s21"); }
+            else if (KIND == K_CMPCND) { asm volatile(".rept 2\n" OP_CMPCND("0") OP_CMPCND("1") OP_CMPCND("2") OP_CMPCND("3") OP_CMPCND("4") OP_CMPCND("5") OP_CMPCND("6") OP_CMPCND("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_ADDCO) { asm volatile(".rept 4\n" OP_ADDCO("0") OP_ADDCO("1") OP_ADDCO("2") OP_ADDCO("3") OP_ADDCO("4") OP_ADDCO("5") OP_ADDCO("6") OP_ADDCO("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_CMPU) { asm volatile(".rept 4\n" OP_CMPU("0") OP_CMPU("1") OP_CMPU("2") OP_CMPU("3") OP_CMPU("4") OP_CMPU("5") OP_CMPU("6") OP_CMPU("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_MINF) { BODY8(OP_MINF) }
+            else if (KIND == K_SUBF) { BODY8(OP_SUBF) }
+            else if (KIND == K_FMAC) { BODY8(OP_FMAC) }
+            else if (KIND == K_MADF) { BODY8(OP_MADF) }
+            else if (KIND == K_XOR) { BODY8(OP_XOR) }
+            else if (KIND == K_LSHLADD) { BODY8(OP_LSHLADD) }
+            else if (KIND == K_ADD3) { BODY8(OP_ADD3) }
+            else if (KIND == K_CVTI) { BODY8(OP_CVTI) }
+            else if (KIND == K_MULLIT) { BODY8(OP_MULLIT) }
+            else if (KIND == K_ADDK) { BODY8(OP_ADDK) }
+            else if (KIND == K_CMPFMA) { asm volatile(OP_CMPFMA("0") OP_CMPFMA("1") OP_CMPFMA("2") OP_CMPFMA("3") OP_CMPFMA("4") OP_CMPFMA("5") OP_CMPFMA("6") OP_CMPFMA("7") : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_SALU) { asm volatile(".rept 32\n" OP_SALU("0") ".endr\n" ::: "s20", "scc"); }
+            else if (KIND == K_SAND64) { asm volatile(".rept 32\n" OP_SAND64("0") ".endr\n" ::: "s20", "s21", "scc"); }
+            else if (KIND == K_P1) { asm volatile(".rept 8\n v_cmp_lt_f32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_P2) { asm volatile("s_mov_b64 vcc, exec\n .rept 4\n" OP_CNDMASK("0") OP_CNDMASK("1") OP_CNDMASK("2") OP_CNDMASK("3") OP_CNDMASK("4") OP_CNDMASK("5") OP_CNDMASK("6") OP_CNDMASK("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_P3) { asm volatile(".rept 8\n v_cmp_lt_f32_e32 vcc, %0, %8\n v_cmp_lt_f32_e32 vcc, %1, %8\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_P4) { asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n .rept 8\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_P5) { asm volatile(".rept 8\n v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20", "s21"); }
+            else if (KIND == K_P6) { asm volatile(".rept 4\n" OP_CMP("0") OP_CMP("1") OP_CMP("2") OP_CMP("3") OP_CMP("4") OP_CMP("5") OP_CMP("6") OP_CMP("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b), "v"(a), "s"(sa) : "vcc"); }
+            else if (KIND == K_P7) { asm volatile(".rept 8\n v_cmp_lt_u32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_READFIRST) {
+                asm volatile(".rept 4\n" OP_READLANE("0") OP_READLANE("1") OP_READLANE("2") OP_READLANE("3") OP_READLANE("4") OP_READLANE("5") OP_READLANE("6") OP_READLANE("7") ".endr\n"
+                             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20");
+            } else if (KIND == K_FMA64) {
+                asm volatile(".rept 4\n"
+                             "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                             "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                             ".endr\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(da), "v"(db));
+            } else if (KIND == K_PKFMA) {
+                // the 64-bit register pairs of the doubles serve as float2 operands
+                asm volatile(".rept 4\n"
+                             "v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                             "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                             ".endr\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(da), "v"(db));
+            } else if (KIND == K_DSREAD) {
+                asm volatile(".rept 4\n"
+                             "ds_read_b32 %0, %8\n ds_read_b32 %1, %8\n ds_read_b32 %2, %8\n ds_read_b32 %3, %8\n"
+                             "ds_read_b32 %4, %8\n ds_read_b32 %5, %8\n ds_read_b32 %6, %8\n ds_read_b32 %7, %8\n"
+                             ".endr\n s_waitcnt lgkmcnt(0)\n"
+                             : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7) : "v"(lds_addr));
+            }
+        }
+        t1 = __builtin_readcyclecounter();
+    }
+    const float s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+    if (s == 12345.678f) sink[0] = s;                    // keep the chains alive
+    if (on && lane == __ffsll((long long)exec_mask) - 1) {
+        // where did this wave run?  HW_ID (hwreg 4): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13; XCC_ID (hwreg 20): 3:0
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = spans + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 3;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = ((unsigned long long)(xcc & 15u) << 16) | (unsigned long long)(hw & 0xfff0u);      // SIMD identity
+    }
+}
+
+typedef void (*kern_t)(unsigned long long*, float*, uint64_t, float, float);
+template <int K> struct Table { static void fill(kern_t* t) { t[K] = probe<K>; Table<K - 1>::fill(t); } };
+template <> struct Table<-1> { static void fill(kern_t*) {} };
+
+struct Result { double cyc_per_instr; double waves_per_simd; int simds; double span; };
+// per SIMD: (latest end - earliest start) / (waves on it x instructions per wave); median over SIMDs
+static Result reduce(const std::vector<unsigned long long>& raw, int waves, double instr) {
+    std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> by;
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int w = 0; w < waves; ++w) {
+        by[raw[w * 3 + 2]].push_back({raw[w * 3], raw[w * 3 + 1]});
+        lo = std::min(lo, raw[w * 3]); hi = std::max(hi, raw[w * 3 + 1]);
+    }
+    std::vector<double> v;
+    double nw = 0;
+    for (auto& kv : by) {
+        // waves of one SIMD may run in several rounds: take the total busy span of the SIMD and all its waves
+        unsigned long long a = ~0ull, b = 0;
+        for (auto& p : kv.second) { a = std::min(a, p.first); b = std::max(b, p.second); }
+        v.push_back((double)(b - a) / ((double)kv.second.size() * instr));
+        nw += (double)kv.second.size();
+    }
+    std::sort(v.begin(), v.end());
+    return {v[v.size() / 2], nw / (double)by.size(), (int)by.size(), (double)(hi - lo)};
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device: %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
+    kern_t kern[K_COUNT];
+    Table<K_COUNT - 1>::fill(kern);
+    unsigned long long* d_spans;
+    float* d_sink;
+    const int max_blocks = cus * 8;
+    CHECK(hipMalloc(&d_spans, sizeof(unsigned long long) * max_blocks * 4 * 3));
+    CHECK(hipMalloc(&d_sink, 64));
+    std::vector<unsigned long long> spans(max_blocks * 4 * 3);
+    const double instr = (double)REPS * UNROLL;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    struct Mask { const char* name; uint64_t m; };
+    const Mask masks[] = {{"all 64 lanes", ~0ull}, {"lanes 0-31", 0xffffffffull}, {"lanes 0-15", 0xffffull}, {"even lanes", 0x5555555555555555ull},
+                          {"lanes 0-15 + 32-47", 0x0000ffff0000ffffull}};
+    auto run = [&](int k, int blocks, uint64_t mask, float* ms_out) -> Result {
+        for (int pass = 0; pass < 2; ++pass) {      // first pass warms the clocks / instruction cache
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern[k], dim3(blocks), dim3(256), 0, 0, d_spans, d_sink, mask, 1.0000001f, 1e-9f);
+            (void)hipEventRecord(e1, 0);
+            (void)hipDeviceSynchronize();
+        }
+        if (ms_out) (void)hipEventElapsedTime(ms_out, e0, e1);
+        (void)hipMemcpy(spans.data(), d_spans, sizeof(unsigned long long) * blocks * 4 * 3, hipMemcpyDeviceToHost);
+        return reduce(spans, blocks * 4, instr);
+    };
+    printf("\n== shader cycles (s_memtime) per wave-instruction per SIMD: per SIMD (last end - first start) / (its waves x instructions per wave), median over SIMDs ==\n");
+    printf("   columns: blocks per CU launched -> [cycles | waves per SIMD actually observed]\n");
+    printf("%-34s %16s %16s %16s %16s\n", "instruction", "1 block/CU", "2 blocks/CU", "4 blocks/CU", "8 blocks/CU");
+    for (int k = 0; k < K_COUNT; ++k) {
+        printf("%-34s", kNames[k]);
+        for (int W : {1, 2, 4, 8}) {
+            const Result r = run(k, cus * W, ~0ull, nullptr);
+            printf("   %6.3f | %5.2f", r.cyc_per_instr, r.waves_per_simd);
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    printf("\n== partial EXEC masks, 8 blocks per CU: cycles per wave-instruction per SIMD ==\n");
+    printf("%-34s", "instruction");
+    for (const Mask& m : masks) printf(" %18s", m.name);
+    printf("\n");
+    for (int k : {(int)K_FMA, (int)K_ADDU, (int)K_MULLO, (int)K_RCP, (int)K_FMA64, (int)K_DSREAD}) {
+        printf("%-34s", kNames[k]);
+        for (const Mask& m : masks) printf(" %18.3f", run(k, cus * 8, m.m, nullptr).cyc_per_instr);
+        printf("\n");
+        fflush(stdout);
+    }
+    // wall-clock cross-check: the s_memtime rate, and the whole-chip rate of the saturated launch
+    printf("\n== wall clock (HIP events) of the 8-blocks-per-CU launch ==\n");
+    for (int k : {(int)K_FMA, (int)K_ADDF, (int)K_ADDU, (int)K_MULLO, (int)K_RCP, (int)K_CNDMASK, (int)K_PKFMA}) {
+        float ms = 0;
+        const Result r = run(k, cus * 8, ~0ull, &ms);
+        const double wave_instr = instr * cus * 8 * 4;
+        printf("%-34s %.3f ms  s_memtime span %.0f ticks -> %.1f MHz tick rate; %.3f ns per wave-instruction per SIMD (%d SIMDs seen) = %.2f cycles at 2.4 GHz; %.1f T lane-ops/s\n",
+               kNames[k], ms, r.span, r.span / (ms * 1e3), ms * 1e6 / (wave_instr / r.simds), r.simds, ms * 1e6 / (wave_instr / r.simds) * 2.4,
+               wave_instr * 64 / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}

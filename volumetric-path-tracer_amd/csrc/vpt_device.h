@@ -88,6 +88,11 @@ struct Counters {
     unsigned long long sched[8];
     // [0] refill, [1] Philox top-up, [2] walk step, [3] transitions: wave-level shader-clock cycles (s_memtime)
     unsigned long long cycles[4];
+    // spatial coherence of the density look-ups of single-volume scenes (counting builds only; wave-level sums):
+    // [0] wave-level look-up events, [1] lanes taking part, [2] distinct 8x8x8-voxel bricks among those lanes,
+    // [3] distinct 4x4x4 bricks, [4] distinct 128-byte lines over one lane's 8 taps summed over lanes,
+    // [5] distinct 128-byte lines over ALL taps of the wave (what one gather pass asks the L1 for)
+    unsigned long long coh[8];
 };
 
 #ifndef VPT_SUB

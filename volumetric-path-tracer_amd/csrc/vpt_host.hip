@@ -145,6 +145,31 @@ Box vdb_bounds(const vpt_gpu_vdb& v) {
     return b;
 }
 
+// World-space box of the points get_density / get_color / get_emission accept for this instance (render_kernel.cu:987-997):
+// index positions in [bmin, bmin + dim].  That is one voxel more per axis than Bounds() above covers (bmax - bmin =
+// dim - 1 for a grid densified over its active bbox, gpu_vdb.cpp:453-455), so a point can be inside the look-up domain
+// of an instance whose AABB it has left.  Returned as the union with Bounds(), grown by 1e-4 of its size (the device's
+// u in [0, 1] test is evaluated in fp32).  Used to refine the candidate lists (vpt_scene_set_volumes), never for the
+// octree itself, which must reproduce the reference's.
+struct BoxD { double lo[3], hi[3]; };
+BoxD lookup_domain_bounds(const vpt_gpu_vdb& v, const Box& aabb) {
+    const mat4 i2w = mat4_transpose(load_xform(v));
+    const double b0[3] = {v.vdb_info.bmin.x, v.vdb_info.bmin.y, v.vdb_info.bmin.z};
+    const double b1[3] = {b0[0] + (double)v.vdb_info.dim.x, b0[1] + (double)v.vdb_info.dim.y, b0[2] + (double)v.vdb_info.dim.z};
+    BoxD r = {{aabb.lo.x, aabb.lo.y, aabb.lo.z}, {aabb.hi.x, aabb.hi.y, aabb.hi.z}};
+    for (int c = 0; c < 8; ++c) {
+        const f3 q = mk3((float)((c & 1) ? b1[0] : b0[0]), (float)((c & 2) ? b1[1] : b0[1]), (float)((c & 4) ? b1[2] : b0[2]));
+        const f3 p = mat4_transform_point(i2w, q);
+        const double pc[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; ++a) { r.lo[a] = std::min(r.lo[a], pc[a]); r.hi[a] = std::max(r.hi[a], pc[a]); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        const double g = 1e-4 * (r.hi[a] - r.lo[a]) + 1e-6 * std::max(std::fabs(r.lo[a]), std::fabs(r.hi[a]));
+        r.lo[a] -= g; r.hi[a] += g;
+    }
+    return r;
+}
+
 bool overlaps(const Box& a, const Box& b) {                  // AABB.h:134-139
     bool x = (a.hi.x >= b.lo.x) && (a.lo.x <= b.hi.x);
     bool y = (a.hi.y >= b.lo.y) && (a.lo.y <= b.hi.y);
@@ -379,6 +404,8 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<DVolume> dv(num_volumes);
     std::vector<Box> bounds(num_volumes);
+    // the previous scene's device arrays are released below: until this call succeeds there is no scene to render
+    ctx->scene_ready = false;
     ctx->any_color = ctx->any_emission = false;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (void* b : ctx->bricked) (void)hipFree(b);
@@ -534,10 +561,14 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         // Candidate lists of the instance loop.  A leaf's list (every instance whose bounds overlap the leaf, as the
         // reference builds it) is refined per SUB-CELL of the leaf (VPT_SUB^3 of them, 4x4x4): an instance that does not contain the look-up
         // point contributes nothing (get_density returns 0 outside, :997), so visiting only the instances whose bounds
-        // overlap the point's sub-cell gives the same sums, in the same order, with a third of the candidates.  The
+        // overlap the point's sub-cell gives the same sums, in the same order, with a third of the candidates.  "Bounds"
+        // here is the world box of the instance's LOOK-UP DOMAIN (lookup_domain_bounds: one voxel more per axis than the
+        // AABB the octree is built from -- a point in that shell is still summed by the reference).  The
         // sub-cell boxes are grown by 1e-3 of their size, far more than the rounding of the device's cell index and of
         // the bounds themselves, so every instance that can contain a point of the cell is listed.  One 64-byte matrix
         // slot per LIST ENTRY, in list order: a candidate's matrix is read at the list position itself.
+        std::vector<BoxD> domain(num_volumes);
+        for (int v = 0; v < num_volumes; ++v) domain[v] = lookup_domain_bounds(volumes[v], bounds[v]);
         std::vector<uint32_t> sub_offsets((size_t)512 * VPT_SUB3 + 1, 0);
         std::vector<uint32_t> sub_entries;
         for (int p3 = 0; p3 < 512; ++p3) {
@@ -550,8 +581,8 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
                     const double lo[3] = {b3.lo.x + w[0] * (cx - grow) / VPT_SUB, b3.lo.y + w[1] * (cy - grow) / VPT_SUB, b3.lo.z + w[2] * (cz - grow) / VPT_SUB};
                     const double hi[3] = {b3.lo.x + w[0] * (cx + 1 + grow) / VPT_SUB, b3.lo.y + w[1] * (cy + 1 + grow) / VPT_SUB, b3.lo.z + w[2] * (cz + 1 + grow) / VPT_SUB};
                     for (uint32_t q = offsets[p3]; q < offsets[p3 + 1]; ++q) {
-                        const Box& bb = bounds[indices[q]];
-                        if (bb.lo.x <= hi[0] && bb.hi.x >= lo[0] && bb.lo.y <= hi[1] && bb.hi.y >= lo[1] && bb.lo.z <= hi[2] && bb.hi.z >= lo[2])
+                        const BoxD& bb = domain[indices[q]];
+                        if (bb.lo[0] <= hi[0] && bb.hi[0] >= lo[0] && bb.lo[1] <= hi[1] && bb.hi[1] >= lo[1] && bb.lo[2] <= hi[2] && bb.hi[2] >= lo[2])
                             sub_entries.push_back(indices[q]);
                     }
                 }
@@ -647,6 +678,15 @@ int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[12]) {
     HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memcpy(out, c.sched, sizeof(c.sched));
     std::memcpy(out + 8, c.cycles, sizeof(c.cycles));
+    return VPT_OK;
+}
+
+int vpt_test_get_coherence(vpt_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    Counters c;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    std::memcpy(out, c.coh, sizeof(c.coh));
     return VPT_OK;
 }
 

@@ -118,6 +118,74 @@ VPT_D int sub_cell(const TraceParams& P, f3 lo, f3 p) {
     return (iz * VPT_SUB + iy) * VPT_SUB + ix;
 }
 
+// Counting builds, single-volume scenes: how coherent are the density look-ups a wave issues together?  (DESIGN.md section 4:
+// the evidence behind not staging brick tiles in LDS.)  Executed by the lanes that are about to fetch; wave-level sums.
+template <bool A24>
+VPT_D void coherence_stats(const TraceParams& P, f3 p) {
+    if (((__builtin_readcyclecounter() >> 5) & 15ull) != 0ull) return;       // a wave-uniform 1-in-16 sample of the events (all figures are ratios)
+    f3 u;
+    const bool inside = to_unit(P.vol0.m, P.vol0, p, u);
+    if (!inside) return;
+    const DVolume& v = P.vol0;
+    const Taps t = make_taps(v.dim, u);
+    // float index of the 8 taps in the layout actually used
+    uint32_t a[8];
+    if (v.bricked) {
+        const uint32_t row = (uint32_t)v.bdim[0] * 64u, slab = (uint32_t)v.bdim[1] * row;
+        const uint32_t x[2] = {(((uint32_t)t.i0 >> 2) << 6) + ((uint32_t)t.i0 & 3u), (((uint32_t)t.i1 >> 2) << 6) + ((uint32_t)t.i1 & 3u)};
+        const uint32_t y[2] = {((uint32_t)t.j0 >> 2) * row + (((uint32_t)t.j0 & 3u) << 2), ((uint32_t)t.j1 >> 2) * row + (((uint32_t)t.j1 & 3u) << 2)};
+        const uint32_t z[2] = {((uint32_t)t.k0 >> 2) * slab + (((uint32_t)t.k0 & 3u) << 4), ((uint32_t)t.k1 >> 2) * slab + (((uint32_t)t.k1 & 3u) << 4)};
+        for (int q = 0; q < 8; ++q) a[q] = z[q >> 2] + y[(q >> 1) & 1] + x[q & 1];
+    } else {
+        const uint32_t dx = (uint32_t)v.dim[0], dy = (uint32_t)v.dim[1];
+        const uint32_t x[2] = {(uint32_t)t.i0, (uint32_t)t.i1}, y[2] = {(uint32_t)t.j0, (uint32_t)t.j1}, z[2] = {(uint32_t)t.k0, (uint32_t)t.k1};
+        for (int q = 0; q < 8; ++q) a[q] = (z[q >> 2] * dy + y[(q >> 1) & 1]) * dx + x[q & 1];
+    }
+    uint32_t own_lines = 0;
+    for (int q = 0; q < 8; ++q) {
+        bool seen = false;
+        for (int r = 0; r < q; ++r) seen = seen || (a[r] >> 5) == (a[q] >> 5);
+        own_lines += seen ? 0u : 1u;
+    }
+    const uint32_t b8 = (((uint32_t)t.k0 >> 3) * 4096u + ((uint32_t)t.j0 >> 3)) * 4096u + ((uint32_t)t.i0 >> 3);
+    const uint32_t b4 = (((uint32_t)t.k0 >> 2) * 4096u + ((uint32_t)t.j0 >> 2)) * 4096u + ((uint32_t)t.i0 >> 2);
+    const unsigned long long act = __ballot(1);
+    uint32_t d8 = 0, d4 = 0, dl = 0;
+    for (unsigned long long m = act; m != 0ull;) {
+        const uint32_t id = (uint32_t)__shfl((int)b8, __ffsll((long long)m) - 1);
+        m &= ~__ballot(b8 == id);
+        d8++;
+    }
+    for (unsigned long long m = act; m != 0ull;) {
+        const uint32_t id = (uint32_t)__shfl((int)b4, __ffsll((long long)m) - 1);
+        m &= ~__ballot(b4 == id);
+        d4++;
+    }
+    // distinct lines over all taps of the wave: retire one line id per round
+    uint32_t done = 0;                                   // bit q: tap q's line has been counted
+    for (;;) {
+        const unsigned long long m = __ballot(done != 0xffu);
+        if (m == 0ull) break;
+        uint32_t cand = 0;
+        for (int q = 7; q >= 0; --q) cand = ((done >> q) & 1u) ? cand : (a[q] >> 5);       // lowest tap not yet counted
+        const uint32_t id = (uint32_t)__shfl((int)cand, __ffsll((long long)m) - 1);
+        for (int q = 0; q < 8; ++q) done |= ((a[q] >> 5) == id) ? (1u << q) : 0u;
+        dl++;
+    }
+    const int leader = __ffsll((long long)act) - 1;
+    // wave sum of own_lines
+    unsigned long long sum_own = 0;
+    for (unsigned long long m = act; m != 0ull; m &= m - 1ull) sum_own += (unsigned long long)__shfl((int)own_lines, __ffsll((long long)m) - 1);
+    if (__lane_id() == leader) {
+        atomicAdd(&P.counters->coh[0], 1ull);
+        atomicAdd(&P.counters->coh[1], (unsigned long long)__popcll(act));
+        atomicAdd(&P.counters->coh[2], (unsigned long long)d8);
+        atomicAdd(&P.counters->coh[3], (unsigned long long)d4);
+        atomicAdd(&P.counters->coh[4], sum_own);
+        atomicAdd(&P.counters->coh[5], (unsigned long long)dl);
+    }
+}
+
 // Returns true when the walk ended.  hist / n_hist: per-lane LDS history of the densities seen by
 // the fused first walk (record_hist), stride 256 floats.
 // retries (vol_integrator only: use_retries): how many further `sample()` calls the integrator's depth
@@ -227,6 +295,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
             lookup_volume<COLOR, EMIT, COUNT, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, c.n_d, c.n_c, c.n_e, is_sample);
         });
     }
+    if (COUNT && !MULTI && !is_emit) coherence_stats<A24>(P, w.pos);
     if (is_sample) {
         // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
         // (one correctly rounded divide by emission_pivot) and fetch are evaluated there.

@@ -412,8 +412,10 @@ def _finish(sd):
     return sd
 
 
-def fireball_scene(width, height, n=256, lib=None):
-    """BASELINE config 3: emission + blackbody LUT, sun only (emission_scale = 1, pivot = 1)."""
+def fireball_scene(width, height, n=256, lib=None, sky=False):
+    """BASELINE config 3: emission + blackbody LUT (emission_scale = 1, pivot = 1).  sky=True is the BASELINE.md 4
+    specification (procedural sun + sky: the caller binds the atmosphere LUTs, as for config 2); sky=False is the
+    sun-only variant (sky_mult = 0, no LUTs needed) the small parity scenes use."""
     lib = lib or load_library()
     dens, heat = fireball_grids(n)
     sd = SceneDesc()
@@ -425,15 +427,18 @@ def fireball_scene(width, height, n=256, lib=None):
     kp = _base_kp(lib, width, height)
     kp.emission_scale = 1.0
     kp.emission_pivot = 1.0
-    kp.sky_mult = 0.0
+    if not sky:
+        kp.sky_mult = 0.0
     sd.kp = kp
     return _finish(sd)
 
 
-def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacing=None, lib=None):
+def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacing=None, lib=None, sky=False, rotate=True):
     """BASELINE config 5: grid x grid instances of one coloured-smoke grid (density + Cd) on a
     jittered lattice with random unit quaternions, scale 1, via the .ins transform
-    (vpt_instance_xform == main.cpp:1060-1095), DOF on."""
+    (vpt_instance_xform == main.cpp:1060-1095), DOF on.  sky=True: procedural sun + sky as BASELINE.md 4 specifies
+    (the caller binds the atmosphere LUTs); sky=False: sun only.  rotate=False keeps the instances axis-aligned
+    (identity quaternion), the case in which an instance's AABB is exactly its index-space box."""
     lib = lib or load_library()
     dens, cd = smoke_grids(n)
     voxel = 8.0 / n
@@ -448,6 +453,8 @@ def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacin
             pos = np.array([(gi - (grid - 1) / 2) * spacing, 0.0, (gj - (grid - 1) / 2) * spacing]) + rng.uniform(-2.0, 2.0, 3)
             q = rng.normal(size=4)
             q /= np.linalg.norm(q)
+            if not rotate:
+                q = np.array([0.0, 0.0, 0.0, 1.0])
             v = GpuVdb.from_buffer_copy(base)
             out = F44()
             lib.vpt_instance_xform(C.byref(base.xform), C.byref((C.c_double * 3)(*pos)), C.byref((C.c_double * 4)(*q)), 1.0, C.byref(out))
@@ -456,7 +463,8 @@ def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacin
     vols = [v for v, _, _, _ in sd.volumes]
     sd.camera, center, dist = frame_camera(lib, vols, width, height, aperture=aperture)
     kp = _base_kp(lib, width, height)
-    kp.sky_mult = 0.0
+    if not sky:
+        kp.sky_mult = 0.0
     sd.kp = kp
     return _finish(sd)
 
