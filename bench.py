@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the hot path (BASELINE.json metric) on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|sun|c1|c3|c4|c5] [--spp N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|sun|c1|c3|c4|c5|c3-sun|c5-sun] [--spp N]
+                    [--scaling weak|strong] [--no-other-configs] [--no-cpu-baseline] [--no-per-frame]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one render of the named workload (default: BASELINE config 2 = dragon.vdb, 1920x1080,
-64 spp, procedural sun + sky): `spp` iterations of `volume_rt_kernel` per rank (raygen + trace +
-tail/resolve kernels, inputs resident in HBM).  The other BASELINE configs (c3 fireball emission,
-c4 large cloud + HDRI + vol_integrator, c5 100 instances at 4K with DOF) run on their synthetic
-stand-ins; they are reported in DESIGN.md, the driver's bench line is c2.  With N > 1
-every rank renders its own iteration stripe (weak scaling: N*spp samples per pixel per
-step) and the accumulation buffers are combined with ONE all-reduce (RCCL) inside the
-timed region.  Rank 0 prints one JSON line.
+A "step" = one render of the named workload (default: BASELINE config 2 = dragon.vdb, 1920x1080, 64 spp, procedural
+sun + sky): `spp` iterations of `volume_rt_kernel` per rank (raygen + trace + tail/resolve kernels, inputs resident in
+HBM).  The JSON line of rank 0 carries, next to the headline:
+  roofline       of the headline's dominant kernel (the tracer) -- three labelled fractions, see `roofline_block`
+  other_configs  BASELINE configs 3, 4, 5 on their synthetic stand-ins at spec size, 2 steps each, N = 1 only
+  per_frame      the literal drop-in call: one vpt_render (1 iteration) + device sync per frame, as main.cpp:1822-1829
+  cpu_baseline   the reference's own kernel built for the host (oracle/_ref) or the oracle, on a bounded sample of the same
+                 frame -- and the HIP image of the SAME iterations compared with it (`parity_rel_l2`)
+With N > 1 every rank renders its own iteration stripe and the accumulation buffers are combined with ONE RCCL
+all-reduce below the C ABI (vpt_allreduce_accum) inside the timed region, with no host synchronisation inside a step.
+  --scaling weak   (default) every rank renders `spp` iterations: N*spp samples per pixel per step
+  --scaling strong the job's `spp` iterations are split over the ranks (spp/N each): fixed total work
 """
 import argparse
 import json
@@ -23,6 +28,100 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (guides/MI355X_MICROARCH.md)
+DEFAULT_SPP = {"c1": 64, "sun": 64, "c2": 64, "c3": 256, "c3-sun": 256, "c4": 128, "c5": 512, "c5-sun": 512}
+
+
+def make_scene(pkg, cfg, W, H, spp, grid_scale, dev, local_rank):
+    """-> (SceneDesc, workload string, data string, W, H)"""
+    if cfg in ("c1", "sun", "c2"):
+        sd = pkg.scene.dragon_scene(W, H, cfg)
+        workload = "dragon.vdb %dx%dx%dspp, %s" % (W, H, spp, {
+            "c2": "procedural sun+sky (BASELINE config 2)", "sun": "sun NEE only, sky_mult=0 (config 2 without the sky LUTs)",
+            "c1": "one point light, no atmosphere (BASELINE config 1)"}[cfg])
+        data = "synthetic camera/lights on the reference's dragon.vdb grid (committed fixture)"
+    elif cfg in ("c3", "c3-sun"):
+        sd = pkg.scene.fireball_scene(W, H, n=256, sky=cfg == "c3")
+        workload = "synthetic fireball 256^3 (density + heat, blackbody LUT) %dx%dx%dspp, %s (BASELINE config 3 stand-in)" % (
+            W, H, spp, "procedural sun+sky" if cfg == "c3" else "sun only")
+        data = "synthetic (fireball.vdb is not shipped with the reference)"
+    elif cfg == "c4":
+        shape = tuple(int(round(x * grid_scale)) for x in (1216, 704, 1024))
+        grid = pkg.scene.cloud_grid_torch(shape, device=dev)
+        sd = pkg.scene.cloud_scene(W, H, env=(2048, 1024), integrator=1, device_grid=grid)
+        workload = "synthetic cloud %dx%dx%d f32 (%.2f GB) + 2048x1024 HDRI, vol_integrator, %dx%dx%dspp (BASELINE config 4 stand-in)" % (
+            shape[2], shape[1], shape[0], grid.numel() * 4 / 1e9, W, H, spp)
+        data = "synthetic (the Disney cloud is not shipped with the reference)"
+    elif cfg in ("c5", "c5-sun"):
+        if W == 1920 and H == 1080:
+            W, H = 3840, 2160
+        sd = pkg.scene.instanced_scene(W, H, n=128, grid=10, aperture=2.0, sky=cfg == "c5")
+        workload = "100 instances of a synthetic 128^3 coloured-smoke grid over the octree, DOF, %s, %dx%dx%dspp (BASELINE config 5 stand-in)" % (
+            "procedural sun+sky" if cfg == "c5" else "sun only", W, H, spp)
+        data = "synthetic (colored_smoke.vdb is not shipped with the reference)"
+    else:
+        raise SystemExit("unknown --config " + cfg)
+    if cfg in ("c2", "c3", "c4", "c5"):
+        pkg.atmosphere.attach_default_atmosphere(sd, device=local_rank)
+    return sd, workload, data, W, H
+
+
+def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator):
+    """cs: stats of a counted pass, st: HIP-event times of the last timed step.
+
+    Three fractions of the 8 TB/s HBM peak, each recomputable from this line and profiles/ of the same commit:
+      frac_kernel (= `frac`): bytes the tracer has to move (the trilinear fetches it issues: density at every step for
+          the instances whose domain holds the point, colour at real collisions, emission; plus its record stream:
+          4 + 64 B read and 64 B written per traced ray) / its HIP-event duration
+      frac_step: the same look-up bytes + the 88-byte framebuffer term of BASELINE.md 3, x samples / whole-step time
+      hbm_measured_frac: FETCH_SIZE x 2 + WRITE_SIZE of the tracer (rocprofv3 --pmc, profiles/traffic.json) / its duration
+    and, for reference, frac_step_reference_counts with the reference-defined look-up counts of SURVEY 8d (every
+    instance of the leaf at every step, the first walk twice): not a bound on this kernel (it exceeds 1 on config 5)."""
+    n = float(max(1, cs.samples))
+    nd, nc, ne = cs.density_lookups / n, cs.color_lookups / n, cs.emission_lookups / n
+    fd, fc, fe = cs.density_fetches / n, cs.color_fetches / n, cs.emission_fetches / n
+    counted_iters = max(1.0, n / float(W * H))
+    traced = cs.queued_rays / float(W * H) / counted_iters
+    b_lookup = 32.0 * fd + 128.0 * fc + 32.0 * fe
+    b_kernel = b_lookup + 132.0 * traced
+    b_step = b_lookup + 88.0
+    b_ref = 32.0 * nd + 128.0 * nc + 32.0 * ne + 88.0
+    kernel_name = "vpt::trace_vol_kernel" if integrator else "vpt::trace_kernel"
+    trace_s = st.trace_ms * 1e-3
+    achieved = b_kernel * samples_per_step / trace_s / 1e9 if trace_s > 0 else 0.0
+    r = {
+        "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "frac_kernel": round(achieved / HBM_PEAK_GBS, 5),
+        "frac_step": round(b_step * samples_per_step / step_s / 1e9 / HBM_PEAK_GBS, 5),
+        "frac_step_reference_counts": round(b_ref * samples_per_step / step_s / 1e9 / HBM_PEAK_GBS, 5),
+        "hbm_measured_frac": None,
+        "bytes_per_sample": {"kernel_must_move": round(b_kernel, 2), "step_required": round(b_step, 2), "survey_8d_reference_counts": round(b_ref, 2)},
+        "per_sample": {"density_fetches": round(fd, 4), "color_fetches": round(fc, 4), "emission_fetches": round(fe, 4),
+                       "density_lookups_reference": round(nd, 4), "color_lookups_reference": round(nc, 4), "emission_lookups_reference": round(ne, 4),
+                       "tracking_steps": round(cs.tracking_steps / n, 4), "skip_steps": round(cs.skip_steps / n, 4), "rays_traced_fraction": round(traced, 4)},
+        "raygen_ms_per_step": round(st.raygen_ms, 3), "trace_ms_per_step": round(st.trace_ms, 3),
+        "tail_resolve_ms_per_step": round(st.tail_ms + st.resolve_ms, 3),
+        "note": "achieved = bytes the tracer must move per sample x samples per step / HIP-event time of its launches in the step",
+    }
+    # measured HBM traffic of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    # command, corrected per MI355X_MICROARCH.md; tools/profile_bench.sh + tools/make_traffic_json.py write the file)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f).get(cfg)
+        if tj and tj.get("width") == W and tj.get("height") == H:
+            per_sample = tj["bytes_per_launch"] / float(tj["samples_per_launch"])
+            ipl = max(1, min(64, spp, (16 << 30) // (W * H * 64)))      # iterations per tracer launch: the chunk rule of vpt_render_batch
+            launches = -(-spp // ipl)
+            r["traffic"] = round(per_sample * samples_per_step / launches / 1e9, 4)
+            r["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+            r["launches_per_step"] = launches
+            if trace_s > 0:
+                r["hbm_measured_frac"] = round(per_sample * samples_per_step / trace_s / 1e9 / HBM_PEAK_GBS, 5)
+            vk = (tj.get("valu") or {}).get(kernel_name)
+            if vk:
+                r["valu"] = vk
+    return r
 
 
 def main():
@@ -33,10 +132,14 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=0, help="iterations per rank and step (default: the config's own)")
+    ap.add_argument("--spp", type=int, default=0, help="iterations per step (weak: per rank; strong: of the whole job); default: the config's own")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--grid-scale", type=float, default=1.0, help="c4: linear scale of the 1024x704x1216 cloud grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-per-frame", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -68,160 +171,162 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, H = args.width, args.height
     cfg = args.config
-    spp = args.spp or {"c3": 256, "c4": 128, "c5": 512}.get(cfg, 64)
-    if cfg in ("c1", "sun", "c2"):
-        sd = pkg.scene.dragon_scene(W, H, cfg)
-        workload = "dragon.vdb %dx%dx%dspp, %s" % (W, H, spp, {
-            "c2": "procedural sun+sky (BASELINE config 2)", "sun": "sun NEE only, sky_mult=0 (config 2 without the sky LUTs)",
-            "c1": "one point light, no atmosphere (BASELINE config 1)"}[cfg])
-        data = "synthetic camera/lights on the reference's dragon.vdb grid (committed fixture)"
-    elif cfg == "c3":
-        sd = pkg.scene.fireball_scene(W, H, n=256)
-        workload = "synthetic fireball 256^3 (density + heat, blackbody LUT) %dx%dx%dspp, sun (BASELINE config 3 stand-in)" % (W, H, spp)
-        data = "synthetic (fireball.vdb is not shipped with the reference)"
-    elif cfg == "c4":
-        shape = tuple(int(round(x * args.grid_scale)) for x in (1216, 704, 1024))
-        grid = pkg.scene.cloud_grid_torch(shape, device=dev)
-        sd = pkg.scene.cloud_scene(W, H, env=(2048, 1024), integrator=1, device_grid=grid)
-        workload = "synthetic cloud %dx%dx%d f32 (%.2f GB) + 2048x1024 HDRI, vol_integrator, %dx%dx%dspp (BASELINE config 4 stand-in)" % (
-            shape[2], shape[1], shape[0], grid.numel() * 4 / 1e9, W, H, spp)
-        data = "synthetic (the Disney cloud is not shipped with the reference)"
-    elif cfg == "c5":
-        if args.width == 1920 and args.height == 1080:
-            W, H = 3840, 2160
-        sd = pkg.scene.instanced_scene(W, H, n=128, grid=10, aperture=2.0)
-        workload = "100 instances of a synthetic 128^3 coloured-smoke grid over the octree, DOF, %dx%dx%dspp (BASELINE config 5 stand-in)" % (W, H, spp)
-        data = "synthetic (colored_smoke.vdb is not shipped with the reference)"
+    job_spp = args.spp or DEFAULT_SPP.get(cfg, 64)
+    if args.scaling == "strong" and world > 1:
+        if job_spp % world:
+            raise SystemExit("--scaling strong needs spp (%d) divisible by the number of ranks (%d)" % (job_spp, world))
+        spp = job_spp // world
     else:
-        raise SystemExit("unknown --config " + cfg)
-    if cfg in ("c2", "c4"):
-        pkg.atmosphere.attach_default_atmosphere(sd, device=local_rank)
-    hb = pkg.scene.HipBinding(sd, device=local_rank)
-    first_it, stride, bn_pre = pkg.dist.stripe(rank, world)
-    bn0 = hb.blue_noise.clone()
+        spp = job_spp
 
-    tstream = torch.cuda.current_stream(dev)
+    def measure(cfg, spp, steps, warmup, W, H, with_extras):
+        """one workload: returns the dict of the JSON line (rank 0) or None"""
+        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or args.scaling == "weak" else spp * world, args.grid_scale, dev, local_rank)
+        hb = pkg.scene.HipBinding(sd, device=local_rank)
+        first_it, stride, bn_pre = pkg.dist.stripe(rank, world)
+        bn0 = hb.blue_noise.clone()
+        torch.cuda.synchronize(dev)
+        use_comm = world > 1 and backend == "nccl"
+        if use_comm:
+            pkg.dist.init_comm(hb.ctx)                   # RCCL communicator of this context (id carried by torch.distributed)
+        # everything a step enqueues goes to the context's own stream; torch ops on it through an ExternalStream view
+        cstream = torch.cuda.ExternalStream(hb.ctx.stream, device=dev)
 
-    def one_step():
-        if world == 1:
-            # the next `spp` iterations of the progressive render (iteration indices, blue-noise table and running means
-            # carry on from the previous step, as consecutive frames of the reference do): no host round trip between steps
-            hb.render(spp)
-            return
-        hb.sync()                                       # the previous step's kernels are done with the blue-noise table
-        hb.blue_noise.copy_(bn0)
-        tstream.synchronize()                           # torch's stream -> visible to the ctx stream
-        if bn_pre:
-            hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre, sd.width * sd.height)
-        hb.render(spp, iter_stride=stride, iteration=first_it)
+        def one_step():
+            if world == 1:
+                # the next `spp` iterations of the progressive render (iteration indices, blue-noise table and running means
+                # carry on from the previous step, as consecutive frames of the reference do): no host round trip between steps
+                hb.render(spp)
+                return
+            # a step of the N-rank job: this rank's stripe of a fresh render, then the one all-reduce.  All of it is enqueued
+            # on the context's stream in order -- the next step's kernels queue behind the reduce, no host fence in between.
+            with torch.cuda.stream(cstream):
+                hb.blue_noise.copy_(bn0)
+            if bn_pre:
+                hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre, sd.width * sd.height)
+            hb.render(spp, iter_stride=stride, iteration=first_it)
+            if use_comm:
+                pkg.dist.combine_means(hb.accum, spp, ctx=hb.ctx)
+            else:
+                hb.sync()                                   # host-staged fallback (gloo): ctx stream -> torch's stream
+                pkg.dist.combine_means(hb.accum, spp)
+                torch.cuda.synchronize(dev)
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        hb.kp.iteration = first_it
+        for _ in range(warmup):
+            one_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        st = hb.ctx.stats()                               # per-kernel HIP-event times of the LAST step (events on the ctx stream)
         if world > 1:
-            hb.sync()                                   # ctx stream -> visible to torch's stream
-            pkg.dist.combine_means(hb.accum, spp)
-            tstream.synchronize()                       # the next step's kernels overwrite accum
-
-    def fence():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        samples_per_step_rank = W * H * spp
+        value = samples_per_step_rank * world * steps / elapsed / 1e6
+        out = None
+        if rank == 0:
+            # ---- look-up counts: an untimed 2-iteration counted pass
+            hb.ctx.set_counting(True)
+            hb.blue_noise.copy_(bn0)
+            torch.cuda.synchronize(dev)
+            hb.render(2, iter_stride=stride, iteration=first_it)
+            hb.sync()
+            cs = hb.ctx.stats()
+            hb.ctx.set_counting(False)
+            step_s = elapsed / steps
+            roofline = roofline_block(cfg, W, H, spp, cs, st, samples_per_step_rank, step_s, sd.kp.integrator)
+            out = {
+                "metric": "Msamples/s (W*H*spp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
+                "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": data,
+                "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp,
+                           "parallelism": "iteration-striped x%d + 1 RCCL all-reduce under the C ABI" % world if world > 1 else "1 GPU",
+                           "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
+                "roofline": roofline,
+            }
+            if with_extras and world == 1 and not args.no_per_frame:
+                out["per_frame"] = per_frame(hb, sd, bn0, W, H)
+            if with_extras and world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(hb, sd, bn0, W, H, spp)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        hb.ctx.close()
+        del hb
+        torch.cuda.empty_cache()
+        return out
 
-    torch.cuda.synchronize(dev)
-    hb.kp.iteration = first_it
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        if world == 1:
-            pass
-    fence()
-    elapsed = time.perf_counter() - t0
-    # per-kernel HIP-event times of the LAST step (events live on the ctx stream the kernels run on)
-    st = hb.ctx.stats()
-    trace_ms, resolve_ms, raygen_ms, tail_ms = st.trace_ms, st.resolve_ms, st.raygen_ms, st.tail_ms
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    samples_per_step_rank = W * H * spp
-    total_samples = samples_per_step_rank * world * args.steps
-    value = total_samples / elapsed / 1e6
-
-    out = None
-    if rank == 0:
-        # ---- algorithmic bytes: counted on an untimed 2-iteration pass
-        hb.ctx.set_counting(True)
+    def per_frame(hb, sd, bn0, W, H):
+        """the literal drop-in call (main.cpp:1822-1829): one launch per iteration, device sync after every frame"""
         hb.blue_noise.copy_(bn0)
-        hb.render(2, iter_stride=stride, iteration=first_it)
-        hb.sync()
-        cs = hb.ctx.stats()
-        hb.ctx.set_counting(False)
-        n = float(cs.samples)
-        nd, nc, ne = cs.density_lookups / n, cs.color_lookups / n, cs.emission_lookups / n
-        b_trace = 32.0 * nd + 128.0 * nc + 32.0 * ne + 64.0     # + the 64-byte path record the trace kernel writes
-        b_survey = 32.0 * nd + 128.0 * nc + 32.0 * ne + 88.0    # SURVEY 8d figure (framebuffer term belongs to resolve)
-        kernel_name = "vpt::trace_vol_kernel" if sd.kp.integrator else "vpt::trace_kernel"
-        trace_s = trace_ms * 1e-3
-        achieved = b_trace * samples_per_step_rank / trace_s / 1e9 if trace_s > 0 else 0.0
-        roofline = {
-            "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "algorithmic_bytes_per_sample": round(b_trace, 2), "survey_8d_bytes_per_sample": round(b_survey, 2),
-            "density_lookups_per_sample": round(nd, 4), "tracking_steps_per_sample": round(cs.tracking_steps / n, 4),
-            "skip_steps_per_sample": round(cs.skip_steps / n, 4),
-            "raygen_ms_per_step": round(raygen_ms, 3), "trace_ms_per_step": round(trace_ms, 3),
-            "tail_resolve_ms_per_step": round(tail_ms + resolve_ms, 3),
-            "rays_traced_fraction": round(cs.queued_rays / float(W * H * min(2, spp)), 4),
-            "note": "achieved = algorithmic bytes (SURVEY 8d) x samples per launch / HIP-event time of the launch; traffic = HBM bytes per launch from "
-                    "the committed rocprofv3 PMC passes (profiles/), null when this configuration has not been profiled",
-        }
-        # measured HBM traffic of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # very command, corrected per MI355X_MICROARCH.md; tools/profile_bench.sh writes the file)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f).get(cfg)
-            if tj and tj.get("width") == W and tj.get("height") == H:
-                per_sample = tj["bytes_per_launch"] / float(tj["samples_per_launch"])
-                # iterations per tracer launch: the chunk rule of vpt_render_batch (<= 64 iterations, <= 16 GiB of records)
-                ipl = max(1, min(64, spp, (16 << 30) // (W * H * 64)))
-                launches = -(-spp // ipl)
-                roofline["traffic"] = round(per_sample * samples_per_step_rank / launches / 1e9, 4)
-                roofline["launches_per_step"] = launches
-                vk = (tj.get("valu") or {}).get(kernel_name)
-                if vk:      # what bounds this kernel in practice: vector-instruction issue, at this many active lanes
-                    roofline["valu_issue_busy"] = vk["valu_issue_busy"]
-                    roofline["active_lanes_per_valu_instruction"] = vk["active_lanes_per_valu_instruction"]
-                roofline["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
-        cpu = None
+        torch.cuda.synchronize(dev)
+        hb.kp.iteration = 0
+        for _ in range(4):
+            hb.render_frame()
+            hb.sync()
+        tf = time.perf_counter()
+        for _ in range(args.frames):
+            hb.render_frame()
+            hb.sync()
+        dt = time.perf_counter() - tf
+        st = hb.ctx.stats()
+        return {"value": round(W * H * args.frames / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(dt / args.frames * 1e3, 4),
+                "frames": args.frames, "kernels_ms_last_frame": {"raygen": round(st.raygen_ms, 4), "trace": round(st.trace_ms, 4), "tail_resolve": round(st.tail_ms, 4)},
+                "call": "vpt_render (iter_count 1) + vpt_sync per frame, as source/main.cpp:1822-1829"}
+
+    def cpu_baseline(hb, sd, bn0, W, H, spp):
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)
-        if not args.no_cpu_baseline and world == 1 and host_grids:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_binding
-            import ref_binding
-            cores = os.cpu_count() or 1
-            # the reference's own kernel source compiled for the CPU (oracle/_ref/libvptref.so, shipped prebuilt) when it
-            # is there, else the oracle restatement; both produce the same image bit for bit (tests/test_oracle_vs_ref.py)
-            use_ref = ref_binding.have_ref()
-            ob = ref_binding.RefBinding(sd) if use_ref else oracle_binding.OracleBinding(sd)
-            tc = time.perf_counter()
-            ob.render(args.cpu_iters, nthreads=cores)
-            dtc = time.perf_counter() - tc
-            what = ("reference render_kernel.cu built for the host (oracle/_ref, %d threads over pixels)" % cores) if use_ref \
-                else "oracle (OpenMP over rows)"
-            cpu = {"value": round(W * H * args.cpu_iters / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-                   "kind": "reference" if use_ref else "port",
-                   "sample": "%d of %d iterations of the same %dx%d frame, %s, %.1f s" % (args.cpu_iters, spp, W, H, what, dtc)}
-        out = {
-            "metric": "Msamples/s (W*H*spp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data,
-            "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp, "parallelism": "iteration-striped x%d + 1 all-reduce" % world,
-                       "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
+        if not host_grids:
+            return None
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding
+        import ref_binding
+        cores = os.cpu_count() or 1
+        # the reference's own kernel source compiled for the CPU (oracle/_ref/libvptref.so, shipped prebuilt) when it
+        # is there, else the oracle restatement; both produce the same image bit for bit (tests/test_oracle_vs_ref.py)
+        use_ref = ref_binding.have_ref()
+        ob = ref_binding.RefBinding(sd) if use_ref else oracle_binding.OracleBinding(sd)
+        tc = time.perf_counter()
+        ob.render(args.cpu_iters, nthreads=cores)
+        dtc = time.perf_counter() - tc
+        # the SAME iterations with the HIP path, into the same (reset) buffers: full-size parity of the headline frame
+        hb.blue_noise.copy_(bn0)
+        torch.cuda.synchronize(dev)
+        hb.render(args.cpu_iters, iteration=0)
+        hb.sync()
+        got, ref = hb.accum.cpu().numpy(), ob.accum
+        rel = float(np.sqrt(((got.astype(np.float64) - ref) ** 2).sum()) / max(1e-30, np.sqrt((ref.astype(np.float64) ** 2).sum())))
+        dgot, dref = hb.depth.cpu().numpy(), ob.depth
+        what = ("reference render_kernel.cu built for the host (oracle/_ref, %d threads over pixels)" % cores) if use_ref \
+            else "oracle (OpenMP over rows)"
+        return {"value": round(W * H * args.cpu_iters / dtc / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                "kind": "reference" if use_ref else "port",
+                "sample": "%d of %d iterations of the same %dx%d frame, %s, %.1f s" % (args.cpu_iters, spp, W, H, what, dtc),
+                "parity_rel_l2": rel, "parity_depth_max_abs_diff": float(np.abs(dgot - dref).max()),
+                "parity_depth_pixels_differing": int((dgot != dref).sum()),
+                "parity_note": "HIP accum / depth buffers vs this CPU render after the same %d iterations at full size (tolerance 1e-3 rel. L2)" % args.cpu_iters}
+
+    out = measure(cfg, spp, args.steps, args.warmup, args.width, args.height, True)
+    if world == 1 and not args.no_other_configs and cfg == "c2":
+        others = []
+        for oc in ("c3", "c4", "c5"):
+            o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False)
+            if o:
+                others.append({"config": o["config"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                               "warmup": o["warmup"], "data": o["data"], "roofline": o["roofline"]})
+        if out is not None:
+            out["other_configs"] = others
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

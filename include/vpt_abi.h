@@ -308,10 +308,36 @@ typedef struct vpt_render_stats {
     float              resolve_ms;        /* 0: the resolve is fused into the tail kernel */
     float              raygen_ms;         /* HIP-event time of raygen_kernel           */
     float              tail_ms;           /* HIP-event time of tail_resolve_kernel      */
+    /* trilinear fetches the tracer actually issued (counting renders): the look-up point lies inside the instance's
+     * domain and the value is used -- density / colour (float4 texels) / emission.  The N_* above are the reference-defined
+     * counts (every instance of the leaf at every step, :1003-1014, and the colour at every step, :1662). */
+    unsigned long long density_fetches;
+    unsigned long long color_fetches;
+    unsigned long long emission_fetches;
 } vpt_render_stats;
 /* enable/disable look-up counting (off by default: counting costs atomics) */
 int  vpt_set_counting(vpt_ctx *ctx, int enable);
 int  vpt_get_stats(vpt_ctx *ctx, vpt_render_stats *out);
+
+/* ---- multi-GPU (the reference is single-GPU, source/main.cpp:353) --------------------------
+ * One process (or thread) per GPU, one context each.  Rank r of G renders iterations r, r+G, ... of every pixel
+ * (vpt_render_batch with iter_stride = G after vpt_blue_noise_advance(r)); its accum buffer then holds the running
+ * mean of ITS n_local iterations.  vpt_allreduce_accum turns every rank's buffer into the job's mean,
+ *     accum <- sum_r n_r * accum_r / sum_r n_r,
+ * with ONE RCCL all-reduce over xGMI (the image and the iteration count travel in one grouped call), enqueued on
+ * `stream` (NULL = the context's stream) between a scale and a divide kernel -- no host synchronisation; a render
+ * issued afterwards on the same stream is ordered behind it.  RCCL (librccl.so) is loaded on the first vpt_comm_* call.
+ *   vpt_comm_unique_id: ncclGetUniqueId on ONE rank; the 128 bytes reach the other ranks by the host's own means
+ *                       (MPI, a file, torch.distributed's store: see INTEGRATION.md).
+ *   vpt_comm_init_rank: ncclCommInitRank for this context's device (collective: every rank calls it). */
+#define VPT_COMM_ID_BYTES 128
+int  vpt_comm_unique_id(unsigned char *out_id /* [VPT_COMM_ID_BYTES] */);
+int  vpt_comm_init_rank(vpt_ctx *ctx, int nranks, int rank, const unsigned char *id /* [VPT_COMM_ID_BYTES] */);
+int  vpt_comm_destroy(vpt_ctx *ctx);
+int  vpt_allreduce_accum(vpt_ctx *ctx, float *accum_device, unsigned long long n_floats, unsigned int n_local_iterations, void *stream);
+/* display_buffer / raw_buffer.xyz of kp from kp->accum_buffer as it is NOW (render_kernel.cu:2292-2316: ACES fit, gamma, 8-bit
+ * pack): a render tonemaps this rank's running mean, so after vpt_allreduce_accum the display image is refreshed with this. */
+int  vpt_resolve_display(vpt_ctx *ctx, const vpt_kernel_params *kp, void *stream);
 
 /* ---- atmosphere (prerequisite of the procedural sky) -----------------------------
  * vpt_atmosphere_default_model: the scalars atmosphere::atmosphere() + init() + update_model() leave in

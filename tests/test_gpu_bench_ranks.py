@@ -25,6 +25,11 @@ def test_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["config"]["spp_per_gpu"] == 4
+    # fixed total work: the job's 4 iterations split over the 2 ranks
+    r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["spp_per_gpu"] == 2 and d["value"] > 0
 
 
 def test_striped_ranks_equal_single_rank(pkg):
@@ -50,7 +55,7 @@ def test_striped_ranks_equal_single_rank(pkg):
 def test_single_rank_bench_line_contract():
     """the N = 1 bench line: every key of the contract, the roofline object and the CPU baseline leg"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
-           "--spp", "4", "--cpu-iters", "1"]
+           "--spp", "4", "--cpu-iters", "2", "--frames", "4", "--grid-scale", "0.125"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -66,7 +71,62 @@ def test_single_rank_bench_line_contract():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    for k in ("frac_kernel", "frac_step", "hbm_measured_frac", "frac_step_reference_counts"):
+        assert k in rf, k
+    assert 0 < rf["frac_kernel"] < 1 and 0 < rf["frac_step"] < 1
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    # full-frame parity of the same iterations: HIP vs the CPU render (the reference's kernel where oracle/_ref exists)
+    assert cb["parity_rel_l2"] <= 1e-3 and cb["parity_depth_pixels_differing"] == 0
+    # the literal drop-in call and the other BASELINE configs travel in the same line
+    pf = d["per_frame"]
+    assert pf["value"] > 0 and pf["frames"] == 4 and pf["ms_per_frame"] > 0
+    oc = d["other_configs"]
+    assert len(oc) == 3
+    for o in oc:
+        assert o["value"] > 0 and "workload" in o["config"] and 0 < o["roofline"]["frac"] < 1 and 0 < o["roofline"]["frac_step"] < 1
+
+
+def test_c_abi_allreduce_single_rank(pkg):
+    """vpt_comm_* / vpt_allreduce_accum (RCCL loaded at run time, below the C ABI) on a one-rank communicator: the scale ->
+    grouped all-reduce -> divide chain on the context's stream returns the rank's own mean, and vpt_resolve_display
+    reproduces the display image the batch wrote.  (Two ranks cannot share the single GPU of this box: RCCL rejects
+    duplicate devices; the 2-rank image identity is covered by test_striped_ranks_equal_single_rank and, through gloo,
+    tests/test_dist_gloo.py; tools/vpt_cli --ranks and bench.py --gpus N run the same entry points on N GPUs.)"""
+    import torch
+    sd = pkg.scene.dragon_scene(160, 90, "sun")
+    hb = pkg.scene.HipBinding(sd, device=0)
+    hb.ctx.comm_init(1, 0, hb.ctx.comm_unique_id())
+    hb.render(5)
+    hb.sync()
+    before, disp = hb.accum.clone(), hb.display.clone()
+    pkg.dist.combine_means(hb.accum, 5, ctx=hb.ctx)                 # C-ABI path (the context has a communicator)
+    hb.display.zero_()
+    torch.cuda.synchronize()
+    hb.ctx.resolve_display(hb.kp)
+    hb.sync()
+    np.testing.assert_allclose(hb.accum.cpu().numpy(), before.cpu().numpy(), rtol=3e-7, atol=0)      # (5 x) / 5: at most one rounding each way
+    d0, d1 = disp.cpu().numpy().view(np.uint8).astype(np.int32), hb.display.cpu().numpy().view(np.uint8).astype(np.int32)
+    assert np.abs(d0 - d1).max() <= 1
+    hb.ctx.comm_destroy()
+    with pytest.raises(pkg.VptError):
+        hb.ctx.allreduce_accum(hb.accum, 5)                         # no communicator any more: an error, not a silent no-op
+
+
+def test_cli_two_ranks_equal_one(pkg, tmp_path):
+    """the C++ host on 2 GPUs (threads, one context each, RCCL all-reduce under the C ABI) == the same job on 1 GPU"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import test_gpu_cli as tc
+    d = str(tmp_path)
+    tc._write_assets(pkg, d)
+    imgs = []
+    for ranks in (1, 2):
+        out = os.path.join(d, "r%d" % ranks)
+        info = tc._run(pkg, [os.path.join(d, "dragon.vdb"), "--assets", d, "--size", "160", "90", "--spp", "8", "--out", out, "--ranks", str(ranks)])
+        assert info["ranks"] == ranks
+        imgs.append(tc._read_pfm(out + ".pfm"))
+    np.testing.assert_allclose(imgs[0], imgs[1], rtol=2e-5, atol=1e-7)

@@ -12,7 +12,10 @@
 //     --sun AZ EL         degrees                                                       (default 120 30)
 //     --fov F --aperture A --density-mult D --emission-scale E --g G --ray-depth N --volume-depth N
 //     --out PREFIX        writes PREFIX.pfm (linear accum) and PREFIX.ppm (display)     (default render)
-//     --device N
+//     --device N          first device
+//     --ranks G           render on G GPUs (devices N .. N+G-1), one host thread + one context each: rank r renders
+//                         iterations r, r+G, ... (spp / G of them) and the images are combined with ONE RCCL all-reduce
+//                         under the C ABI (vpt_allreduce_accum); rank 0 writes the result           (default 1)
 // Main-loop mapping: load grids (main.cpp:1283-1303) -> octree (:1313) -> camera (:1321, "F" framing
 // :526-543) -> Kernel_params defaults (:1350-1376) -> LUT textures (:1383-1402) -> atmosphere init
 // (:1469-1472) -> create_cdf (:1461) -> launches (:1822-1829) -> save (:1583-1650).
@@ -23,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vpt_abi.h"
@@ -50,6 +54,15 @@ static bool ends_with(const std::string& s, const char* suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+struct Options {
+    std::string scene, assets = "./assets", env, lights_file, out = "render";
+    int W = 1920, H = 1080, spp = 64, device = 0, ranks = 1;
+    float fov = 30.0f, aperture = 0.0f;
+    vpt_kernel_params kp;
+};
+
+static int render_rank(const Options& opt, int rank, const unsigned char* comm_id);
+
 int main(int argc, char** argv) {
     vpt_ctx* ctx = nullptr;
     if (argc < 2) {
@@ -58,10 +71,12 @@ int main(int argc, char** argv) {
                         "[--ray-depth N] [--volume-depth N] [--out PREFIX] [--device N]\n");
         return 2;
     }
-    std::string scene = argv[1], assets = "./assets", env, lights_file, out = "render";
-    int W = 1920, H = 1080, spp = 64, device = 0;
-    float fov = 30.0f, aperture = 0.0f;
-    vpt_kernel_params kp;
+    Options opt;
+    opt.scene = argv[1];
+    std::string &scene = opt.scene, &assets = opt.assets, &env = opt.env, &lights_file = opt.lights_file, &out = opt.out;
+    int &W = opt.W, &H = opt.H, &spp = opt.spp, &device = opt.device;
+    float &fov = opt.fov, &aperture = opt.aperture;
+    vpt_kernel_params& kp = opt.kp;
     vpt_kernel_params_default(&kp);
     kp.max_interactions = 1u << 30;
     for (int i = 2; i < argc; ++i) {
@@ -85,11 +100,35 @@ int main(int argc, char** argv) {
         else if (a == "--volume-depth") { need(1); kp.volume_depth = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--ranks") { need(1); opt.ranks = atoi(argv[++i]); }
         else { fprintf(stderr, "vpt_cli: unknown option %s\n", a.c_str()); return 2; }
     }
     if (W <= 0 || H <= 0 || spp <= 0) { fprintf(stderr, "vpt_cli: bad --size / --spp\n"); return 2; }
+    if (opt.ranks < 1 || spp % opt.ranks != 0) { fprintf(stderr, "vpt_cli: --ranks must divide --spp\n"); return 2; }
+    (void)ctx; (void)scene; (void)assets; (void)env; (void)lights_file; (void)out; (void)fov; (void)aperture; (void)device;
+    if (opt.ranks == 1) return render_rank(opt, 0, nullptr);
+    // one host thread per GPU; the RCCL id is made once and shared in-process (a multi-process host would ship the
+    // 128 bytes over its own channel)
+    unsigned char id[VPT_COMM_ID_BYTES];
+    if (vpt_comm_unique_id(id) != VPT_OK) { fprintf(stderr, "vpt_cli: vpt_comm_unique_id: %s\n", vpt_last_error(nullptr)); return 1; }
+    std::vector<int> rc((size_t)opt.ranks, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < opt.ranks; ++r) th.emplace_back([&, r] { rc[(size_t)r] = render_rank(opt, r, id); });
+    for (auto& t : th) t.join();
+    for (int r : rc)
+        if (r != 0) return r;
+    return 0;
+}
+
+static int render_rank(const Options& opt, int rank, const unsigned char* comm_id) {
+    vpt_ctx* ctx = nullptr;
+    const std::string &scene = opt.scene, &assets = opt.assets, &env = opt.env, &lights_file = opt.lights_file, &out = opt.out;
+    const int W = opt.W, H = opt.H, spp = opt.spp, ranks = opt.ranks, device = opt.device + rank;
+    const float fov = opt.fov, aperture = opt.aperture;
+    vpt_kernel_params kp = opt.kp;
 
     CHECK(vpt_create(device, &ctx));
+    if (ranks > 1) CHECK(vpt_comm_init_rank(ctx, ranks, rank, comm_id));
 
     // ---- volumes: one file or an instance file (main.cpp:1283-1303, 980-1102) --------------------------
     std::vector<vpt_gpu_vdb> instances;
@@ -187,11 +226,24 @@ int main(int argc, char** argv) {
 
     // ---- render: `spp` launches of volume_rt_kernel (main.cpp:1822-1829) -----------------------------------------
     vpt_light_list ll = {(unsigned)lights.size(), lights.empty() ? nullptr : lights.data()};
-    kp.iteration = 0;
+    // rank r of G: iterations r, r+G, ... with the blue-noise table advanced r steps; G = 1: all of them
+    kp.iteration = (unsigned)rank;
     const auto t0 = std::chrono::steady_clock::now();
-    CHECK(vpt_render_batch(ctx, &cam, &ll, &sph, &atm, &kp, (unsigned)spp, 1, nullptr));
+    if (rank > 0) CHECK(vpt_blue_noise_advance(ctx, kp.blue_noise_buffer, (unsigned)rank, (unsigned)n, nullptr));
+    CHECK(vpt_render_batch(ctx, &cam, &ll, &sph, &atm, &kp, (unsigned)(spp / ranks), (unsigned)ranks, nullptr));
+    if (ranks > 1) {
+        // the one collective of the path, then the display image of the JOB's mean (the batch tonemapped this rank's)
+        CHECK(vpt_allreduce_accum(ctx, (float*)d_accum, (unsigned long long)n * 3ull, (unsigned)(spp / ranks), nullptr));
+        CHECK(vpt_resolve_display(ctx, &kp, nullptr));
+    }
     CHECK(vpt_sync(ctx));
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rank != 0) {
+        for (vpt_io_volume* v : files) vpt_io_vdb_free(v);
+        vpt_io_free(bn); vpt_io_free(bb); vpt_io_free(dc);
+        vpt_destroy(ctx);
+        return 0;
+    }
 
     // ---- save (main.cpp:1583-1650: linear image + display image) ------------------------------------------------------
     std::vector<float> accum(n * 3);
@@ -206,9 +258,9 @@ int main(int argc, char** argv) {
     float mx, mn;
     vpt_scene_get_root(ctx, &lo, &hi, &mx, &mn);
     printf("{\"scene\": \"%s\", \"instances\": %zu, \"width\": %d, \"height\": %d, \"spp\": %d, \"integrator\": %d, \"environment_type\": %u, "
-           "\"render_s\": %.6f, \"msamples_per_s\": %.3f, \"precompute_s\": %.3f, \"mean\": %.6g, \"max_extinction\": %g, "
+           "\"ranks\": %d, \"render_s\": %.6f, \"msamples_per_s\": %.3f, \"precompute_s\": %.3f, \"mean\": %.6g, \"max_extinction\": %g, "
            "\"camera_dist\": %g, \"out\": \"%s.pfm\"}\n",
-           scene.c_str(), instances.size(), W, H, spp, kp.integrator, kp.environment_type, s, (double)n * spp / s / 1e6, pre_s,
+           scene.c_str(), instances.size(), W, H, spp, kp.integrator, kp.environment_type, ranks, s, (double)n * spp / s / 1e6, pre_s,
            mean / (double)(n * 3), mx, dist, out.c_str());
     for (vpt_io_volume* v : files) vpt_io_vdb_free(v);
     vpt_io_free(bn); vpt_io_free(bb); vpt_io_free(dc);

@@ -93,6 +93,10 @@ struct Counters {
     // [3] distinct 4x4x4 bricks, [4] distinct 128-byte lines over one lane's 8 taps summed over lanes,
     // [5] distinct 128-byte lines over ALL taps of the wave (what one gather pass asks the L1 for)
     unsigned long long coh[8];
+    // trilinear fetches actually issued (the point lies inside the instance's look-up domain and the value is used):
+    // [0] density, [1] colour (float4 texels), [2] emission -- what the tracer really moves, as opposed to the
+    // reference-defined look-up counts above (one per instance of the leaf and step, fetched or not)
+    unsigned long long fetches[4];
 };
 
 #ifndef VPT_SUB

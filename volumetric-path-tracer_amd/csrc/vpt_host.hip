@@ -8,6 +8,8 @@
 // No CPU fallback exists: every render entry point needs a gfx950 device and fails with
 // VPT_E_NO_DEVICE / VPT_E_HIP otherwise.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +29,7 @@ hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool e
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream);
+hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
 
@@ -91,6 +94,22 @@ struct vpt_ctx {
     DPointLight* d_lights = nullptr;
     size_t lights_capacity = 0;
     std::vector<DPointLight> lights_cache;
+    // multi-GPU: one RCCL communicator per context (vpt_comm_init_rank); librccl.so is loaded on first use, so a
+    // single-GPU host never maps it
+    ncclComm_t comm = nullptr;
+    int comm_nranks = 0, comm_rank = 0;
+    float* d_comm_count = nullptr;         // 1 float: this rank's iteration count, summed over ranks next to the image
+    // tuning / test switches, read from the environment ONCE, when the context is created (vpt_create)
+    size_t brick_min_bytes = (size_t)192 << 20;   // VPT_BRICK_MIN_BYTES: density grids below this stay un-bricked
+    bool force_no_addr24 = false;          // VPT_NO_ADDR24: tests force the 32-bit texel index arithmetic
+    unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
+    bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
+    bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
+    // camera-point scattering table: rebuilt only when its inputs change (per-frame calls reuse it)
+    float cam_tab_key[46] = {0};
+    const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool cam_tab_built = false;
+    bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
     // stats
     bool counting = false;
     std::vector<hipEvent_t> ev_pool;
@@ -276,6 +295,11 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = ctx->trans_min_vol = (uint32_t)std::atoi(trm);
+    if (const char* e = std::getenv("VPT_BRICK_MIN_BYTES")) ctx->brick_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    ctx->force_no_addr24 = std::getenv("VPT_NO_ADDR24") != nullptr;
+    if (const char* e = std::getenv("VPT_BATCH_ITERS")) ctx->batch_iters = std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 0u;
+    ctx->no_heads = std::getenv("VPT_NO_HEADS") != nullptr;
+    ctx->no_cam_table = std::getenv("VPT_NO_CAM_TABLE") != nullptr;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
@@ -295,6 +319,8 @@ void vpt_destroy(vpt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)vpt_comm_destroy(ctx);
+    (void)hipFree(ctx->d_comm_count);
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
@@ -410,8 +436,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (void* b : ctx->bricked) (void)hipFree(b);
     ctx->bricked.clear();
-    size_t brick_min = (size_t)192 << 20;                 // grids below this stay L2 / Infinity-Cache resident anyway
-    if (const char* e = std::getenv("VPT_BRICK_MIN_BYTES")) brick_min = (size_t)std::strtoull(e, nullptr, 10);
+    const size_t brick_min = ctx->brick_min_bytes;        // grids below this stay L2 / Infinity-Cache resident anyway
     std::vector<std::pair<const float*, const float*>> brick_cache;     // instances share their file's grid
     for (int i = 0; i < num_volumes; ++i) {
         const vpt_vdb_info& vi = volumes[i].vdb_info;
@@ -475,7 +500,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             const int ddim[3] = {vi.dim.x, vi.dim.y, vi.dim.z};
             bool ok = fits(ddim) && fits(d.edim) && fits(d.cdim);
             if (d.bricked) ok = ok && (long long)d.bdim[0] * d.bdim[1] * 64 < (1 << 24);
-            if (std::getenv("VPT_NO_ADDR24")) ok = false;        // tests: force the 32-bit index arithmetic
+            if (ctx->force_no_addr24) ok = false;                // tests: force the 32-bit index arithmetic
             d.addr24 = ok ? 1 : 0;
         }
         // xform.transpose().inverse(), evaluated once with the operand order of
@@ -667,6 +692,9 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         out->emission_lookups = c.emission_lookups;
         out->tracking_steps = c.tracking_steps;
         out->skip_steps = c.skip_steps;
+        out->density_fetches = c.fetches[0];
+        out->color_fetches = c.fetches[1];
+        out->emission_fetches = c.fetches[2];
     }
     return VPT_OK;
 }
@@ -687,6 +715,134 @@ int vpt_test_get_coherence(vpt_ctx* ctx, unsigned long long out[8]) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memcpy(out, c.coh, sizeof(c.coh));
+    return VPT_OK;
+}
+
+// ---- multi-GPU: the one collective of the path, below the C ABI ---------------------------------------
+// (iteration striping, every rank holds the running mean of ITS iterations; the image of the job is
+//  sum_r n_r mean_r / sum_r n_r.)  RCCL is bound at run time: libvpt_hip.so itself does not link librccl.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+bool rccl_load(vpt_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_rccl_mutex);
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) {
+        set_error(ctx, "vpt_comm: cannot load librccl.so (%s)", dlerror());
+        return false;
+    }
+    RcclApi a;
+    a.lib = h;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        set_error(ctx, "vpt_comm: librccl.so lacks an expected symbol");
+        dlclose(h);
+        return false;
+    }
+    g_rccl = a;
+    return true;
+}
+#define RCCLCHK(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) {                                                                             \
+            set_error(ctx, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__);   \
+            return VPT_E_HIP;                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+// accum[i] *= n (weighted sum of this rank), count[0] = n
+__global__ void comm_scale_kernel(float* __restrict__ accum, size_t n_floats, float n, float* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) count[0] = n;
+    if (i < n_floats) accum[i] *= n;
+}
+// accum[i] /= count[0] (IEEE divide: this file is built strict)
+__global__ void comm_divide_kernel(float* __restrict__ accum, size_t n_floats, const float* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_floats) accum[i] = accum[i] / count[0];
+}
+}  // namespace
+
+int vpt_comm_unique_id(unsigned char* out_id) {
+    if (!out_id) return VPT_E_INVALID;
+    if (!rccl_load(nullptr)) return VPT_E_UNSUPPORTED;
+    static_assert(VPT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    RCCLCHK(nullptr, g_rccl.GetUniqueId(&id));
+    std::memcpy(out_id, id.internal, VPT_COMM_ID_BYTES);
+    return VPT_OK;
+}
+
+int vpt_comm_init_rank(vpt_ctx* ctx, int nranks, int rank, const unsigned char* id_bytes) {
+    if (!ctx || !id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return VPT_E_INVALID;
+    if (ctx->comm) {
+        set_error(ctx, "vpt_comm_init_rank: the context already has a communicator (vpt_comm_destroy first)");
+        return VPT_E_INVALID;
+    }
+    if (!rccl_load(ctx)) return VPT_E_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_bytes, VPT_COMM_ID_BYTES);
+    RCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
+    if (!ctx->d_comm_count) HIPCHK(ctx, hipMalloc(&ctx->d_comm_count, 64));
+    return VPT_OK;
+}
+
+int vpt_comm_destroy(vpt_ctx* ctx) {
+    if (!ctx) return VPT_E_INVALID;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_nranks = 0;
+    }
+    return VPT_OK;
+}
+
+int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats, unsigned int n_local_iterations, void* stream_v) {
+    if (!ctx || !accum || n_floats == 0) return VPT_E_INVALID;
+    if (!ctx->comm) {
+        set_error(ctx, "vpt_allreduce_accum: no communicator (vpt_comm_init_rank)");
+        return VPT_E_NOT_READY;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const unsigned blocks = (unsigned)((n_floats + 255ull) / 256ull);
+    // everything on ONE stream, in order: weighted sum of this rank -> one grouped all-reduce (image + iteration count)
+    // -> divide.  No host synchronisation: the next render on the same stream simply queues behind it.
+    hipLaunchKernelGGL(comm_scale_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, (float)n_local_iterations, ctx->d_comm_count);
+    HIPCHK(ctx, hipGetLastError());
+    RCCLCHK(ctx, g_rccl.GroupStart());
+    RCCLCHK(ctx, g_rccl.AllReduce(accum, accum, (size_t)n_floats, ncclFloat32, ncclSum, ctx->comm, stream));
+    RCCLCHK(ctx, g_rccl.AllReduce(ctx->d_comm_count, ctx->d_comm_count, 1, ncclFloat32, ncclSum, ctx->comm, stream));
+    RCCLCHK(ctx, g_rccl.GroupEnd());
+    hipLaunchKernelGGL(comm_divide_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, ctx->d_comm_count);
+    HIPCHK(ctx, hipGetLastError());
     return VPT_OK;
 }
 
@@ -901,8 +1057,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (chunk < 1) chunk = 1;
     if (chunk > 64) chunk = 64;
     if (chunk > iter_count) chunk = iter_count;
-    const char* env_chunk = std::getenv("VPT_BATCH_ITERS");
-    if (env_chunk && std::atoi(env_chunk) > 0) chunk = std::min<size_t>((size_t)std::atoi(env_chunk), iter_count);
+    if (ctx->batch_iters > 0) chunk = std::min<size_t>((size_t)ctx->batch_iters, iter_count);
     if (ctx->records_capacity < chunk * per_iter) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
@@ -927,7 +1082,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // compact sample heads: a sample whose primary ray starts no walk needs its direction and depth only -- plus its
     // origin when the lens is open; with lens_radius == 0 every primary ray starts exactly at the camera origin
     // (camera.h:131-136: offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0)
-    const bool compact = !std::getenv("VPT_NO_HEADS");
+    const bool compact = !ctx->no_heads;
     P.heads = compact ? ctx->d_heads : nullptr;
     P.head_org = nullptr;
     if (compact && cam->lens_radius != 0.0f) {
@@ -949,17 +1104,35 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     R.records = ctx->d_records;
 
     // camera-point scattering table (vpt_sky.h): valid for samples whose env_pos is the camera origin
-    if (R.has_atmosphere && !std::getenv("VPT_NO_CAM_TABLE")) {
+    if (R.has_atmosphere && !ctx->no_cam_table) {
         if (!ctx->d_cam_tab) HIPCHK(ctx, hipMalloc(&ctx->d_cam_tab, sizeof(float4) * 8 * 128 * 2));
         R.cam_tab = ctx->d_cam_tab;
         R.cam_tab_pos[0] = cam->origin.x; R.cam_tab_pos[1] = cam->origin.y; R.cam_tab_pos[2] = cam->origin.z;
-        HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_cam_tab, stream));
+        // the table is a function of the view point, the sun direction, the model scalars and the two 4-D tables: a frame
+        // loop that changes none of them (main.cpp:1822-1829, one launch per iteration) builds it once
+        float key[46];
+        std::memcpy(key, R.cam_tab_pos, sizeof(float) * 3);
+        std::memcpy(key + 3, R.sun_dir, sizeof(float) * 3);
+        std::memcpy(key + 6, R.atm_f, sizeof(float) * 40);
+        const void* tex[4] = {R.transmittance_tex.data, R.scattering_tex.data, R.irradiance_tex.data, R.single_mie_tex.data};
+        if (!ctx->cam_tab_built || std::memcmp(key, ctx->cam_tab_key, sizeof(key)) != 0 || std::memcmp(tex, ctx->cam_tab_tex, sizeof(tex)) != 0) {
+            HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_cam_tab, stream));
+            std::memcpy(ctx->cam_tab_key, key, sizeof(key));
+            std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
+            ctx->cam_tab_built = true;
+        }
         R.cam_tab_valid = 1;
     }
     ctx->spans.clear();
     ctx->ev_used = 0;
     ctx->last_samples = 0;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), stream));
+#ifdef VPT_PROFILE_SECTIONS
+    ctx->counters_dirty = true;                           // section-timing builds write cycle sums on every render
+#endif
+    if (ctx->counting || ctx->counters_dirty) {           // the look-up counters are only written by counting renders
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), stream));
+        ctx->counters_dirty = ctx->counting;
+    }
 
     const bool multi = P.num_volumes > 1;
     const bool color = ctx->any_color;
@@ -1012,6 +1185,17 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
 int vpt_render(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* lights, const vpt_sphere* ref_sphere,
                const vpt_atmosphere_parameters* atmosphere, const vpt_kernel_params* kernel_params, void* stream) {
     return vpt_render_batch(ctx, cam, lights, ref_sphere, atmosphere, kernel_params, 1, 1, stream);
+}
+
+int vpt_resolve_display(vpt_ctx* ctx, const vpt_kernel_params* kp, void* stream_v) {
+    if (!ctx || !kp || !kp->accum_buffer) return VPT_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const unsigned long long n = (unsigned long long)kp->resolution.x * kp->resolution.y;
+    if (n == 0 || n > 0xffffffffull) return VPT_E_INVALID;
+    HIPCHK(ctx, launch_display(reinterpret_cast<const float*>(kp->accum_buffer), kp->display_buffer, reinterpret_cast<float*>(kp->raw_buffer), (uint32_t)n,
+                               kp->exposure_scale, stream));
+    return VPT_OK;
 }
 
 int vpt_blue_noise_advance(vpt_ctx* ctx, vpt_float3* blue_noise_buffer, unsigned int steps, unsigned int num_pixels, void* stream_v) {

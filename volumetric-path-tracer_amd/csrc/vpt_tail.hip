@@ -26,6 +26,23 @@ VPT_D f3 rtt_and_odt_fit(f3 v) {                                                
     return mk3(__fdiv_rn(a.x, b.x), __fdiv_rn(a.y, b.y), __fdiv_rn(a.z, b.z));
 }
 
+// ACES fit + gamma + 8-bit pack of a mean (:2292-2316); returns the linear display value (raw.xyz)
+VPT_D f3 tonemap(f3 acc, float exposure_scale, unsigned int& packed) {
+    f3 val = mk3(0.59719f * acc.x + 0.35458f * acc.y + 0.04823f * acc.z,
+                 0.07600f * acc.x + 0.90834f * acc.y + 0.01566f * acc.z,
+                 0.02840f * acc.x + 0.13383f * acc.y + 0.83777f * acc.z);
+    val = rtt_and_odt_fit(val);
+    val = mk3(1.60475f * val.x + -0.53108f * val.y + -0.07367f * val.z,
+              -0.10208f * val.x + 1.10813f * val.y + -0.00605f * val.z,
+              -0.00327f * val.x + -0.07276f * val.y + 1.07602f * val.z) * exposure_scale;
+    const float ig = (float)(1.0 / 2.2);
+    const unsigned int r = (unsigned int)(255.0f * fmin_(powf(fmax_(val.x, 0.0f), ig), 1.0f));
+    const unsigned int g = (unsigned int)(255.0f * fmin_(powf(fmax_(val.y, 0.0f), ig), 1.0f));
+    const unsigned int b = (unsigned int)(255.0f * fmin_(powf(fmax_(val.z, 0.0f), ig), 1.0f));
+    packed = 0xff000000u | (r << 16) | (g << 8) | b;
+    return val;
+}
+
 // stage 3 (last): one thread per PIXEL walks the batch's path records in iteration order:
 //   environment tail of the integrator (direct :1838-1850 / vol :1752)  -> sample value
 //   NaN/Inf guard (:2263-2264), viz_dof tint (:2266-2274), running means (:2278-2287)
@@ -127,21 +144,26 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     if (R.depth) R.depth[idx] = dep;
 
     if (R.display || R.raw) {
-        // :2292-2316
-        f3 val = mk3(0.59719f * acc.x + 0.35458f * acc.y + 0.04823f * acc.z,
-                     0.07600f * acc.x + 0.90834f * acc.y + 0.01566f * acc.z,
-                     0.02840f * acc.x + 0.13383f * acc.y + 0.83777f * acc.z);
-        val = rtt_and_odt_fit(val);
-        val = mk3(1.60475f * val.x + -0.53108f * val.y + -0.07367f * val.z,
-                  -0.10208f * val.x + 1.10813f * val.y + -0.00605f * val.z,
-                  -0.00327f * val.x + -0.07276f * val.y + 1.07602f * val.z) * R.exposure_scale;
-        const float ig = (float)(1.0 / 2.2);
-        const unsigned int r = (unsigned int)(255.0f * fmin_(powf(fmax_(val.x, 0.0f), ig), 1.0f));
-        const unsigned int g = (unsigned int)(255.0f * fmin_(powf(fmax_(val.y, 0.0f), ig), 1.0f));
-        const unsigned int b = (unsigned int)(255.0f * fmin_(powf(fmax_(val.z, 0.0f), ig), 1.0f));
-        if (R.display) R.display[idx] = 0xff000000u | (r << 16) | (g << 8) | b;
+        unsigned int packed;
+        const f3 val = tonemap(acc, R.exposure_scale, packed);
+        if (R.display) R.display[idx] = packed;
         if (R.raw) reinterpret_cast<float4*>(R.raw)[idx] = make_float4(val.x, val.y, val.z, tr_last);
     }
+}
+
+// display / raw images of an accumulation buffer that was changed outside the render (vpt_allreduce_accum: the batch
+// tonemapped this rank's running mean, the job's mean arrives afterwards); raw.w (alpha of the last iteration) is kept
+__global__ void display_kernel(const float* __restrict__ accum, unsigned int* __restrict__ display, float4* __restrict__ raw, uint32_t n, float exposure_scale) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    unsigned int packed;
+    const f3 val = tonemap(mk3(accum[3 * idx], accum[3 * idx + 1], accum[3 * idx + 2]), exposure_scale, packed);
+    if (display) display[idx] = packed;
+    if (raw) { raw[idx].x = val.x; raw[idx].y = val.y; raw[idx].z = val.z; }
+}
+hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream) {
+    hipLaunchKernelGGL(display_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, accum, display, reinterpret_cast<float4*>(raw), n, exposure_scale);
+    return hipGetLastError();
 }
 
 // camera-point scattering table (vpt_sky.h): 8 nu slices x 128 mu rows, one thread per entry

@@ -101,22 +101,29 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
         if (x < (int)P.width && y < (int)P.height) {
             const uint32_t pixel = (uint32_t)y * P.width + (uint32_t)x;
             s = kiter * P.n_pixels + pixel;
-            Rng rng;
-            rng_init(rng, pixel, iteration * 4096u);
-            uint32_t draws = 0;
             const float2 bn = P.blue_noise[(size_t)kiter * 65536 + (y % 256) * 256 + (x % 256)];
             const float u = (float)(x + bn.x) / (float)P.width;
             const float v = (float)(y + bn.y) / (float)P.height;
-            // camera::get_ray, camera.h:131-136
-            f3 pd;
-            do {
-                float a = van_der_corput(P.vdc_tables, rng, pixel, draws);
-                float b = van_der_corput(P.vdc_tables + 101, rng, pixel, draws);
-                pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
-            } while (dot(pd, pd) >= 1.0f);
-            const f3 rdk = P.cam.lens_radius * pd;
-            const f3 offset = ld3(P.cam.u) * rdk.x + ld3(P.cam.v) * rdk.y;
-            (void)rnd_simple(rng, pixel, draws);                          // the `time` draw
+            // camera::get_ray, camera.h:131-136.  With a closed lens (lens_radius == 0) the lens sample is multiplied by zero:
+            // offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0, so the ray does not depend on the stream at all -- it is built
+            // and tested first, and only a ray that goes on to the tracer (41 % of config 2) pays for the Philox block(s)
+            // and the rejection loop that position its stream behind get_ray's draws.
+            Rng rng;
+            uint32_t draws = 0;
+            const bool closed = P.cam.lens_radius == 0.0f;
+            f3 offset = mk3(0.0f);
+            if (!closed) {
+                rng_init(rng, pixel, iteration * 4096u);
+                f3 pd;
+                do {
+                    float a = van_der_corput(P.vdc_tables, rng, pixel, draws);
+                    float b = van_der_corput(P.vdc_tables + 101, rng, pixel, draws);
+                    pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
+                } while (dot(pd, pd) >= 1.0f);
+                const f3 rdk = P.cam.lens_radius * pd;
+                offset = ld3(P.cam.u) * rdk.x + ld3(P.cam.v) * rdk.y;
+                (void)rnd_simple(rng, pixel, draws);                          // the `time` draw
+            }
             const f3 org0 = ld3(P.cam.origin) + offset;
             const f3 B = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - ld3(P.cam.origin) - offset;
             const f3 dir0 = normalize(B);
@@ -131,6 +138,16 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                 // the sphere does; depth_calculator (:1875) still uses get_closest_object
                 float t_far;
                 traced = rendered && box_intersect(ld3(P.root_pmin), ld3(P.root_pmax), org0, inv0, t_box, t_far);
+            }
+            if (closed && traced) {
+                rng_init(rng, pixel, iteration * 4096u);
+                f3 pd;
+                do {
+                    float a = van_der_corput(P.vdc_tables, rng, pixel, draws);
+                    float b = van_der_corput(P.vdc_tables + 101, rng, pixel, draws);
+                    pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
+                } while (dot(pd, pd) >= 1.0f);
+                (void)rnd_simple(rng, pixel, draws);                          // the `time` draw
             }
             // :1883-1888: sphere first -> depth is the distance to it
             const float depth = (obj == 2) ? length(org0 - (org0 + dir0 * t_hit)) : 0.0f;

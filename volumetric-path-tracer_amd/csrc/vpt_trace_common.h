@@ -315,7 +315,14 @@ VPT_D void stage_emission_lut(const TraceParams& P) {
 }
 
 // one volume's contribution at world position p (get_density / get_color / get_emission)
-template <bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24>
+// FC (counting builds): tally the trilinear fetches actually ISSUED (point inside the instance's domain, value wanted),
+// wave-aggregated, into Counters::fetches -- the bytes the kernel really has to move, next to the reference-defined
+// look-up counts n_d / n_c / n_e
+VPT_D void count_fetch(const TraceParams& P, int which, bool issued) {
+    const unsigned long long m = __ballot(issued);
+    if (m != 0ull && __lane_id() == __ffsll((long long)m) - 1) atomicAdd(&P.counters->fetches[which], (unsigned long long)__popcll(m));
+}
+template <bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool FC = COUNT>
 VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v, f3 p, bool want_density, bool want_color, bool want_emission,
                          float& density, f3& color, f3& emission, uint32_t& n_d, uint32_t& n_c, uint32_t& n_e, bool count_color = false) {
     f3 u;
@@ -325,6 +332,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
     // coordinates
     if (want_density) {
         if (COUNT) n_d++;
+        if (FC) count_fetch(P, 0, inside);
         if (inside) {
             const Taps t = make_taps(v.dim, u);
             density += v.bricked ? fetch_f32_bricked<A24>(v.density, v, t) : fetch_f32<A24>(v.density, v.dim, t);
@@ -336,6 +344,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             color = fmax3(color, mk3(1.0f));
         } else {
             if (COUNT) n_c++;
+            if (FC) count_fetch(P, 1, inside);
             f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, u)) : mk3(0.0f);
             color = fmax3(color, c);
         }
@@ -343,6 +352,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
     if (EMIT && want_emission) {
         if (v.has_emission) {
             if (COUNT) n_e++;
+            if (FC) count_fetch(P, 2, inside);
             if (inside) {
                 float index = fetch_f32<A24>(v.emission, v.edim, make_taps(v.edim, u));
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);

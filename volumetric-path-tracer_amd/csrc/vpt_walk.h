@@ -288,7 +288,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         if (EMIT && is_emit && P.vol0.has_emission) c.n_e += n_leaf;
         uint32_t z0 = 0, z1 = 0, z2 = 0;
         for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) {
-            lookup_volume<COLOR, EMIT, false, ELDS, A24>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, z0, z1, z2, false);
+            lookup_volume<COLOR, EMIT, false, ELDS, A24, true>(P, m, v, w.pos, !is_emit, false, is_emit, density, Cd, em, z0, z1, z2, false);
         });
     } else {
         for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) {
@@ -310,7 +310,7 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
                 float dz = 0.0f;
                 f3 ez = mk3(0.0f);
                 for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) { // sum_color :931 (component-wise max)
-                    lookup_volume<COLOR, false, false, false, A24>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
+                    lookup_volume<COLOR, false, false, false, A24, COUNT>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
                 });
             }
             const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "vpt_scene_set_volumes", "vpt_scene_get_root", "vpt_scene_get_octree_stats",
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
+    "vpt_comm_unique_id", "vpt_comm_init_rank", "vpt_comm_destroy", "vpt_allreduce_accum", "vpt_resolve_display",
     "vpt_atmosphere_default_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
     "vpt_env_cdf_build", "vpt_env_cdf_create",
     "vpt_camera_update", "vpt_camera_frame", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
@@ -70,6 +71,11 @@ def load_library(path=None):
     lib.vpt_blue_noise_advance.argtypes = [vp, vp, C.c_uint, C.c_uint, vp]
     lib.vpt_set_counting.argtypes = [vp, C.c_int]
     lib.vpt_get_stats.argtypes = [vp, C.POINTER(RenderStats)]
+    lib.vpt_comm_unique_id.argtypes = [vp]
+    lib.vpt_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.vpt_comm_destroy.argtypes = [vp]
+    lib.vpt_allreduce_accum.argtypes = [vp, vp, C.c_ulonglong, C.c_uint, vp]
+    lib.vpt_resolve_display.argtypes = [vp, C.POINTER(KernelParams), vp]
     lib.vpt_camera_update.argtypes = [C.POINTER(Camera), Float3, Float3, Float3, C.c_float, C.c_float, C.c_float]
     lib.vpt_camera_update.restype = None
     lib.vpt_camera_frame.argtypes = [C.POINTER(Camera), C.POINTER(GpuVdb), C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Float3), C.POINTER(C.c_float)]
@@ -202,6 +208,31 @@ class Context:
     def render_batch(self, cam, lights, sphere, atmosphere, kp, iter_count, iter_stride=1, stream=None):
         self._chk(self.lib.vpt_render_batch(self.h, C.byref(cam), C.byref(lights), C.byref(sphere), C.byref(atmosphere), C.byref(kp),
                                             int(iter_count), int(iter_stride), C.c_void_p(stream) if stream else None), "vpt_render_batch")
+
+    # ---- multi-GPU: the collective lives below the C ABI (RCCL, loaded on first use) ----------------
+    def comm_unique_id(self):
+        """ncclGetUniqueId: 128 bytes, made on ONE rank and handed to the others by the host's own means"""
+        buf = (C.c_ubyte * abi.COMM_ID_BYTES)()
+        self._chk(self.lib.vpt_comm_unique_id(buf), "vpt_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_ubyte * abi.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._chk(self.lib.vpt_comm_init_rank(self.h, int(nranks), int(rank), buf), "vpt_comm_init_rank")
+        self.comm_nranks = int(nranks)
+
+    def comm_destroy(self):
+        self._chk(self.lib.vpt_comm_destroy(self.h), "vpt_comm_destroy")
+        self.comm_nranks = 0
+
+    def allreduce_accum(self, accum_tensor, n_local, stream=None):
+        """accum (running mean of this rank's n_local iterations) <- the job's mean; enqueued on `stream` (ctx stream if None)"""
+        self._chk(self.lib.vpt_allreduce_accum(self.h, C.c_void_p(accum_tensor.data_ptr()), int(accum_tensor.numel()), int(n_local),
+                                               C.c_void_p(stream) if stream else None), "vpt_allreduce_accum")
+
+    def resolve_display(self, kp, stream=None):
+        """display / raw.xyz of kp's buffers from its accum buffer as it is now (after an all-reduce)"""
+        self._chk(self.lib.vpt_resolve_display(self.h, C.byref(kp), C.c_void_p(stream) if stream else None), "vpt_resolve_display")
 
     def blue_noise_advance(self, bn_tensor, steps, num_pixels, stream=None):
         """num_pixels = W*H of the render being positioned (only min(W*H, 65536) entries advance per launch)."""

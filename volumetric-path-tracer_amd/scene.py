@@ -251,6 +251,11 @@ class HipBinding:
         self.ctx.render_batch(self.sd.camera, self.lights, self.sd.sphere, self.atmosphere, self.kp, iter_count, iter_stride, stream)
         self.kp.iteration += int(iter_count) * int(iter_stride)
 
+    def render_frame(self, stream=None):
+        """the reference's per-frame call (main.cpp:1822-1829): ONE iteration through vpt_render"""
+        self.ctx.render(self.sd.camera, self.lights, self.sd.sphere, self.atmosphere, self.kp, stream)
+        self.kp.iteration += 1
+
     def sync(self):
         self.ctx.sync()
 
