@@ -106,3 +106,22 @@ def test_two_different_files_take_the_general_instance_path(pkg):
     sd.camera = cam
     st = _check(pkg, sd, 3)
     assert st.color_lookups > 0 and st.emission_lookups > 0
+
+
+def test_axis_aligned_instances_and_their_edge_shell(pkg):
+    """Instances that are NOT rotated (round-1 advisor finding): Bounds() covers index space [bmin, bmax], the look-up accepts
+    [bmin, bmin + dim] (render_kernel.cu:997 with dim = bmax - bmin + 1, gpu_vdb.cpp:453-455), so a point in the one-voxel shell
+    past bmax is outside an instance's AABB yet still summed by the reference whenever the instance is in the leaf's list.  The
+    refined per-sub-cell candidate lists must keep such an instance.  Coarse 8^3 grids (the shell is an eighth of the instance),
+    every voxel non-zero, boxes abutting and overlapping: sums, look-up counts, depth and alpha equal the oracle's, which walks
+    the leaf lists as the reference does."""
+    n = 8
+    rng = np.random.default_rng(3)
+    dens = (0.2 + 0.8 * rng.random((n, n, n), dtype=np.float32)).astype(np.float32)
+    cd = np.ones((n, n, n, 4), np.float32)
+    cd[..., :3] = rng.random((n, n, n, 3), dtype=np.float32)
+    for spacing in (8.0, 9.5):
+        sd = pkg.scene.instanced_scene(112, 80, n=n, grid=4, aperture=0.0, rotate=False, spacing=spacing, grids=(dens, cd))
+        sd.kp.density_mult = 0.5
+        st = _check(pkg, sd, 3)
+        assert st.color_lookups > 0

@@ -594,6 +594,10 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         // slot per LIST ENTRY, in list order: a candidate's matrix is read at the list position itself.
         std::vector<BoxD> domain(num_volumes);
         for (int v = 0; v < num_volumes; ++v) domain[v] = lookup_domain_bounds(volumes[v], bounds[v]);
+#ifdef VPT_EXPERIMENT_SUBLIST_AABB      // the round-1 behaviour (lists filtered with Bounds() only): shows that the shell test sees it
+        for (int v = 0; v < num_volumes; ++v)
+            domain[v] = BoxD{{bounds[v].lo.x, bounds[v].lo.y, bounds[v].lo.z}, {bounds[v].hi.x, bounds[v].hi.y, bounds[v].hi.z}};
+#endif
         std::vector<uint32_t> sub_offsets((size_t)512 * VPT_SUB3 + 1, 0);
         std::vector<uint32_t> sub_entries;
         for (int p3 = 0; p3 < 512; ++p3) {

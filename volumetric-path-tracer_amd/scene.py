@@ -438,14 +438,15 @@ def fireball_scene(width, height, n=256, lib=None, sky=False):
     return _finish(sd)
 
 
-def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacing=None, lib=None, sky=False, rotate=True):
+def instanced_scene(width, height, n=128, grid=10, seed=99, aperture=2.0, spacing=None, lib=None, sky=False, rotate=True, grids=None):
     """BASELINE config 5: grid x grid instances of one coloured-smoke grid (density + Cd) on a
     jittered lattice with random unit quaternions, scale 1, via the .ins transform
     (vpt_instance_xform == main.cpp:1060-1095), DOF on.  sky=True: procedural sun + sky as BASELINE.md 4 specifies
     (the caller binds the atmosphere LUTs); sky=False: sun only.  rotate=False keeps the instances axis-aligned
-    (identity quaternion), the case in which an instance's AABB is exactly its index-space box."""
+    (identity quaternion), the case in which an instance's AABB is exactly its index-space box.  grids: (density, Cd)
+    to use instead of smoke_grids(n)."""
     lib = lib or load_library()
-    dens, cd = smoke_grids(n)
+    dens, cd = grids if grids is not None else smoke_grids(n)
     voxel = 8.0 / n
     base = make_gpu_vdb(dens, (0, 0, 0), (n - 1, n - 1, n - 1), _grid_matrix(dens.shape, voxel), voxel, color=cd)
     rng = np.random.default_rng(seed)
