@@ -96,3 +96,33 @@ def attach_synthetic_atmosphere(sd, seed=5):
 def pkg_atmosphere():
     from oracle_binding import pkg
     return pkg.atmosphere
+
+
+REF_CDF_PATH = os.path.join(ROOT, "oracle", "_ref", "ref_env_cdf")
+
+
+def have_ref_env_cdf():
+    """the reference's create_cdf fill + host sky compiled from main.cpp's own lines (oracle/Makefile, target ref)"""
+    if not os.path.exists(REF_CDF_PATH) and os.path.isdir("/root/reference/source"):
+        try:
+            import __graft_entry__ as ge
+            ge.build_ref()
+        except Exception:
+            return False
+    return os.path.exists(REF_CDF_PATH)
+
+
+def ref_env_cdf(azimuth, elevation, sky_color):
+    """run oracle/_ref/ref_env_cdf: dict(val [res,res,3], func, cdf [res,res], marginal_func, marginal_cdf [res], marginal_int, res)"""
+    import subprocess
+    import tempfile
+    import numpy as np
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        subprocess.run([REF_CDF_PATH, repr(float(azimuth)), repr(float(elevation))] + [repr(float(c)) for c in sky_color] + [f.name], check=True)
+        raw = open(f.name, "rb").read()
+    res = int(np.frombuffer(raw[:4], "<u4")[0])
+    mi = float(np.frombuffer(raw[4:8], "<f4")[0])
+    a = np.frombuffer(raw[8:], "<f4")
+    n = res * res
+    return dict(res=res, marginal_int=mi, val=a[:3 * n].reshape(res, res, 3).copy(), func=a[3 * n:4 * n].reshape(res, res).copy(),
+                cdf=a[4 * n:5 * n].reshape(res, res).copy(), marginal_func=a[5 * n:5 * n + res].copy(), marginal_cdf=a[5 * n + res:5 * n + 2 * res].copy())

@@ -110,3 +110,45 @@ def test_env_cdf_black_sky_falls_back_to_product_cdf(pkg):
     x = np.arange(16, dtype=np.float32) / 16
     np.testing.assert_array_equal(T["cdf"], x[None, :] * x[:, None])       # main.cpp:713-719
     assert T["marginal_int"] == 0.0 and T["marginal_cdf"][0] == 1.0
+
+
+# ---- the pin on reference code: main.cpp's own lines compiled for the host (oracle/_ref/ref_env_cdf) -------------------
+def _product_tables(pkg, az, el, sky):
+    lib = pkg.load_library()
+    kp = pkg.abi.KernelParams()
+    lib.vpt_kernel_params_default(C.byref(kp))
+    kp.azimuth, kp.elevation = float(az), float(el)
+    kp.sky_color = pkg.abi.Float3(*[float(c) for c in sky])
+    return pkg.host.env_cdf_build(kp, res=180)
+
+
+def _assert_tables_identical(T, R):
+    assert T["res"] == 180
+    np.testing.assert_array_equal(T["val"][..., :3], R["val"])
+    for k in ("func", "cdf", "marginal_func", "marginal_cdf"):
+        np.testing.assert_array_equal(T[k], R[k], err_msg=k)
+    assert np.float32(T["marginal_int"]) == np.float32(R["marginal_int"])
+
+
+def test_env_cdf_bit_identical_to_reference_golden(pkg):
+    """vpt_env_cdf_build == the tables written by the reference's own code (fixture from tests/golden/make_ref_env_cdf_golden.py)"""
+    g = pkg.scene.load_golden("ref_env_cdf.npz")
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 3
+    for name in names:
+        az, el, r, gc, b = [float(x) for x in g[name + "/params"]]
+        T = _product_tables(pkg, az, el, (r, gc, b))
+        np.testing.assert_array_equal(T["val"][::6, :, :3], g[name + "/val_rows_every_6"])
+        for k in ("func", "cdf", "marginal_func", "marginal_cdf"):
+            np.testing.assert_array_equal(T[k], g[name + "/" + k], err_msg=k)
+        assert np.float32(T["marginal_int"]) == np.float32(g[name + "/marginal_int"])
+
+
+def test_env_cdf_bit_identical_to_reference_live(pkg):
+    """the same against the program itself, on further suns (built where /root/reference exists; the GPU box gets it prebuilt)"""
+    import pytest
+    import ref_binding
+    if not ref_binding.have_ref_env_cdf():
+        pytest.skip("oracle/_ref/ref_env_cdf not available (no reference tree here)")
+    for az, el, sky in ((120.0, 30.0, (1, 1, 1)), (0.0, 0.0, (1, 1, 1)), (359.0, 89.0, (2.0, 0.5, 0.25)), (200.0, -10.0, (1, 1, 1)), (33.0, 61.0, (0, 0, 0))):
+        _assert_tables_identical(_product_tables(pkg, az, el, sky), ref_binding.ref_env_cdf(az, el, sky))
