@@ -80,6 +80,86 @@ def test_vdb_reader_on_synthetic_files(pkg, tmp_path, flags):
     assert v2.grid(1) is None and v2.grid(2) is None and v2.info.vdb_info.has_color == 0
 
 
+@pytest.mark.parametrize("flags", [0, W.ZIP | W.ACTIVE_MASK])
+def test_vdb_reader_half_float_grids(pkg, tmp_path, flags):
+    """grids saved as 16-bit floats (the "_HalfFloat" descriptor suffix: Houdini's default save): the value blocks are
+    binary16 -- float and vec3s grids, leaves and tile values, an inactive value (full float in the file) -- next to a
+    full-float grid in the same file; every decoded value is exactly the half the file holds"""
+    rng = np.random.default_rng(21 + flags)
+
+    def h(x):
+        return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+    def hleaf(ncomp, fill=0.6, inactive=0.0):
+        vals, mask = _leaf(rng, ncomp, fill)
+        vals = h(vals)
+        vals[~mask] = inactive
+        return vals, mask
+    dl = {(0, 0, 0): hleaf(1), (8, 0, 16): hleaf(1), (136, 8, 0): hleaf(1), (-8, -16, -8): hleaf(1, 0.3)}
+    # extremes of binary16: largest finite, smallest normal, a subnormal, a negative value
+    v0 = dl[(0, 0, 0)][0]
+    m0 = dl[(0, 0, 0)][1]
+    idx = np.flatnonzero(m0)[:4]
+    v0[idx, 0] = h([65504.0, 6.1035156e-05, 5.9604645e-08 * 3, -2.5])
+    tiles = {(16, 8, 8): h(0.3)}
+    cl = {(0, 0, 0): hleaf(3), (8, 0, 16): hleaf(3)}
+    fl = {(0, 0, 0): _leaf(rng, 1)}                                              # a FULL-float grid in the same file
+    path = str(tmp_path / "h.vdb")
+    W.write_vdb(path, [
+        dict(name="density", type="float", leaves=dl, tiles3=tiles, flags=flags, map_values=W.uniform_scale(0.5), half=True),
+        dict(name="heat", type="float", leaves=fl, flags=flags, map_values=W.uniform_scale(0.5)),
+        dict(name="Cd", type="vec3s", leaves=cl, flags=flags, map_values=W.uniform_scale(0.5), half=True),
+    ])
+    v = pkg.io.VdbFile(path)
+    ref, lo, hi = _dense_from(dl, tiles, 1)
+    np.testing.assert_array_equal(v.grid(0), ref[..., 0])
+    assert v.info.vdb_info.max_density == np.float32(65504.0)
+    np.testing.assert_array_equal(v.grid(1), _dense_from(fl, {}, 1)[0][..., 0])
+    np.testing.assert_array_equal(v.grid(2)[..., :3], _dense_from(cl, {}, 3)[0])
+    if flags & W.ACTIVE_MASK:
+        # a non-background inactive value (metadata code 2): written as a 4-byte float truncated to half precision
+        il = {(0, 0, 0): hleaf(1, 0.5, inactive=float(h(0.123)))}
+        p2 = str(tmp_path / "i.vdb")
+        W.write_vdb(p2, [dict(name="density", type="float", leaves=il, flags=flags, map_values=W.uniform_scale(0.5), half=True)])
+        vals, mask = il[(0, 0, 0)]
+        d2 = pkg.io.VdbFile(p2, emission=None, color=None).grid(0)
+        n = np.flatnonzero(mask)
+        lo2 = np.array([(n >> 6).min(), ((n >> 3) & 7).min(), (n & 7).min()])
+        for k in range(512):                              # inactive voxels inside the active bbox carry the inactive value
+            q = np.array([k >> 6, (k >> 3) & 7, k & 7]) - lo2
+            if (q >= 0).all() and (q < np.array(d2.shape[::-1])).all():
+                assert d2[q[2], q[1], q[0]] == vals[k, 0]
+
+
+def test_vdb_reader_rejects_corrupt_offsets_and_blosc_headers(pkg, tmp_path):
+    """offsets taken from the file are range-checked (round-1 advisor findings): a grid / block / end position outside the
+    file, and blosc chunk headers with a zero type size or a block offset in front of the chunk, are ParseErrors"""
+    rng = np.random.default_rng(5)
+    path = str(tmp_path / "o.vdb")
+    W.write_vdb(path, [dict(name="density", type="float", leaves={(0, 0, 0): _leaf(rng, 1)}, map_values=W.uniform_scale(1.0))])
+    raw = bytearray(open(path, "rb").read())
+    key = b"Tree_float_5_4_3"
+    at = raw.find(key) + len(key) + 4                    # past the type string and the empty instance-parent string: 3 x int64
+    for slot, val in ((0, 1 << 40), (0, -5), (1, 1 << 40), (2, (1 << 62))):
+        bad = bytearray(raw)
+        bad[at + 8 * slot:at + 8 * slot + 8] = struct.pack("<q", val)
+        f = tmp_path / ("bad%d_%d.vdb" % (slot, abs(val) % 97))
+        f.write_bytes(bytes(bad))
+        with pytest.raises(pkg.VptError, match="offset outside the file|truncated|end offset"):
+            pkg.io.VdbFile(str(f), emission=None, color=None)
+    lib = pkg.load_library()
+    if hasattr(lib, "vpt_io_test_blosc_decode"):
+        import ctypes as C
+        lib.vpt_io_test_blosc_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        out = (C.c_ubyte * 4096)()
+
+        def chunk(typesize, bstart, nbytes=4096, blocksize=4096, flags=0x21):
+            return bytes([2, 1, flags, typesize]) + struct.pack("<III", nbytes, blocksize, 16 + 4 + 8) + struct.pack("<i", bstart) + b"\0" * 8
+        for c in (chunk(0, 20), chunk(4, -2), chunk(4, 3), chunk(4, 1 << 20)):
+            buf = (C.c_ubyte * len(c)).from_buffer_copy(c)
+            assert lib.vpt_io_test_blosc_decode(buf, len(c), out, 4096) != 0
+
+
 def test_vdb_reader_affine_map_and_errors(pkg, tmp_path):
     rng = np.random.default_rng(9)
     aff = np.array([[0.2, 0.1, 0, 0], [-0.1, 0.2, 0, 0], [0, 0, 0.3, 0], [1, 2, 3, 1]], np.float64)

@@ -20,8 +20,9 @@ def _bits(mask):
     return np.packbits(np.asarray(mask, bool), bitorder="little").tobytes()
 
 
-def _values(vals, vmask, flags, background):
-    """compressed_values(N): vals (N, C) float32, vmask (N,) bool"""
+def _values(vals, vmask, flags, background, half=False):
+    """compressed_values(N): vals (N, C) float32, vmask (N,) bool.  half: the value block is binary16 (io::HalfWriter);
+    the inactive value stays a 4-byte float, truncated to half precision, as OpenVDB writes it"""
     vals = np.asarray(vals, np.float32)
     n = vals.shape[0]
     out = b""
@@ -31,6 +32,8 @@ def _values(vals, vmask, flags, background):
             # one non-background inactive value: metadata 2 (NO_MASK_AND_ONE_INACTIVE_VAL)
             iv = inactive[0]
             assert (inactive == iv).all(), "writer supports at most one inactive value"
+            if half:
+                iv = np.asarray(iv, np.float16).astype(np.float32)
             out += struct.pack("<b", 2) + np.asarray(iv, "<f4").tobytes()
         else:
             out += struct.pack("<b", 0)
@@ -38,7 +41,7 @@ def _values(vals, vmask, flags, background):
     else:
         out += struct.pack("<b", 6)
         data = vals
-    raw = np.ascontiguousarray(data, "<f4").tobytes()
+    raw = np.ascontiguousarray(data, "<f2" if half else "<f4").tobytes()
     if flags & ZIP:
         if len(raw) <= 64:                       # small buffers are stored raw with a negative size
             out += struct.pack("<q", -len(raw)) + raw
@@ -50,7 +53,7 @@ def _values(vals, vmask, flags, background):
     return out
 
 
-def _grid_bytes(leaves, tiles3, ncomp, background, flags, map_type, map_values, meta):
+def _grid_bytes(leaves, tiles3, ncomp, background, flags, map_type, map_values, meta, half=False):
     """leaves: {(ox,oy,oz): (vals[512,C], mask[512])}, origins multiples of 8 inside ONE 4096^3 root
     child at origin (0,0,0) ... ; tiles3: {(ox,oy,oz): val} active 8^3 tiles."""
     bg = np.zeros(ncomp, np.float32) + np.asarray(background, np.float32)
@@ -74,7 +77,7 @@ def _grid_bytes(leaves, tiles3, ncomp, background, flags, map_type, map_values, 
             i = ((rel[0] >> 7) << 10) | ((rel[1] >> 7) << 5) | (rel[2] >> 7)
             cm5[i] = True
             kids5.setdefault(i, []).append(o)
-        topo += _bits(cm5) + _bits(vm5) + _values(np.tile(bg, (32768, 1)), vm5, flags, bg)
+        topo += _bits(cm5) + _bits(vm5) + _values(np.tile(bg, (32768, 1)), vm5, flags, bg, half)
         for i in sorted(kids5):
             o5 = np.array(ro) + np.array([(i >> 10) << 7, ((i >> 5) & 31) << 7, (i & 31) << 7])
             cm4 = np.zeros(4096, bool); vm4 = np.zeros(4096, bool)
@@ -89,36 +92,39 @@ def _grid_bytes(leaves, tiles3, ncomp, background, flags, map_type, map_values, 
                 else:
                     vm4[j] = True
                     vals4[j] = tiles3[o]
-            topo += _bits(cm4) + _bits(vm4) + _values(vals4, vm4, flags, bg)
+            topo += _bits(cm4) + _bits(vm4) + _values(vals4, vm4, flags, bg, half)
             for j in sorted(order):
                 vals, mask = leaves[order[j]]
                 topo += _bits(mask)
-                bufs += _bits(mask) + _values(np.asarray(vals, np.float32).reshape(512, ncomp), np.asarray(mask, bool), flags, bg)
+                bufs += _bits(mask) + _values(np.asarray(vals, np.float32).reshape(512, ncomp), np.asarray(mask, bool), flags, bg, half)
     return head + topo, bufs
 
 
 def write_vdb(path, grids):
-    """grids: list of dict(name, type ('float'|'vec3s'), leaves, tiles3, background, flags, map_type, map_values)"""
+    """grids: list of dict(name, type ('float'|'vec3s'), leaves, tiles3, background, flags, map_type, map_values, half)"""
     out = struct.pack("<qIII", 0x56444220, 224, 5, 2) + b"\x01" + b"0" * 36
     out += struct.pack("<I", 0)                                 # file metadata
     out += struct.pack("<I", len(grids))
     blobs = []
     for g in grids:
         ncomp = 3 if g["type"] == "vec3s" else 1
-        meta = {"class": ("string", b"fog volume"), "is_saved_as_half_float": ("bool", b"\x00")}
+        half = bool(g.get("half", False))
+        meta = {"class": ("string", b"fog volume"), "is_saved_as_half_float": ("bool", b"\x01" if half else b"\x00")}
         a, b = _grid_bytes(g["leaves"], g.get("tiles3", {}), ncomp, g.get("background", 0.0), g.get("flags", 0),
-                           g.get("map_type", "UniformScaleMap"), g["map_values"], meta)
+                           g.get("map_type", "UniformScaleMap"), g["map_values"], meta, half)
         blobs.append((g, a, b))
     pos = len(out)
+    def tname(g):                                               # GridDescriptor: the type name carries the half-float suffix
+        return "Tree_%s_5_4_3" % g["type"] + ("_HalfFloat" if g.get("half") else "")
     for g, a, b in blobs:                                       # descriptor sizes first
-        pos += len(_s(g["name"])) + len(_s("Tree_%s_5_4_3" % g["type"])) + len(_s("")) + 24
+        pos += len(_s(g["name"])) + len(_s(tname(g))) + len(_s("")) + 24
     descs = b""
     body = b""
     cur = len(out)
     # descriptors are interleaved with the grids in real files: name/type/parent/offsets then the grid
     res = out
     for g, a, b in blobs:
-        d = _s(g["name"]) + _s("Tree_%s_5_4_3" % g["type"]) + _s("")
+        d = _s(g["name"]) + _s(tname(g)) + _s("")
         grid_pos = len(res) + len(d) + 24
         block_pos = grid_pos + len(a)
         end_pos = block_pos + len(b)

@@ -60,10 +60,15 @@ struct Reader {
     const uint8_t* b;
     size_t n, p;
     const uint8_t* take(size_t k) {
-        if (k > n - p) throw ParseError("truncated file");
+        if (p > n || k > n - p) throw ParseError("truncated file");
         const uint8_t* r = b + p;
         p += k;
         return r;
+    }
+    // an offset read FROM the file (grid / block / end positions): inside the buffer or a ParseError
+    void seek(int64_t pos) {
+        if (pos < 0 || (uint64_t)pos > (uint64_t)n) throw ParseError("offset outside the file");
+        p = (size_t)pos;
     }
     template <class T>
     T get() {
@@ -128,6 +133,7 @@ void blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t nbytes_out)
     std::memcpy(&cbytes, src + 12, 4);
     if (nbytes != nbytes_out) throw ParseError("blosc: unexpected uncompressed size");
     if (cbytes > n) throw ParseError("blosc: chunk larger than its frame");
+    if (typesize == 0) throw ParseError("blosc: zero type size");
     if (flags & 0x2) {                                        // BLOSC_MEMCPYED
         if (n < 16 + (size_t)nbytes) throw ParseError("blosc: truncated memcpy chunk");
         std::memcpy(dst, src + 16, nbytes);
@@ -145,6 +151,8 @@ void blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t nbytes_out)
     for (size_t blk = 0; blk < nblocks; ++blk) {
         int32_t bstart;
         std::memcpy(&bstart, src + 16 + 4 * blk, 4);
+        if (bstart < 0 || (size_t)bstart < 16 + 4 * nblocks || (size_t)bstart >= n) throw ParseError("blosc: block offset outside the chunk");
+        if (blk * (size_t)blocksize >= nbytes_out) throw ParseError("blosc: block table larger than the output");
         const size_t bsize = (blk == nblocks - 1 && nbytes % blocksize) ? nbytes % blocksize : blocksize;
         const bool leftover = bsize != blocksize;
         size_t nsplits = 1;
@@ -153,11 +161,11 @@ void blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t nbytes_out)
         size_t ip = (size_t)bstart, op = 0;
         uint8_t* target = shuffle ? tmp.data() : dst + blk * blocksize;
         for (size_t s = 0; s < nsplits; ++s) {
-            if (ip + 4 > n) throw ParseError("blosc: truncated split header");
+            if (ip > n || n - ip < 4) throw ParseError("blosc: truncated split header");
             int32_t cb;
             std::memcpy(&cb, src + ip, 4);
             ip += 4;
-            if (cb < 0 || ip + (size_t)cb > n) throw ParseError("blosc: truncated split");
+            if (cb < 0 || (size_t)cb > n - ip || op + neblock > bsize) throw ParseError("blosc: truncated split");
             if ((size_t)cb == neblock) {
                 std::memcpy(target + op, src + ip, neblock);
             } else if (codec == 1) {
@@ -237,8 +245,25 @@ void read_raw(Reader& r, uint8_t* out, size_t nbytes_out, uint32_t flags) {
     std::memcpy(out, r.take(nbytes_out), nbytes_out);
 }
 
-// io::readCompressedValues: `n` values of `ncomp` floats, value mask `vm` (n bits)
-void read_values(Reader& r, size_t n, const uint8_t* vm, uint32_t flags, int ncomp, const float* background, std::vector<float>& out) {
+float half_to_float(uint16_t h);       // defined with the OpenEXR reader below (exact: every binary16 value is a binary32 value)
+
+// the value block of io::readCompressedValues: `count` values of `ncomp` floats.  Grids saved as half float
+// (GridDescriptor type suffix "_HalfFloat", io/GridDescriptor.cc; Houdini's "16-bit float" save option) store this block
+// -- and only this block -- as binary16 (io::HalfReader): 2 bytes per component before compression
+void read_value_block(Reader& r, float* out, size_t count, int ncomp, uint32_t flags, bool half) {
+    if (!half) {
+        read_raw(r, (uint8_t*)out, count * ncomp * 4, flags);
+        return;
+    }
+    std::vector<uint16_t> h(count * ncomp);
+    read_raw(r, (uint8_t*)h.data(), count * ncomp * 2, flags);
+    for (size_t i = 0; i < count * (size_t)ncomp; ++i) out[i] = half_to_float(h[i]);
+}
+
+// io::readCompressedValues: `n` values of `ncomp` floats, value mask `vm` (n bits).  The inactive values of the
+// node-mask compression are full floats even in a half-float grid (the writer truncates them to half precision but
+// stores 4 bytes, io/Compression.h)
+void read_values(Reader& r, size_t n, const uint8_t* vm, uint32_t flags, int ncomp, const float* background, std::vector<float>& out, bool half) {
     const int8_t metadata = r.get<int8_t>();
     float inactive0[3], inactive1[3];
     for (int c = 0; c < ncomp; ++c) inactive0[c] = inactive1[c] = background[c];
@@ -251,11 +276,11 @@ void read_values(Reader& r, size_t n, const uint8_t* vm, uint32_t flags, int nco
     const size_t count = ((flags & COMPRESS_ACTIVE_MASK) && metadata != 6) ? popcount_bytes(vm, n / 8) : n;
     out.assign(n * ncomp, 0.0f);
     if (count == n) {
-        read_raw(r, (uint8_t*)out.data(), n * ncomp * 4, flags);
+        read_value_block(r, out.data(), n, ncomp, flags, half);
         return;
     }
     std::vector<float> packed(count * ncomp);
-    read_raw(r, (uint8_t*)packed.data(), count * ncomp * 4, flags);
+    read_value_block(r, packed.data(), count, ncomp, flags, half);
     size_t k = 0;
     for (size_t i = 0; i < n; ++i) {
         float* o = &out[i * ncomp];
@@ -361,20 +386,17 @@ void read_grid(Reader& r, Grid& g, int64_t grid_pos, int64_t block_pos, int64_t 
     if (g.type.rfind("Tree_float_5_4_3", 0) == 0) g.ncomp = 1;
     else if (g.type.rfind("Tree_vec3s_5_4_3", 0) == 0) g.ncomp = 3;
     else throw ParseError("vdb: unsupported grid type " + g.type);
-    if (g.type.size() >= 10 && g.type.compare(g.type.size() - 10, 10, "_HalfFloat") == 0) throw ParseError("vdb: half-float grids are not supported");
-    r.p = (size_t)grid_pos;
+    // the descriptor's type suffix is what OpenVDB's reader goes by (GridDescriptor::read strips it and sets saveFloatAsHalf,
+    // Archive::readGrid passes that to the stream); the grid metadatum of the same name is informational
+    const bool half = g.type.size() >= 10 && g.type.compare(g.type.size() - 10, 10, "_HalfFloat") == 0;
+    r.seek(grid_pos);
     const uint32_t flags = r.get<uint32_t>();
     const uint32_t meta_count = r.get<uint32_t>();
     for (uint32_t i = 0; i < meta_count; ++i) {
         const std::string mname = r.str();
         const std::string mtype = r.str();
-        if (mname == "is_saved_as_half_float" && mtype == "bool") {
-            const uint32_t size = r.get<uint32_t>();
-            const uint8_t* v = r.take(size);
-            if (size && v[0]) throw ParseError("vdb: half-float grids are not supported");
-        } else {
-            skip_meta_value(r);
-        }
+        (void)mname; (void)mtype;
+        skip_meta_value(r);
     }
     read_transform(r, g);
     // ---- topology: RootNode<InternalNode<InternalNode<LeafNode<T,3>,4>,5>>
@@ -407,7 +429,7 @@ void read_grid(Reader& r, Grid& g, int64_t grid_pos, int64_t block_pos, int64_t 
         int32_t org5[3];
         std::memcpy(org5, r.take(12), 12);
         const std::vector<uint8_t> cm5 = grab(4096), vm5 = grab(4096);
-        read_values(r, 32768, vm5.data(), flags, g.ncomp, g.background, vals);
+        read_values(r, 32768, vm5.data(), flags, g.ncomp, g.background, vals, half);
         std::vector<float> vals5 = vals;
         for (size_t i = 0; i < 32768; ++i) {
             const int32_t o5[3] = {org5[0] + (int32_t)((i >> 10) << 7), org5[1] + (int32_t)(((i >> 5) & 31) << 7), org5[2] + (int32_t)((i & 31) << 7)};
@@ -425,7 +447,7 @@ void read_grid(Reader& r, Grid& g, int64_t grid_pos, int64_t block_pos, int64_t 
                 continue;
             }
             const std::vector<uint8_t> cm4 = grab(512), vm4 = grab(512);
-            read_values(r, 4096, vm4.data(), flags, g.ncomp, g.background, vals);
+            read_values(r, 4096, vm4.data(), flags, g.ncomp, g.background, vals, half);
             for (size_t j = 0; j < 4096; ++j) {
                 const int32_t o4[3] = {o5[0] + (int32_t)((j >> 8) << 3), o5[1] + (int32_t)(((j >> 4) & 15) << 3), o5[2] + (int32_t)((j & 15) << 3)};
                 if (!bit(cm4.data(), j)) {
@@ -447,13 +469,13 @@ void read_grid(Reader& r, Grid& g, int64_t grid_pos, int64_t block_pos, int64_t 
         }
     }
     // ---- buffers, same depth-first order
-    r.p = (size_t)block_pos;
+    r.seek(block_pos);
     g.leaves.resize(leaf_origins.size());
     for (size_t i = 0; i < leaf_origins.size(); ++i) {
         Leaf& lf = g.leaves[i];
         std::memcpy(lf.org, leaf_origins[i].data(), 12);
         std::memcpy(lf.mask, r.take(64), 64);
-        read_values(r, 512, lf.mask, flags, g.ncomp, g.background, lf.vals);
+        read_values(r, 512, lf.mask, flags, g.ncomp, g.background, lf.vals, half);
     }
     if ((int64_t)r.p != end_pos) throw ParseError("vdb: grid '" + g.name + "' did not parse to its end offset");
     densify(g);
@@ -477,6 +499,16 @@ struct vpt_io_ins {
 extern "C" {
 
 const char* vpt_io_last_error(void) { return g_io_error.c_str(); }
+
+// test probe (not in include/vpt_io.h): one c-blosc chunk through the decoder; 0 on success, VPT_E_IO on a ParseError
+int vpt_io_test_blosc_decode(const unsigned char* src, size_t n, unsigned char* dst, size_t nbytes_out) {
+    try {
+        blosc_decode(src, n, dst, nbytes_out);
+    } catch (const std::exception& e) {
+        return fail(VPT_E_IO, "%s", e.what());
+    }
+    return VPT_OK;
+}
 void vpt_io_free(void* p) { free(p); }
 
 int vpt_io_vdb_load(const char* filename, const char* density_channel, const char* emission_channel, const char* color_channel,
@@ -527,7 +559,7 @@ int vpt_io_vdb_load(const char* filename, const char* density_channel, const cha
                 if ((w < 2 && g.ncomp != 1) || (w == 2 && g.ncomp != 3)) throw ParseError("vdb: grid '" + name + "' has the wrong value type for its channel");
                 vol->present[w] = true;
             }
-            r.p = (size_t)end_pos;
+            r.seek(end_pos);
         }
     } catch (const std::exception& e) {
         return fail(VPT_E_IO, "%s: %s", filename, e.what());
