@@ -350,6 +350,25 @@ int  vpt_resolve_display(vpt_ctx *ctx, const vpt_kernel_params *kp, void *stream
  * vpt_atmosphere_read_lut: device->host copy of one table (0 transmittance 256x64, 1 irradiance
  * 256x64, 2 scattering 256x128x32, 3 single Mie 256x128x32; float4 texels). */
 int  vpt_atmosphere_default_model(vpt_atmosphere_parameters *atm);
+/* vpt_atmosphere_model: the same scalars for ANY setting of the reference's model switches -- what atmosphere::init
+ * (spectra, atmosphere.cpp:1193-1224), precompute's luminance factors (:903-910) and update_model(lambdas) (:698-784) leave in
+ * atmosphere_parameters: solar spectrum constant / ASTM, ozone on / off, white balance, luminance mode NONE (0) or
+ * APPROXIMATE (1) (PRECOMPUTED (2), the 15-wavelength precompute, returns VPT_E_UNSUPPORTED), the three wavelengths the
+ * tables are computed for, exposure, the 102-degree sun-zenith limit of half-precision tables, the length unit.  The published
+ * data tables behind it (solar irradiance, ozone cross-sections, CIE 1931 CMFs) are read from `spectra_file`
+ * (NULL: data/atmosphere_spectra.bin next to the library).  Follow with vpt_atmosphere_precompute. */
+typedef struct vpt_atmosphere_model_options {
+    int    use_constant_solar_spectrum;   /* 1 */
+    int    use_ozone;                     /* 1 */
+    int    do_white_balance;              /* 1 */
+    int    use_luminance;                 /* 0 NONE, 1 APPROXIMATE, 2 PRECOMPUTED (unsupported) */
+    int    half_precision;                /* 0 */
+    float  exposure;                      /* 1 */
+    double lambdas[3];                    /* 680, 550, 440 nm */
+    double length_unit_in_meters;         /* 1 */
+} vpt_atmosphere_model_options;
+void vpt_atmosphere_model_options_default(vpt_atmosphere_model_options *opt);
+int  vpt_atmosphere_model(const vpt_atmosphere_model_options *opt, const char *spectra_file, vpt_atmosphere_parameters *atm);
 int  vpt_atmosphere_precompute(vpt_ctx *ctx, vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
 int  vpt_atmosphere_read_lut(vpt_ctx *ctx, const vpt_atmosphere_parameters *atm, int which, float *host_out, size_t n_floats);
 

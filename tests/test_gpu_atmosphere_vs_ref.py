@@ -32,11 +32,11 @@ def rel_l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((b ** 2).sum())))
 
 
-def reference_tables(pkg, orders=4):
+def reference_tables(pkg, orders=4, params=None):
     """-> (tables, defined): the reference's tables and the mask of texels that do not depend on out-of-bounds reads"""
     r = C.CDLL(LIB)
     r.ref_atmosphere_precompute.argtypes = [C.POINTER(pkg.abi.AtmosphereParameters), C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float]
-    p = pkg.atmosphere.default_model()
+    p = params if params is not None else pkg.atmosphere.default_model()
     runs = []
     for fill in (0.0, 7.0):
         out = {k: np.zeros(pkg.atmosphere.LUT_SHAPES[k], np.float32) for k in NAMES}
@@ -90,3 +90,22 @@ def test_tables_match_reference_kernels_live(pkg, hip_tables):
         assert e < 2e-4, k
     # the transmittance stage reads no table; single scattering only the transmittance table (0.2 % past its end)
     assert defined["transmittance"].all() and defined["single_mie"].mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libvptref_atm.so not shipped")
+def test_non_default_model_tables_match_reference_kernels_live(pkg):
+    """a model other than the default (vpt_atmosphere_model: ASTM solar spectrum, no ozone, other wavelengths, no white
+    balance -- scalars pinned on the reference's update_model by tests/test_atmosphere_model.py) through the product's
+    precompute and through the reference's kernels"""
+    kw = dict(use_constant_solar_spectrum=0, use_ozone=0, do_white_balance=0, lambdas=(650.0, 510.0, 475.0))
+    ctx = pkg.host.Context(0)
+    _, luts = pkg.atmosphere.precompute(ctx, pkg.atmosphere.model(**kw), orders=3)
+    ctx.close()
+    ref, defined = reference_tables(pkg, orders=3, params=pkg.atmosphere.model(**kw))
+    dflt = pkg.atmosphere.default_model()
+    assert bytes(pkg.atmosphere.model(**kw)) != bytes(dflt)
+    for k in NAMES:
+        ok = defined[k]
+        assert ok.mean() > 0.5 and np.isfinite(luts[k]).all()
+        assert masked_rel_l2(luts[k], ref[k], ok) < 2e-4, k

@@ -143,6 +143,11 @@ class RenderStats(C.Structure):
                 ("density_fetches", C.c_ulonglong), ("color_fetches", C.c_ulonglong), ("emission_fetches", C.c_ulonglong)]
 
 
+class AtmosphereModelOptions(C.Structure):
+    _fields_ = [("use_constant_solar_spectrum", C.c_int), ("use_ozone", C.c_int), ("do_white_balance", C.c_int), ("use_luminance", C.c_int),
+                ("half_precision", C.c_int), ("exposure", C.c_float), ("lambdas", C.c_double * 3), ("length_unit_in_meters", C.c_double)]
+
+
 COMM_ID_BYTES = 128
 ADDR_WRAP, ADDR_CLAMP = 0, 1
 FILTER_POINT, FILTER_LINEAR = 0, 1

@@ -22,6 +22,25 @@ def default_model():
     return p
 
 
+def model(spectra_file=None, **options):
+    """vpt_atmosphere_model: the scalars for any switch setting (use_constant_solar_spectrum, use_ozone, do_white_balance,
+    use_luminance, half_precision, exposure, lambdas=(r, g, b) in nm, length_unit_in_meters)."""
+    from . import abi
+    lib = load_library()
+    o = abi.AtmosphereModelOptions()
+    lib.vpt_atmosphere_model_options_default(C.byref(o))
+    for k, v in options.items():
+        if k == "lambdas":
+            o.lambdas = (C.c_double * 3)(*[float(x) for x in v])
+        else:
+            setattr(o, k, v)
+    p = AtmosphereParameters()
+    rc = lib.vpt_atmosphere_model(C.byref(o), spectra_file.encode() if spectra_file else None, C.byref(p))
+    if rc != 0:
+        raise VptError("vpt_atmosphere_model -> %d" % rc)
+    return p
+
+
 def precompute(ctx, params=None, orders=4):
     """Runs the precompute on ctx's GPU; returns (params with device buffers + textures, dict of numpy LUTs)."""
     p = params or default_model()

@@ -27,8 +27,13 @@
 // Not timed, not on the parity-critical decision path: plain fp32/fp64 device math.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "../../include/vpt_abi.h"
 #include "vpt_math.h"
@@ -423,6 +428,186 @@ int vpt_atmosphere_default_model(vpt_atmosphere_parameters* p) {
     p->mu_s_min = (float)std::cos(120.0 / 180.0 * (double)VPT_PI);   // M_PI is the float macro in the reference
     p->use_luminance = 0;
     p->exposure = 1.0f;
+    p->angle = 0.0f;
+    return VPT_OK;
+}
+
+// ---- the general model: atmosphere::init's spectra + sky_sun factors + update_model, for any toggle set -------------
+// (source/atmosphere/atmosphere.cpp:1193-1224 spectra and constants, :903-912 luminance factors, :698-784 update_model,
+//  :123-238 the CIE / interpolation helpers.)  The published data tables the reference compiles in (solar spectrum, ozone
+//  cross-sections, CIE 1931 colour matching functions, XYZ->sRGB) are DATA: they live in data/atmosphere_spectra.bin next to
+//  the library (tools/make_atmosphere_spectra.py), not in this source.
+namespace {
+struct Spectra {
+    int n = 0, lmin = 0, step = 0, rows = 0;
+    std::vector<double> solar, ozone, cie, xyz2srgb;
+};
+bool load_spectra(const char* path, Spectra& S) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    char magic[8];
+    int32_t hdr[3], rows = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "VPTSPEC1", 8) == 0 && fread(hdr, 4, 3, f) == 3 && hdr[0] > 1 && hdr[0] < 4096 && hdr[2] > 0;
+    if (ok) {
+        S.n = hdr[0]; S.lmin = hdr[1]; S.step = hdr[2];
+        S.solar.resize(S.n); S.ozone.resize(S.n);
+        ok = fread(S.solar.data(), 8, S.n, f) == (size_t)S.n && fread(S.ozone.data(), 8, S.n, f) == (size_t)S.n && fread(&rows, 4, 1, f) == 1 && rows > 1 && rows < 4096;
+    }
+    if (ok) {
+        S.rows = rows;
+        S.cie.resize((size_t)rows * 4); S.xyz2srgb.resize(9);
+        ok = fread(S.cie.data(), 8, (size_t)rows * 4, f) == (size_t)rows * 4 && fread(S.xyz2srgb.data(), 8, 9, f) == 9;
+    }
+    fclose(f);
+    return ok;
+}
+// atmosphere::interpolate :170-186
+double interp(const std::vector<double>& wl, const std::vector<double>& fn, double w) {
+    if (w < wl[0]) return fn[0];
+    for (size_t i = 0; i + 1 < wl.size(); ++i)
+        if (w < wl[i + 1]) {
+            const double u = (w - wl[i]) / (wl[i + 1] - wl[i]);
+            return fn[i] * (1.0 - u) + fn[i + 1] * u;
+        }
+    return fn[fn.size() - 1];
+}
+// cie_color_matching_function_table_value :123-135 (5 nm rows; 0 outside (lambda_min, lambda_max))
+double cie_value(const Spectra& S, double w, int col) {
+    const double lmax = S.lmin + S.step * (S.n - 1);
+    if (w <= S.lmin || w >= lmax) return 0.0;
+    double u = (w - S.lmin) / 5.0;
+    const int row = (int)floor(u);
+    u -= row;
+    return S.cie[4 * (size_t)row + col] * (1.0 - u) + S.cie[4 * (size_t)(row + 1) + col] * u;
+}
+// compute_spectral_radiance_to_luminance_factors :188-216 (the fixed 680 / 550 / 440 nm of kLambdaR/G/B, 1 nm steps)
+void luminance_factors(const Spectra& S, const std::vector<double>& wl, const std::vector<double>& solar, double power, double k[3]) {
+    const double lam[3] = {680.0, 550.0, 440.0};
+    const double s[3] = {interp(wl, solar, lam[0]), interp(wl, solar, lam[1]), interp(wl, solar, lam[2])};
+    k[0] = k[1] = k[2] = 0.0;
+    const int lmax = S.lmin + S.step * (S.n - 1);
+    for (int l = S.lmin; l < lmax; l += 1) {
+        const double x = cie_value(S, l, 1), y = cie_value(S, l, 2), z = cie_value(S, l, 3);
+        const double* m = S.xyz2srgb.data();
+        const double bar[3] = {m[0] * x + m[1] * y + m[2] * z, m[3] * x + m[4] * y + m[5] * z, m[6] * x + m[7] * y + m[8] * z};
+        const double irr = interp(wl, solar, l);
+        for (int c = 0; c < 3; ++c) k[c] += bar[c] * irr / s[c] * pow(l / lam[c], power);
+    }
+    for (int c = 0; c < 3; ++c) k[c] *= 683.0 * 1;                     // MAX_LUMINOUS_EFFICACY * dlambda
+}
+}  // namespace
+
+void vpt_atmosphere_model_options_default(vpt_atmosphere_model_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->use_constant_solar_spectrum = 1;          // atmosphere.h: m_use_constant_solar_spectrum = true
+    o->use_ozone = 1;
+    o->do_white_balance = 1;                     // atmosphere::atmosphere() :1336-1338
+    o->use_luminance = 0;
+    o->half_precision = 0;
+    o->exposure = 1.0f;
+    o->lambdas[0] = 680.0; o->lambdas[1] = 550.0; o->lambdas[2] = 440.0;      // kDefaultLambdas
+    o->length_unit_in_meters = 1.0;
+}
+
+int vpt_atmosphere_model(const vpt_atmosphere_model_options* o, const char* spectra_file, vpt_atmosphere_parameters* p) {
+    if (!o || !p) return VPT_E_INVALID;
+    if (o->use_luminance == 2) return VPT_E_UNSUPPORTED;      // PRECOMPUTED: 15-wavelength precompute with blending, not built
+    if (o->use_luminance < 0 || o->use_luminance > 2 || !(o->length_unit_in_meters > 0.0)) return VPT_E_INVALID;
+    std::string path;
+    if (spectra_file && spectra_file[0]) path = spectra_file;
+    else {
+        Dl_info info;                              // default: data/atmosphere_spectra.bin next to this library
+        if (!dladdr((const void*)&vpt_atmosphere_model, &info) || !info.dli_fname) return VPT_E_IO;
+        path = info.dli_fname;
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/data/atmosphere_spectra.bin";
+    }
+    Spectra S;
+    if (!load_spectra(path.c_str(), S)) return VPT_E_IO;
+    // ---- init's spectra (:1193-1224)
+    const double kRayleigh = 1.24062e-6, kMieAngstromAlpha = 0.0, kMieAngstromBeta = 5.328e-3, kMieScaleHeight = 1200.0, kMieAlbedo = 0.9;
+    const double kRayleighScaleHeight = 8000.0, kGroundAlbedo = 0.01, kConstantSolar = 1.5;
+    const double kMaxOzone = 300.0 * 2.687e20 / 15000.0;
+    std::vector<double> wl, solar, ray, mie_s, mie_e, absx, ground;
+    for (int i = 0; i < S.n; ++i) {
+        const int l = S.lmin + i * S.step;
+        const double lambda = (double)l * 1e-3;
+        const double mie = kMieAngstromBeta / kMieScaleHeight * pow(lambda, -kMieAngstromAlpha);
+        wl.push_back(l);
+        solar.push_back(o->use_constant_solar_spectrum ? kConstantSolar : S.solar[i]);
+        ray.push_back(kRayleigh * pow(lambda, -4));
+        mie_s.push_back(mie * kMieAlbedo);
+        mie_e.push_back(mie);
+        absx.push_back(o->use_ozone ? kMaxOzone * S.ozone[i] : 0.0);
+        ground.push_back(kGroundAlbedo);
+    }
+    const double unit = o->length_unit_in_meters;
+    const double bottom = 6360000.0f, top = 6420000.0f;        // float literals in the reference (:1218-1219)
+    std::memset(p, 0, sizeof(*p));
+    // ---- luminance factors (:903-910): use_luminance != PRECOMPUTED here
+    double sky_k[3], sun_k[3];
+    luminance_factors(S, wl, solar, -3.0, sky_k);
+    luminance_factors(S, wl, solar, 0.0, sun_k);
+    // ---- update_model (:698-784)
+    p->sky_spectral_radiance_to_luminance = {(float)sky_k[0], (float)sky_k[1], (float)sky_k[2]};
+    p->sun_spectral_radiance_to_luminance = {(float)sun_k[0], (float)sun_k[1], (float)sun_k[2]};
+    const double* L = o->lambdas;
+    auto at = [&](const std::vector<double>& fn, double scale) {
+        vpt_float3 r = {(float)(interp(wl, fn, L[0]) * scale), (float)(interp(wl, fn, L[1]) * scale), (float)(interp(wl, fn, L[2]) * scale)};
+        return r;
+    };
+    // float3 lambdas in the reference: the wavelengths pass through a float (:890-896)
+    const double Lf[3] = {(double)(float)L[0], (double)(float)L[1], (double)(float)L[2]};
+    L = Lf;
+    p->solar_irradiance = at(solar, 1.0);
+    p->sun_angular_radius = (float)(0.00935 / 2.0);
+    p->bottom_radius = (float)(bottom / unit);
+    p->top_radius = (float)(top / unit);
+    auto adjust = [&](vpt_density_profile d) {                  // adjust_units :237-245 (double members narrowed to float on assignment)
+        for (int i = 0; i < 2; ++i) {
+            d.layers[i].width = (float)((double)d.layers[i].width / unit);
+            d.layers[i].exp_scale = (float)((double)d.layers[i].exp_scale * unit);
+            d.layers[i].linear_term = (float)((double)d.layers[i].linear_term * unit);
+        }
+        return d;
+    };
+    vpt_density_profile rayleigh, mied, ozone;
+    std::memset(&rayleigh, 0, sizeof(rayleigh)); std::memset(&mied, 0, sizeof(mied)); std::memset(&ozone, 0, sizeof(ozone));
+    rayleigh.layers[1] = {0.0f, 1.0f, (float)(-1.0 / kRayleighScaleHeight), 0.0f, 0.0f};
+    mied.layers[1] = {0.0f, 1.0f, (float)(-1.0 / kMieScaleHeight), 0.0f, 0.0f};
+    ozone.layers[0] = {25000.0f, 0.0f, 0.0f, (float)(1.0 / 15000.0), (float)(-2.0 / 3.0)};
+    ozone.layers[1] = {0.0f, 0.0f, 0.0f, (float)(-1.0 / 15000.0), (float)(8.0 / 3.0)};
+    p->rayleigh_density = adjust(rayleigh);
+    p->rayleigh_scattering = at(ray, unit);
+    p->mie_density = adjust(mied);
+    p->mie_scattering = at(mie_s, unit);
+    p->mie_extinction = at(mie_s, unit);                         // D4: interpolated from the Mie SCATTERING spectrum (:728-730)
+    (void)mie_e;
+    p->mie_phase_function_g = 0.8f;
+    p->absorption_density = adjust(ozone);
+    p->absorption_extinction = at(absx, unit);
+    p->ground_albedo = at(ground, 1.0);
+    p->mu_s_min = (float)cos((o->half_precision ? 102.0 : 120.0) / 180.0 * (double)VPT_PI);       // M_PI is the float macro there
+    p->use_luminance = o->use_luminance;
+    double wr = 1.0, wg = 1.0, wb = 1.0;
+    if (o->do_white_balance) {
+        // convert_spectrum_to_linear_srgb :218-235
+        double x = 0.0, y = 0.0, z = 0.0;
+        const int lmax = S.lmin + S.step * (S.n - 1);
+        for (int l = S.lmin; l < lmax; l += 1) {
+            const double v = interp(wl, solar, l);
+            x += cie_value(S, l, 1) * v; y += cie_value(S, l, 2) * v; z += cie_value(S, l, 3) * v;
+        }
+        const double* m = S.xyz2srgb.data();
+        wr = 683.0 * (m[0] * x + m[1] * y + m[2] * z) * 1;
+        wg = 683.0 * (m[3] * x + m[4] * y + m[5] * z) * 1;
+        wb = 683.0 * (m[6] * x + m[7] * y + m[8] * z) * 1;
+        const double w = (wr + wg + wb) / 3.0;
+        wr /= w; wg /= w; wb /= w;
+    }
+    p->white_point = {(float)wr, (float)wg, (float)wb};
+    p->exposure = o->exposure;
     p->angle = 0.0f;
     return VPT_OK;
 }
