@@ -12,7 +12,7 @@ import sys
 def kernel_summary(db):
     con = sqlite3.connect(db)
     cur = con.cursor()
-    print("%-110s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    print("%-110s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         print("%-110s %8d %14.3f %14.3f %8.3f" % (name[:110], calls, total / 1e3, avg / 1e3, pct))
     print()

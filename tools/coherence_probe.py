@@ -31,6 +31,7 @@ ev = max(1, c[0])
 print("%s: %d sampled gather events; per event: %.1f lanes fetch, %.1f distinct 8^3 bricks (%.2f lanes per brick), %.1f distinct 4^3 bricks, "
       "%.2f lines per lane (own taps), %.1f distinct 128-B lines per event (%.2f per lane)"
       % (a.config, c[0], c[1] / ev, c[2] / ev, c[1] / max(1, c[2]), c[3] / ev, c[4] / max(1, c[1]), c[5] / ev, c[5] / max(1, c[1])))
+print("traced rays that crossed empty nodes only (no draw, no look-up): %d of %d queued (%.1f %%)" % (c[6], st.queued_rays, 100.0 * c[6] / max(1, st.queued_rays)))
 if o[0]:
     print("schedule: per pass walking %.1f, parked-in-T %.1f, idle %.1f lanes; tracking-step lanes %.1f/pass; density look-ups per sample %.2f"
           % (o[1] / o[0], o[2] / o[0], o[3] / o[0], o[7] / o[0], st.density_lookups / max(1, st.samples)))

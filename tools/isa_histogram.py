@@ -3,8 +3,26 @@
     python tools/isa_histogram.py <demangled-name-regex> [lib.so]"""
 import collections, os, re, struct, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pat = re.compile(sys.argv[1])
-so = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "volumetric-path-tracer_amd", "libvpt_hip.so")
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+pat = re.compile(args[0])
+so = args[1] if len(args) > 1 else os.path.join(ROOT, "volumetric-path-tracer_amd", "libvpt_hip.so")
+WANT_CYCLES = "--cycles" in sys.argv
+
+
+def issue_cycles(op):
+    """measured issue cycles per wave64 instruction at 8 waves per SIMD (profiles/r02_valu_issue_probe.txt); None: not a VALU instruction"""
+    if not op.startswith("v_"):
+        return None
+    o = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if o.startswith(("v_rcp", "v_sqrt", "v_rsq", "v_log", "v_exp", "v_sin", "v_cos")):
+        return 8.1
+    cheap = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
+             "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_fmamk_f32", "v_fmaak_f32", "v_mul_legacy_f32", "v_cndmask_b32", "v_cmp", "v_accvgpr", "v_nop")
+    if o.startswith(cheap) and not op.endswith("_e64") and not op.endswith("_dpp") and not op.endswith("_sdwa"):
+        return 2.3
+    if o.startswith("v_fma_f32") or o.startswith("v_mov_b32"):
+        return 2.3
+    return 4.2
 data = open(so, "rb").read()
 pos = 0
 while True:
@@ -51,3 +69,11 @@ while True:
             else: cls["other"] += n
         print("   " + ", ".join("%s %d (%.0f%%)" % (a, b, 100.0 * b / tot) for a, b in cls.most_common()))
         print("   top: " + ", ".join("%s %d" % kv for kv in c.most_common(40)))
+        if WANT_CYCLES:
+            tot_c, tot_n = 0.0, 0
+            for op, n in c.items():
+                cyc = issue_cycles(op)
+                if cyc is not None:
+                    tot_c += cyc * n
+                    tot_n += n
+            print("   mean VALU issue cycles (static mix): %.3f over %d VALU instructions" % (tot_c / max(1, tot_n), tot_n))

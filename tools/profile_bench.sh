@@ -4,7 +4,7 @@
 #   tools/profile_bench.sh <tag> [bench args...]
 set -u
 TAG=${1:-prof}; shift || true
-ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-per-frame}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT

@@ -79,8 +79,11 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
     __shared__ uint32_t s_q[64 * VPT_RAYGEN_ROWS];
     __shared__ uint32_t s_n, s_base;
+    __shared__ uint32_t s_occ[20];
     if (threadIdx.x == 0 && threadIdx.y == 0) s_n = 0;
+    if (threadIdx.y == 0 && threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
+    uint32_t n_empty_skips = 0;                       // counting builds: empty-node pushes of the rays resolved here
     // 1-D grid in TILE-major order, the batch's iterations of one 64x64 tile back to back: the queue then
     // holds a tile's rays of all iterations contiguously, so the rays the tracer has in flight at any time
     // come from a few neighbouring tiles and touch a small part of the grid (L2 / Infinity Cache locality
@@ -139,6 +142,37 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                 float t_far;
                 traced = rendered && box_intersect(ld3(P.root_pmin), ld3(P.root_pmax), org0, inv0, t_box, t_far);
             }
+            // direct_integrator: a ray whose walk only ever crosses EMPTY octree nodes draws no random number and looks nothing up.
+            // sample() pushes it from node to node (:1613-1616) until it is outside the root (:1606), returns WHITE without an
+            // interaction, and if get_closest_object finds nothing from there (:1806) every later loop iteration is a no-op: the
+            // path ends with L = 0, beta = 1, alpha = 0, depth = 0 and its primary ray -- exactly what a ray that misses the box
+            // ends with.  27 % of config 2's traced rays are of this kind (the dragon fills a fraction of its padded bounding
+            // box); their pushes are walked here, with the tracer's own operations, and they never enter the queue.
+            if (traced && P.integrator == 0 && obj == 1 && !P.octree_full_single) {
+                f3 pos = org0;
+                pos += dir0 * (t_hit + VPT_EPS);                                    // :1783-1785, as the tracer's refill does
+                const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
+                f3 nmin = mk3(0.0f), nmax = mk3(0.0f);
+                int leaf = 0, st = LOC_EMPTY;
+                uint32_t pushes = 0;
+#pragma unroll 1
+                for (int it = 0; it < 32; ++it) {
+                    st = locate(P, s_occ, occ_top, pos, nmin, nmax, leaf);
+                    if (st != LOC_EMPTY) break;
+                    float t_min, t_max;
+                    box_intersect(nmin, nmax, pos, inv0, t_min, t_max);
+                    t_max = fmax_(t_max, 0.1f);
+                    pos += dir0 * t_max;
+                    pushes++;
+                }
+                if (st == LOC_OUTSIDE) {
+                    float t2;
+                    if (closest_object(P, pos, dir0, inv0, t2) == 0) {
+                        traced = false;
+                        if (COUNT) n_empty_skips += 2u * pushes;                    // depth pass + integrator: the reference walks them twice
+                    }
+                }
+            }
             if (closed && traced) {
                 rng_init(rng, pixel, iteration * 4096u);
                 f3 pd;
@@ -196,6 +230,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     const uint32_t gbase = s_base;
     for (uint32_t i = tid; i < n; i += 256u) P.queue[gbase + i] = s_q[i];
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
+    if (COUNT && n_empty_skips) atomicAdd(&P.counters->skip_steps, (unsigned long long)n_empty_skips);
 }
 #ifndef VPT_TRACE_WAVES_PER_EU
 #define VPT_TRACE_WAVES_PER_EU 3
@@ -579,6 +614,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
                 if (COUNT) {
                     atomicAdd(&P.counters->samples, 1ull);
+                    if (cnt.n_steps == 0u) atomicAdd(&P.counters->coh[6], 1ull);       // traced rays that crossed empty nodes only (no draw, no look-up)
                     atomicAdd(&P.counters->density_lookups, (unsigned long long)cnt.n_d);
                     atomicAdd(&P.counters->color_lookups, (unsigned long long)cnt.n_c);
                     atomicAdd(&P.counters->emission_lookups, (unsigned long long)cnt.n_e);
