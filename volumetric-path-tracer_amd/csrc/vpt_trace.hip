@@ -72,8 +72,9 @@ enum : uint32_t {
 //     direct_integrator's loop is then a no-op and depth = 0), or
 //   * a 64-byte RAY record {org0, t_hit | dir0, obj | philox block | counter, word, depth} and the
 //     slot index into the work queue (wave-ballot compaction, one atomic per wave).
-#define VPT_RAYGEN_ROWS 64        // pixel rows per raygen block (block = 64 x 4 threads, 16 passes)
-template <bool COUNT>
+// ROWS: pixel rows per raygen block (block = 64 x 4 threads, ROWS / 4 passes): 64 for batches (one queue-tail atomic per 4096
+// samples), 16 for launches of a few iterations (the per-frame call, main.cpp:1822-1829: four times the blocks to fill the chip)
+template <bool COUNT, int VPT_RAYGEN_ROWS>
 __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     // grid: tiles x iterations (1-D, tile-major); a block sweeps a 64x64 pixel tile in 16 passes and
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
@@ -649,9 +650,16 @@ static hipError_t launch_variant(const TraceParams& P, int blocks, hipStream_t s
 }
 
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream) {
-    const dim3 grid(((P.width + 63u) / 64u) * ((P.height + VPT_RAYGEN_ROWS - 1u) / VPT_RAYGEN_ROWS) * P.iter_count), block(64, 4, 1);
-    if (P.counters) hipLaunchKernelGGL((raygen_kernel<true>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((raygen_kernel<false>), grid, block, 0, stream, P);
+    const bool small = P.iter_count < 8u;
+    const uint32_t rows = small ? 16u : 64u;
+    const dim3 grid(((P.width + 63u) / 64u) * ((P.height + rows - 1u) / rows) * P.iter_count), block(64, 4, 1);
+    if (small) {
+        if (P.counters) hipLaunchKernelGGL((raygen_kernel<true, 16>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((raygen_kernel<false, 16>), grid, block, 0, stream, P);
+    } else {
+        if (P.counters) hipLaunchKernelGGL((raygen_kernel<true, 64>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((raygen_kernel<false, 64>), grid, block, 0, stream, P);
+    }
     return hipGetLastError();
 }
 
