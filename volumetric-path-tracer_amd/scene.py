@@ -21,6 +21,9 @@ from .host import Context, load_library
 FLT_EPSILON = np.float32(1.1920929e-07)
 FLT_MAX = np.float32(3.4028235e38)
 
+# scene assets of the package itself: decoded copies of the reference's dragon.vdb grid, BN0.bmp and its two look-up EXRs (written by
+# tests/golden/make_fixtures.py), so that the product never reads from the test tree; the test-only fixtures stay in tests/golden
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -89,7 +92,8 @@ def default_sphere():
 
 
 def load_golden(name):
-    return np.load(os.path.join(GOLDEN_DIR, name))
+    p = os.path.join(DATA_DIR, name)
+    return np.load(p if os.path.exists(p) else os.path.join(GOLDEN_DIR, name))
 
 
 def blue_noise_from_rgb(rgb):
