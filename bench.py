@@ -164,8 +164,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     local_rank = dev_index
     import torch.distributed as dist
-    if world > 1:
+    # VPT_BENCH_FORCE_DIST=1: run the N-rank step (process group, RCCL communicator under the C ABI, stream-ordered reduce) with a
+    # single rank -- the functional check of that code path on a 1-GPU box (tests/test_gpu_bench_ranks.py)
+    multi = world > 1 or bool(os.environ.get("VPT_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -187,14 +191,14 @@ def main():
         first_it, stride, bn_pre = pkg.dist.stripe(rank, world)
         bn0 = hb.blue_noise.clone()
         torch.cuda.synchronize(dev)
-        use_comm = world > 1 and backend == "nccl"
+        use_comm = multi and backend == "nccl"
         if use_comm:
             pkg.dist.init_comm(hb.ctx)                   # RCCL communicator of this context (id carried by torch.distributed)
         # everything a step enqueues goes to the context's own stream; torch ops on it through an ExternalStream view
         cstream = torch.cuda.ExternalStream(hb.ctx.stream, device=dev)
 
         def one_step():
-            if world == 1:
+            if not multi:
                 # the next `spp` iterations of the progressive render (iteration indices, blue-noise table and running means
                 # carry on from the previous step, as consecutive frames of the reference do): no host round trip between steps
                 hb.render(spp)
@@ -214,7 +218,7 @@ def main():
                 torch.cuda.synchronize(dev)
 
         def fence():
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -228,7 +232,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         st = hb.ctx.stats()                               # per-kernel HIP-event times of the LAST step (events on the ctx stream)
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -255,11 +259,11 @@ def main():
                            "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
                 "roofline": roofline,
             }
-            if with_extras and world == 1 and not args.no_per_frame:
+            if with_extras and not multi and not args.no_per_frame:
                 out["per_frame"] = per_frame(hb, sd, bn0, W, H)
-            if with_extras and world == 1 and not args.no_cpu_baseline:
+            if with_extras and not multi and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(hb, sd, bn0, W, H, spp)
-        if world > 1:
+        if multi:
             dist.barrier()
         hb.ctx.close()
         del hb
@@ -317,7 +321,7 @@ def main():
                 "parity_note": "HIP accum / depth buffers vs this CPU render after the same %d iterations at full size (tolerance 1e-3 rel. L2)" % args.cpu_iters}
 
     out = measure(cfg, spp, args.steps, args.warmup, args.width, args.height, True)
-    if world == 1 and not args.no_other_configs and cfg == "c2":
+    if not multi and not args.no_other_configs and cfg == "c2":
         others = []
         for oc in ("c3", "c4", "c5"):
             o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False)
@@ -328,7 +332,7 @@ def main():
             out["other_configs"] = others
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -130,3 +130,16 @@ def test_cli_two_ranks_equal_one(pkg, tmp_path):
         assert info["ranks"] == ranks
         imgs.append(tc._read_pfm(out + ".pfm"))
     np.testing.assert_allclose(imgs[0], imgs[1], rtol=2e-5, atol=1e-7)
+
+
+def test_bench_rccl_step_with_one_rank():
+    """bench.py's N-rank step with the REAL backend on this 1-GPU box: VPT_BENCH_FORCE_DIST runs it with a single rank -- nccl (= RCCL)
+    process group, the context's RCCL communicator created from an id carried by torch.distributed, blue-noise reset + render +
+    vpt_allreduce_accum enqueued on the context's stream without host fences, barrier + max-over-ranks timing.  What a second GPU
+    would add is the traffic inside ncclAllReduce."""
+    env = dict(os.environ, VPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "per_frame" not in d and "other_configs" not in d
