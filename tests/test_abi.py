@@ -38,7 +38,8 @@ def test_struct_layouts_match_the_c_compiler(pkg, tmp_path):
     pairs = [("vpt_camera", abi.Camera), ("vpt_point_light", abi.PointLight), ("vpt_light_list", abi.LightList),
              ("vpt_sphere", abi.Sphere), ("vpt_vdb_info", abi.VdbInfo), ("vpt_gpu_vdb", abi.GpuVdb),
              ("vpt_density_profile", abi.DensityProfile), ("vpt_atmosphere_parameters", abi.AtmosphereParameters),
-             ("vpt_kernel_params", abi.KernelParams), ("vpt_texture_desc", abi.TextureDesc), ("vpt_render_stats", abi.RenderStats)]
+             ("vpt_kernel_params", abi.KernelParams), ("vpt_texture_desc", abi.TextureDesc), ("vpt_render_stats", abi.RenderStats),
+             ("vpt_atmosphere_model_options", abi.AtmosphereModelOptions)]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "vpt_abi.h"), "int main(){"]
     expect = []
     for cname, cls in pairs:
