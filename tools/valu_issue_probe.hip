@@ -81,7 +81,7 @@ constexpr int UNROLL = 32;       // instructions per loop body (8 chains x 4)
 
 enum {
     K_FMA, K_FMA_DEP, K_ADDF, K_MULF, K_MAXF, K_ADDU, K_AND, K_LSHL, K_MOV, K_MULLO, K_MULHI, K_MUL24, K_MAD24, K_CNDMASK, K_CMP,
-    K_RCP, K_SQRT, K_LOG, K_EXP, K_CVT, K_FLOOR, K_DIVFIX, K_FMAS, K_MED3, K_BFE, K_DPP, K_READFIRST, K_FMA64, K_PKFMA, K_DSREAD, K_CND64, K_CMP64, K_CMPCND, K_ADDCO, K_CMPU, K_MINF, K_SUBF, K_FMAC, K_MADF, K_XOR, K_LSHLADD, K_ADD3, K_CVTI, K_MULLIT, K_ADDK, K_CMPFMA, K_SALU, K_SAND64, K_P1, K_P2, K_P3, K_P4, K_P5, K_P6, K_P7, K_COUNT
+    K_RCP, K_SQRT, K_LOG, K_EXP, K_CVT, K_FLOOR, K_DIVFIX, K_FMAS, K_MED3, K_BFE, K_DPP, K_READFIRST, K_FMA64, K_PKFMA, K_DSREAD, K_CND64, K_CMP64, K_CMPCND, K_ADDCO, K_CMPU, K_MINF, K_SUBF, K_FMAC, K_MADF, K_XOR, K_LSHLADD, K_ADD3, K_CVTI, K_MULLIT, K_ADDK, K_CMPFMA, K_SALU, K_SAND64, K_P1, K_P2, K_P3, K_P4, K_P5, K_P6, K_P7, K_ADDS, K_MULS, K_FMACS, K_SUBS, K_ADDUS, K_FMA2S, K_MAXK, K_COUNT
 };
 static const char* kNames[K_COUNT] = {
     "v_fma_f32 (8 chains)", "v_fma_f32 (1 dependent chain)", "v_add_f32", "v_mul_f32", "v_max_f32", "v_add_u32", "v_and_b32", "v_lshlrev_b32",
@@ -92,7 +92,9 @@ static const char* kNames[K_COUNT] = {
     "v_min_f32", "v_sub_f32", "v_fmac_f32", "v_mul_legacy_f32", "v_xor_b32", "v_lshl_add_u32", "v_add3_u32", "v_cvt_i32_f32", "v_mul_f32 (32-bit literal)",
     "v_add_f32 (inline const)", "v_cmp + 3 v_fma (per 4)", "s_add_u32", "s_and_b64",
     "P1: v_cmp_f32 vcc + 3 v_cndmask vcc (per 4)", "P2: s_mov vcc once; v_cndmask vcc x32", "P3: 2 v_cmp_f32 vcc + 2 v_fma (per 4)", "P4: 2 v_cndmask vcc + 2 v_fma (per 4)",
-    "P5: v_cmp_e64 sgpr + 3 v_cndmask_e64 (per 4)", "P6: v_cmp_f32 vcc x32, other data", "P7: v_cmp_lt_u32 vcc + 3 v_cndmask (per 4)"};
+    "P5: v_cmp_e64 sgpr + 3 v_cndmask_e64 (per 4)", "P6: v_cmp_f32 vcc x32, other data", "P7: v_cmp_lt_u32 vcc + 3 v_cndmask (per 4)",
+    "v_add_f32 v, SGPR, v (VOP2 e32)", "v_mul_f32 v, SGPR, v (VOP2 e32)", "v_fmac_f32 v, SGPR, v (VOP2 e32)", "v_sub_f32 v, SGPR, v (VOP2 e32)",
+    "v_add_u32 v, SGPR, v (VOP2 e32)", "v_fma_f32 v, v, SGPR, SGPR (same SGPR)", "v_max_f32 v, 0, v (inline const)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void probe(unsigned long long* spans, float* sink, uint64_t exec_mask, float fa, float fb) {
@@ -163,6 +165,13 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* spans, float* s
             else if (KIND == K_P5) { asm volatile(".rept 8\n v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20", "s21"); }
             else if (KIND == K_P6) { asm volatile(".rept 4\n" OP_CMP("0") OP_CMP("1") OP_CMP("2") OP_CMP("3") OP_CMP("4") OP_CMP("5") OP_CMP("6") OP_CMP("7") ".endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b), "v"(a), "s"(sa) : "vcc"); }
             else if (KIND == K_P7) { asm volatile(".rept 8\n v_cmp_lt_u32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "vcc"); }
+            else if (KIND == K_ADDS) { asm volatile(".rept 4\n v_add_f32 %0, %10, %0\n v_add_f32 %1, %10, %1\n v_add_f32 %2, %10, %2\n v_add_f32 %3, %10, %3\n v_add_f32 %4, %10, %4\n v_add_f32 %5, %10, %5\n v_add_f32 %6, %10, %6\n v_add_f32 %7, %10, %7\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_MULS) { asm volatile(".rept 4\n v_mul_f32 %0, %10, %0\n v_mul_f32 %1, %10, %1\n v_mul_f32 %2, %10, %2\n v_mul_f32 %3, %10, %3\n v_mul_f32 %4, %10, %4\n v_mul_f32 %5, %10, %5\n v_mul_f32 %6, %10, %6\n v_mul_f32 %7, %10, %7\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_FMACS) { asm volatile(".rept 4\n v_fmac_f32 %0, %10, %8\n v_fmac_f32 %1, %10, %8\n v_fmac_f32 %2, %10, %8\n v_fmac_f32 %3, %10, %8\n v_fmac_f32 %4, %10, %8\n v_fmac_f32 %5, %10, %8\n v_fmac_f32 %6, %10, %8\n v_fmac_f32 %7, %10, %8\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_SUBS) { asm volatile(".rept 4\n v_sub_f32 %0, %10, %0\n v_sub_f32 %1, %10, %1\n v_sub_f32 %2, %10, %2\n v_sub_f32 %3, %10, %3\n v_sub_f32 %4, %10, %4\n v_sub_f32 %5, %10, %5\n v_sub_f32 %6, %10, %6\n v_sub_f32 %7, %10, %7\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_ADDUS) { asm volatile(".rept 4\n v_add_u32 %0, %10, %0\n v_add_u32 %1, %10, %1\n v_add_u32 %2, %10, %2\n v_add_u32 %3, %10, %3\n v_add_u32 %4, %10, %4\n v_add_u32 %5, %10, %5\n v_add_u32 %6, %10, %6\n v_add_u32 %7, %10, %7\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_FMA2S) { asm volatile(".rept 4\n v_fma_f32 %0, %0, %10, %10\n v_fma_f32 %1, %1, %10, %10\n v_fma_f32 %2, %2, %10, %10\n v_fma_f32 %3, %3, %10, %10\n v_fma_f32 %4, %4, %10, %10\n v_fma_f32 %5, %5, %10, %10\n v_fma_f32 %6, %6, %10, %10\n v_fma_f32 %7, %7, %10, %10\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
+            else if (KIND == K_MAXK) { asm volatile(".rept 4\n v_max_f32 %0, 0, %0\n v_max_f32 %1, 0, %1\n v_max_f32 %2, 0, %2\n v_max_f32 %3, 0, %3\n v_max_f32 %4, 0, %4\n v_max_f32 %5, 0, %5\n v_max_f32 %6, 0, %6\n v_max_f32 %7, 0, %7\n .endr\n" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa)); }
             else if (KIND == K_READFIRST) {
                 asm volatile(".rept 4\n" OP_READLANE("0") OP_READLANE("1") OP_READLANE("2") OP_READLANE("3") OP_READLANE("4") OP_READLANE("5") OP_READLANE("6") OP_READLANE("7") ".endr\n"
                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "s"(sa) : "s20");
