@@ -387,7 +387,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         VPT_TICK(tc1);
         if (phase >= PH_W_FIRST && phase <= PH_W_LAST) {
             const int kind = phase <= PH_W_TRACK ? WALK_SAMPLE : (phase == PH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false);
+            // (one-piece step: moving the refill behind the step, as the split-phase look-up of the vol tracer needs, costs this tracer
+            // 16 % -- its refilled lanes would idle for a pass -- against 1 % gained from the overlap; measured, not used here)
+            Pending no_pd;
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;

@@ -288,6 +288,46 @@ VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, co
     const float c1 = c01 + (c11 - c01) * t.ay;
     return c0 + (c1 - c0) * t.az;
 }
+// The same fetch in two halves (split-phase look-up, vpt_walk.h): `issue` requests the eight texels, `lerp8` interpolates them with
+// the operation order of fetch_f32 -- whatever runs between the two overlaps the memory latency.
+struct Pending {
+    float c[8];           // c000 c100 c010 c110 c001 c101 c011 c111
+    float ax, ay, az;
+    int state;            // 0 none, 1 density known to be 0 (point outside the grid's domain), 2 texels in flight
+};
+template <bool A24>
+VPT_D void issue_f32(const float* __restrict__ g_, const DVolume& v, const Taps& t, Pending& pd) {
+    const gptr_f g = (gptr_f)g_;
+    if (v.bricked) {
+        const uint32_t row = (uint32_t)v.bdim[0] * 64u, slab = (uint32_t)v.bdim[1] * row;
+        const uint32_t x0 = (((uint32_t)t.i0 >> 2) << 6) + ((uint32_t)t.i0 & 3u), x1 = (((uint32_t)t.i1 >> 2) << 6) + ((uint32_t)t.i1 & 3u);
+        const uint32_t y0 = imul<A24>((uint32_t)t.j0 >> 2, row) + (((uint32_t)t.j0 & 3u) << 2), y1 = imul<A24>((uint32_t)t.j1 >> 2, row) + (((uint32_t)t.j1 & 3u) << 2);
+        const uint32_t z0 = imul<A24>((uint32_t)t.k0 >> 2, slab) + (((uint32_t)t.k0 & 3u) << 4), z1 = imul<A24>((uint32_t)t.k1 >> 2, slab) + (((uint32_t)t.k1 & 3u) << 4);
+        pd.c[0] = g[z0 + y0 + x0]; pd.c[1] = g[z0 + y0 + x1];
+        pd.c[2] = g[z0 + y1 + x0]; pd.c[3] = g[z0 + y1 + x1];
+        pd.c[4] = g[z1 + y0 + x0]; pd.c[5] = g[z1 + y0 + x1];
+        pd.c[6] = g[z1 + y1 + x0]; pd.c[7] = g[z1 + y1 + x1];
+    } else {
+        const uint32_t dx = (uint32_t)v.dim[0];
+        const uint32_t s0 = imul<A24>((uint32_t)t.k0, (uint32_t)v.dim[1]), s1 = imul<A24>((uint32_t)t.k1, (uint32_t)v.dim[1]);
+        const uint32_t r00 = imul<A24>(s0 + (uint32_t)t.j0, dx), r10 = imul<A24>(s0 + (uint32_t)t.j1, dx);
+        const uint32_t r01 = imul<A24>(s1 + (uint32_t)t.j0, dx), r11 = imul<A24>(s1 + (uint32_t)t.j1, dx);
+        pd.c[0] = g[r00 + t.i0]; pd.c[1] = g[r00 + t.i1];
+        pd.c[2] = g[r10 + t.i0]; pd.c[3] = g[r10 + t.i1];
+        pd.c[4] = g[r01 + t.i0]; pd.c[5] = g[r01 + t.i1];
+        pd.c[6] = g[r11 + t.i0]; pd.c[7] = g[r11 + t.i1];
+    }
+    pd.ax = t.ax; pd.ay = t.ay; pd.az = t.az;
+}
+VPT_D float lerp8(const Pending& pd) {
+    const float c00 = pd.c[0] + (pd.c[1] - pd.c[0]) * pd.ax;
+    const float c10 = pd.c[2] + (pd.c[3] - pd.c[2]) * pd.ax;
+    const float c01 = pd.c[4] + (pd.c[5] - pd.c[4]) * pd.ax;
+    const float c11 = pd.c[6] + (pd.c[7] - pd.c[6]) * pd.ax;
+    const float c0 = c00 + (c10 - c00) * pd.ay;
+    const float c1 = c01 + (c11 - c01) * pd.ay;
+    return c0 + (c1 - c0) * pd.az;
+}
 VPT_D f4 lerp4(f4 a, f4 b, float t) { return a + (b - a) * t; }
 template <bool A24>
 VPT_D f3 fetch_f4(const f4* __restrict__ g_, const int* dim, const Taps& t) {

@@ -197,7 +197,33 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
     uint32_t qi0 = 0, qi1 = 0, qi2 = 0, qi3 = 0;       // this wave's chunk of queue entries, 4 per lane
 
     for (;;) {
-        // ==== refill idle lanes from the compacted ray queue (as in vpt_trace.hip) ============
+        // ==== one tracking step for every walking lane =====================================
+        // The density look-up of the single-volume kernels is split-phase (vpt_walk.h): the step requests its texels here ...
+        rng_top_up(rng, pixel);
+        constexpr bool SPLIT = !MULTI;
+        Pending pd;
+        pd.state = 0;
+        {
+            int r = WALK_GOES_ON;
+            if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
+                const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
+                r = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24, SPLIT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
+                                                                            retry, phase == VH_W_TRACK, pd);
+            }
+            if (r != WALK_PENDING) pd.state = 0;
+            if (r == WALK_DONE) {
+                if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
+                else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
+                else if (phase == VH_W_EMIT) phase = VH_T_EMIT_DONE;
+                else {
+                    w.trw = tr_end(K, w);
+                    phase = tr_next;
+                }
+            }
+        }
+
+        // ==== ... idle lanes are refilled from the compacted ray queue while those texels travel (the record read is the other
+        // long latency of a pass; a refilled lane takes its first step in the next pass) ...
         const unsigned long long idle = __ballot(phase == VH_IDLE);
         if (idle != 0ull) {
             const unsigned long long active = __ballot(1);
@@ -263,16 +289,13 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
             }
         }
 
-        // ==== one tracking step for every walking lane =====================================
-        rng_top_up(rng, pixel);
-        if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
-            const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
-                                                                   retry, phase == VH_W_TRACK);
+        // ==== ... and the steps with texels in flight interpolate and decide ====================
+        if (SPLIT && pd.state != 0) {
+            const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : WALK_TR;
+            const bool done = walk_finish<COLOR, COUNT, A24>(P, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, pd);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
                 else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
-                else if (phase == VH_W_EMIT) phase = VH_T_EMIT_DONE;
                 else {
                     w.trw = tr_end(K, w);
                     phase = tr_next;

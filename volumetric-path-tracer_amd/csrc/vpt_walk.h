@@ -194,10 +194,52 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
 // same exit distance and sphere test and differs only in its exponential draw, so it is replayed
 // right here (one draw + one log per retry, as many as the buffered Philox words allow) instead of costing
 // a pass of the walk loop each.
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24>
-VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
-                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
-                     int& retries, bool use_retries) {
+// What follows a step's density look-up: sample() accepts or rejects the collision (:1667-1675), Tr() multiplies its estimate
+// (:1239, :1261).  Shared by the one-piece step and the second half of the split-phase step.  Returns true when the walk ended.
+template <bool MULTI, bool COLOR, bool COUNT, bool A24>
+VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample, bool record_hist, float* hist, uint32_t& n_hist, Walk& w, Rng& rng,
+                       uint32_t& draws, float density, int leaf, int cell) {
+    if (is_sample) {
+        // The density-colour LUT value only matters on a real collision, so its index (one correctly rounded divide by
+        // emission_pivot) and fetch are evaluated there.
+        if (w.alpha < 1.0f) w.alpha += density;
+        if (record_hist) {
+            if (n_hist < VPT_HIST_CAP) hist[n_hist * 256] = density;
+            n_hist++;
+        }
+        if (density * K.inv_max > rnd(rng, draws)) {
+            f3 Cd = COLOR ? mk3(0.0f) : mk3(1.0f);
+            if (COLOR) {
+                uint32_t z0 = 0, z1 = 0, z2 = 0;
+                float dz = 0.0f;
+                f3 ez = mk3(0.0f);
+                for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) { // sum_color :931 (component-wise max)
+                    lookup_volume<COLOR, false, false, false, A24, COUNT>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
+                });
+            }
+            const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
+            const float* dc = P.density_color_lut + 3 * index;
+            w.mi = true;
+            w.wgt = (ld3(P.albedo) * Cd * mk3(dc[0], dc[1], dc[2]) / ld3(P.extinction)) * P.energy_inject;
+            return true;
+        }
+    } else {
+        w.trw *= 1 - ((density - K.sigma_c) * K.sigma_r_inv);                 // :1239
+        const float s2 = w.trw * w.trw;
+        if ((s2 + s2 + s2) < VPT_SQ_OF_EPS) return true;                      // :1261 length(tr) < EPS, without the root
+    }
+    return false;
+}
+
+// SPLIT (single-volume kernels): the density look-up of a delta- or ratio-tracking step is SPLIT-PHASE.  walk_step only requests the
+// eight texels (returns WALK_PENDING, `pd` holds them) and the caller runs whatever else the wave has to do -- refilling idle
+// lanes from the ray queue, itself a ~1 us record read -- before walk_finish interpolates and decides: the two memory
+// latencies of a pass overlap instead of adding up.  Per lane the operations and their order are unchanged.
+enum { WALK_GOES_ON = 0, WALK_DONE = 1, WALK_PENDING = 2 };
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false>
+VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
+                    float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
+                    int& retries, bool use_retries, Pending& pd) {
     const bool is_sample = kind == WALK_SAMPLE;
     const bool is_emit = EMIT && kind == WALK_EMIT;
     // Empty-node pushes are cheap and the tracking step below is expensive, so the wave first loops
@@ -230,8 +272,8 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
 #ifdef VPT_PROFILE_SECTIONS
     if (!COUNT) c.n_skips += (uint32_t)(__builtin_readcyclecounter() - tp0_);      // cycles of the skip loop (perf study)
 #endif
-    if (st == LOC_EMPTY) return false;           // still crossing empty nodes: next pass
-    if (st == LOC_OUTSIDE) return true;
+    if (st == LOC_EMPTY) return WALK_GOES_ON;    // still crossing empty nodes: next pass
+    if (st == LOC_OUTSIDE) return WALK_DONE;
     if (COUNT) {
         const unsigned long long m = __ballot(1);
         if (__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&P.counters->sched[7], (unsigned long long)__popcll(m));
@@ -260,15 +302,30 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
                 // a retry draws once and a step that goes on draws a second time: stay within the words
                 // buffered since the pass's refill point (vpt_rng.h), and do not hold the wave up for long
                 const uint32_t buffered = (rng.has_carry ? 1u : 0u) + (4u - rng.idx);
-                if (buffered < 2u || ++spins >= VPT_RETRY_SPINS) return false;
+                if (buffered < 2u || ++spins >= VPT_RETRY_SPINS) return WALK_GOES_ON;
                 continue;
             }
-            return true;
+            return WALK_DONE;
         }
         break;
     }
     w.pos += w.dir * w.t;                                                     // cumulative t (Q-list 1)
-    if (!contains(K.root_lo, K.root_hi, w.pos)) return true;
+    if (!contains(K.root_lo, K.root_hi, w.pos)) return WALK_DONE;
+    if (SPLIT && !MULTI && !is_emit) {
+        // request the texels, decide later (walk_finish)
+        f3 u;
+        const bool inside = to_unit(P.vol0.m, P.vol0, w.pos, u);
+        if (COUNT) c.n_d++;
+        if (COUNT) count_fetch(P, 0, inside);
+        if (COLOR && COUNT && is_sample && P.vol0.has_color) c.n_c++;          // the reference looks the colour up here (:1662)
+        pd.state = 1;
+        if (inside) {
+            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, u), pd);
+            pd.state = 2;
+        }
+        if (COUNT) coherence_stats<A24>(P, w.pos);
+        return WALK_PENDING;
+    }
     float density = 0.0f;
     f3 Cd = COLOR ? mk3(0.0f) : mk3(1.0f);
     f3 em = mk3(0.0f);
@@ -296,37 +353,19 @@ VPT_D bool walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkCons
         });
     }
     if (COUNT && !MULTI && !is_emit) coherence_stats<A24>(P, w.pos);
-    if (is_sample) {
-        // :1667-1675.  The density-colour LUT value only matters on a real collision, so its index
-        // (one correctly rounded divide by emission_pivot) and fetch are evaluated there.
-        if (w.alpha < 1.0f) w.alpha += density;
-        if (record_hist) {
-            if (n_hist < VPT_HIST_CAP) hist[n_hist * 256] = density;
-            n_hist++;
-        }
-        if (density * K.inv_max > rnd(rng, draws)) {
-            if (COLOR) {
-                uint32_t z0 = 0, z1 = 0, z2 = 0;
-                float dz = 0.0f;
-                f3 ez = mk3(0.0f);
-                for_each_instance<MULTI>(P, leaf, cell, [&](const float* m, const DVolume& v) { // sum_color :931 (component-wise max)
-                    lookup_volume<COLOR, false, false, false, A24, COUNT>(P, m, v, w.pos, false, true, false, dz, Cd, ez, z0, z1, z2);
-                });
-            }
-            const int index = (int)floorf(fmin_(fmax_((density * K.inv_max * 255.0f / P.emission_pivot), 0.0f), 255.0f));
-            const float* dc = P.density_color_lut + 3 * index;
-            w.mi = true;
-            w.wgt = (ld3(P.albedo) * Cd * mk3(dc[0], dc[1], dc[2]) / ld3(P.extinction)) * P.energy_inject;
-            return true;
-        }
-    } else if (is_emit) {
+    if (is_emit) {
         w.Ld += em;                                                           // :1335
-    } else {
-        w.trw *= 1 - ((density - K.sigma_c) * K.sigma_r_inv);                 // :1239
-        const float s2 = w.trw * w.trw;
-        if ((s2 + s2 + s2) < VPT_SQ_OF_EPS) return true;                      // :1261 length(tr) < EPS, without the root
+        return WALK_GOES_ON;
     }
-    return false;
+    return walk_decide<MULTI, COLOR, COUNT, A24>(P, K, is_sample, record_hist, hist, n_hist, w, rng, draws, density, leaf, cell) ? WALK_DONE : WALK_GOES_ON;
+}
+
+// second half of a split-phase step: the texels requested by walk_step have (had time to) arrive
+template <bool COLOR, bool COUNT, bool A24>
+VPT_D bool walk_finish(const TraceParams& P, const WalkConst& K, int kind, bool record_hist, float* hist, uint32_t& n_hist, Walk& w, Rng& rng,
+                       uint32_t& draws, const Pending& pd) {
+    const float density = pd.state == 2 ? lerp8(pd) : 0.0f;
+    return walk_decide<false, COLOR, COUNT, A24>(P, K, kind == WALK_SAMPLE, record_hist, hist, n_hist, w, rng, draws, density, 0, 0);
 }
 
 // Tr prologue :1153-1167 (shared by sun / point-light / sky / sphere shadow rays): returns true
