@@ -598,7 +598,23 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         f3 nmin, nmax;
                         int leaf;
                         const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
-                        phase = locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE ? PH_T_TRACK_DONE : PH_W_TRACK;
+                        if (locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf) == LOC_OUTSIDE) {
+                            // ... and what follows such a walk is fixed: every one of the volume_depth inner iterations returns at
+                            // once (beta *= WHITE, no interaction, :1789-1796), then get_closest_object is asked again from here
+                            // (:1806).  Nothing there (the usual case: the ray has left the box for good) ends the path; it is
+                            // finished in this very round instead of going round the state list once more (TRACK_DONE sits before
+                            // this state).  A sphere ahead goes through OUTER_SECOND with the result cached.
+                            gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t);
+                            if (gco_obj == 0) {
+                                rd++;
+                                phase = PH_T_FINISH;
+                            } else {
+                                vd = P.volume_depth + 1;
+                                phase = PH_T_OUTER_SECOND;
+                            }
+                        } else {
+                            phase = PH_W_TRACK;
+                        }
                     } else if (gco_obj == 0) {
                         // nothing ahead: the second get_closest_object (:1806) sees the same ray, so
                         // this and every later iteration is a no-op -> finish (exact)
