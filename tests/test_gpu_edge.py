@@ -123,34 +123,48 @@ def test_nan_guard_substitutes_running_mean(pkg):
     assert rel_l2(got, ob.accum) <= 2e-6
 
 
-@pytest.mark.parametrize("scene", ["dragon", "fireball", "instanced"])
-def test_bricked_density_layout_is_bit_identical(pkg, monkeypatch, scene):
-    """large density grids are re-tiled into 4x4x4 bricks (data layout); forcing it on
-    small scenes must not change a single bit (odd extents: 70x49x31 has partial edge bricks)"""
+@pytest.mark.parametrize("layout", ["bricks", "quads"])
+@pytest.mark.parametrize("scene", ["dragon", "fireball", "instanced", "cloud_vol"])
+def test_relaid_density_layouts_are_bit_identical(pkg, monkeypatch, scene, layout):
+    """large density grids are re-laid as float4 corner quads, or 4x4x4 bricks when those do not fit (data
+    layout); forcing either on small scenes must not change a single bit (odd extents: 70x49x31 has partial edge bricks, and
+    footprints on every face, edge and corner of the grid exercise the quads' clamped rows), and the result is the oracle's:
+    bit-identical depth, image to 2e-6 (1e-3 where the value-only sky code takes part)"""
+    import oracle_binding
     def make():
         if scene == "dragon":
             return pkg.scene.dragon_scene(96, 64, "sun")
         if scene == "fireball":
             return pkg.scene.fireball_scene(96, 64, n=37)
+        if scene == "cloud_vol":
+            sd = pkg.scene.cloud_scene(96, 64, shape=(45, 31, 38), env=(64, 32))        # vol_integrator: the split-phase look-up
+            pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+            return sd
         return pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)
     sd = make()
     a = pkg.scene.HipBinding(sd, device=0)
     a.render(3); a.sync()
-    monkeypatch.setenv("VPT_BRICK_MIN_BYTES", "0")
+    monkeypatch.setenv("VPT_RELAID_MIN_BYTES", "0")
+    monkeypatch.setenv("VPT_GRID_LAYOUT", layout)
     b = pkg.scene.HipBinding(sd, device=0)
     b.ctx.set_counting(True)
     b.render(3); b.sync()
     assert a.accum.abs().max() > 0
     np.testing.assert_array_equal(a.accum.cpu().numpy(), b.accum.cpu().numpy())
     np.testing.assert_array_equal(a.depth.cpu().numpy(), b.depth.cpu().numpy())
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(3)
+    np.testing.assert_array_equal(b.depth.cpu().numpy(), ob.depth)
+    assert rel_l2(b.accum.cpu().numpy(), ob.accum) <= (1e-3 if scene == "cloud_vol" else 2e-6)      # value-only sky code in the vol_integrator
 
 
-@pytest.mark.parametrize("bricks", [False, True])
-def test_24_bit_index_arithmetic_is_bit_identical(pkg, monkeypatch, bricks):
+@pytest.mark.parametrize("layout", [None, "bricks", "quads"])
+def test_24_bit_index_arithmetic_is_bit_identical(pkg, monkeypatch, layout):
     """texel indices are formed with the 24-bit multiplier where the grid extents allow it (vpt_trace_common.h imul);
-    the 32-bit path (VPT_NO_ADDR24, what a >16.7 M-row grid would take) must give the same bits, bricked or not"""
-    if bricks:
-        monkeypatch.setenv("VPT_BRICK_MIN_BYTES", "0")
+    the 32-bit path (VPT_NO_ADDR24, what a >16.7 M-row grid would take) must give the same bits in every grid layout"""
+    if layout:
+        monkeypatch.setenv("VPT_RELAID_MIN_BYTES", "0")
+        monkeypatch.setenv("VPT_GRID_LAYOUT", layout)
     sd = pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)
     a = pkg.scene.HipBinding(sd, device=0)
     a.render(3); a.sync()

@@ -9,7 +9,7 @@ oracle running on the GPU box's host cores:
 
 plus, for config 2, several consecutive iterations through the per-frame entry point vpt_render.  What the small scenes of
 the other test files cannot show is covered here: 2 M / 8.3 M pixel record streams, the 24-bit index path on 128^3 - 608^3
-grids, bricked density (config 4 at this size is above VPT_BRICK_MIN_BYTES), 100 instances over the octree with per-sub-cell
+grids, corner-quad density (config 4 at this size is above VPT_RELAID_MIN_BYTES), 100 instances over the octree with per-sub-cell
 candidate lists, the thin lens at 4K, the real atmosphere tables.
 """
 import numpy as np
@@ -88,7 +88,7 @@ def test_config4_cloud_half_size_grid_1080p(pkg):
     sd.env_map = S.hdri_map(2048, 1024)
     S._finish(sd)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    assert grid.nbytes >= (192 << 20)                 # above VPT_BRICK_MIN_BYTES: the bricked layout is what runs
+    assert grid.nbytes >= (8 << 20)                   # above VPT_RELAID_MIN_BYTES: the corner-quad layout is what runs
     e, st = _compare(pkg, sd, 1)
     assert st.tracking_steps > st.density_lookups      # vol_integrator's runs of empty sample() calls
 

@@ -7,9 +7,12 @@
 //     bits) plus a CSR list of instance indices per leaf -- child boxes are re-derived
 //     arithmetically by halving the parent box (bvh_kernels.cu:150-202 divide_bbox), which
 //     reproduces the reference's node boxes bit-for-bit without the 2.5 KB OCTNode;
-//   * density grids too large for the Infinity Cache (>= VPT_BRICK_MIN_BYTES, default 192 MiB) are
-//     re-tiled once into 4x4x4 bricks of 256 B: a trilinear footprint then touches ~2.5 cache lines
-//     instead of 4 scattered ones;
+//   * density and emission grids that do not stay in L2 (>= VPT_RELAID_MIN_BYTES, default 8 MiB) are
+//     re-laid once as CORNER QUADS (GRID_QUADS): entry (x, j, k), j in [-1, dy-1], k in [-1, dz-1], is the float4
+//     (c(x,j,k), c(x,j+1,k), c(x,j,k+1), c(x,j+1,k+1)) with clamped j, k -- a trilinear footprint is then two float4
+//     loads from ONE 32-byte run (x, x+1) instead of eight dwords on four scattered rows: 4x the memory (288 GB
+//     of HBM is what it is spent on), about half the HBM traffic per look-up (1.1 lines of 128 B instead of ~2.5 with half of
+//     them hitting L2).  Density grids whose quads would not fit fall back to 4x4x4 bricks of 256 B (GRID_BRICKS);
 //   * path records: one 64-byte line per pixel-sample, written once by the trace
 //     kernel, read once by the resolve kernel.
 #pragma once
@@ -17,6 +20,8 @@
 #include "vpt_math.h"
 
 namespace vpt {
+
+enum { GRID_DENSE = 0, GRID_BRICKS = 1, GRID_QUADS = 2 };
 
 struct DVolume {
     const float* density;
@@ -30,8 +35,10 @@ struct DVolume {
     int has_emission;
     int edim[3];           // emission texture extent
     int cdim[3];           // colour texture extent
-    int bricked;           // density is stored as 4x4x4 bricks (256 B, x fastest inside a brick), bricks x fastest
-    int bdim[2];           // bricks along x and y
+    int layout;            // of the density grid: GRID_DENSE (x fastest), GRID_BRICKS (4x4x4 bricks of 256 B, x fastest inside a
+                           // brick, bricks x fastest) or GRID_QUADS (float4 corner quads, x fastest, (dy+1)(dz+1) rows)
+    int bdim[2];           // GRID_BRICKS: bricks along x and y
+    int elayout;           // of the emission grid: GRID_DENSE or GRID_QUADS
     int addr24;            // every texel-index product of this volume's grids fits the 24-bit multiplier (see imul)
 };
 

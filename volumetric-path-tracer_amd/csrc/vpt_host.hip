@@ -100,7 +100,8 @@ struct vpt_ctx {
     int comm_nranks = 0, comm_rank = 0;
     float* d_comm_count = nullptr;         // 1 float: this rank's iteration count, summed over ranks next to the image
     // tuning / test switches, read from the environment ONCE, when the context is created (vpt_create)
-    size_t brick_min_bytes = (size_t)192 << 20;   // VPT_BRICK_MIN_BYTES: density grids below this stay un-bricked
+    size_t relaid_min_bytes = (size_t)8 << 20;    // VPT_RELAID_MIN_BYTES: density / emission grids below this stay dense (they live in L2)
+    int grid_layout = -1;                  // VPT_GRID_LAYOUT (tests): force "dense" / "bricks" / "quads" for grids >= relaid_min_bytes; -1: quads, bricks if those do not fit
     bool force_no_addr24 = false;          // VPT_NO_ADDR24: tests force the 32-bit texel index arithmetic
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
     bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
@@ -295,7 +296,9 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = ctx->trans_min_vol = (uint32_t)std::atoi(trm);
-    if (const char* e = std::getenv("VPT_BRICK_MIN_BYTES")) ctx->brick_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("VPT_RELAID_MIN_BYTES")) ctx->relaid_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("VPT_GRID_LAYOUT"))
+        ctx->grid_layout = !std::strcmp(e, "dense") ? GRID_DENSE : !std::strcmp(e, "bricks") ? GRID_BRICKS : !std::strcmp(e, "quads") ? GRID_QUADS : -1;
     ctx->force_no_addr24 = std::getenv("VPT_NO_ADDR24") != nullptr;
     if (const char* e = std::getenv("VPT_BATCH_ITERS")) ctx->batch_iters = std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 0u;
     ctx->no_heads = std::getenv("VPT_NO_HEADS") != nullptr;
@@ -424,6 +427,19 @@ __global__ void brick_kernel(const float* __restrict__ src, float* __restrict__ 
     dst[o] = src[((size_t)z * dy + y) * dx + x];
 }
 
+// dense x-fastest grid -> corner quads (vpt_device.h): entry (x, jc, kc), jc = j + 1 in [0, dy], kc = k + 1 in [0, dz], holds
+// the four texels (j, k), (j+1, k), (j, k+1), (j+1, k+1) of column x with CUDA's clamp addressing applied
+__global__ void quads_kernel(const float* __restrict__ src, float4* __restrict__ dst, int dx, int dy, int dz, size_t total) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int x = (int)(o % (size_t)dx);
+    const size_t r = o / (size_t)dx;
+    const int jc = (int)(r % (size_t)(dy + 1)), kc = (int)(r / (size_t)(dy + 1));
+    const int j0 = max(jc - 1, 0), j1 = min(jc, dy - 1), k0 = max(kc - 1, 0), k1 = min(kc, dz - 1);
+    dst[o] = make_float4(src[((size_t)k0 * dy + j0) * dx + x], src[((size_t)k0 * dy + j1) * dx + x],
+                         src[((size_t)k1 * dy + j0) * dx + x], src[((size_t)k1 * dy + j1) * dx + x]);
+}
+
 // ---- scene ------------------------------------------------------------------------------------
 int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volumes) {
     if (!ctx || !volumes || num_volumes <= 0) return VPT_E_INVALID;
@@ -436,8 +452,43 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (void* b : ctx->bricked) (void)hipFree(b);
     ctx->bricked.clear();
-    const size_t brick_min = ctx->brick_min_bytes;        // grids below this stay L2 / Infinity-Cache resident anyway
-    std::vector<std::pair<const float*, const float*>> brick_cache;     // instances share their file's grid
+    const size_t relaid_min = ctx->relaid_min_bytes;      // grids below this stay L2 resident anyway
+    struct Relaid { const float* src; const float* dst; int layout; };
+    std::vector<Relaid> relaid;                           // instances share their file's grid
+    // f32 grid -> the layout the tracers read it in: corner quads when the grid is above the threshold, the entry count fits 32 bits
+    // and the 4x footprint is at most half of the free HBM; else (density only) 4x4x4 bricks; else the caller's dense array
+    auto relay = [&](const DTexture& t, bool bricks_allowed, const float** out, int* out_layout) -> int {
+        *out = t.data;
+        *out_layout = GRID_DENSE;
+        if ((size_t)t.width * t.height * t.depth * sizeof(float) < relaid_min || ctx->grid_layout == GRID_DENSE) return VPT_OK;
+        for (auto& c : relaid)
+            if (c.src == t.data && (bricks_allowed || c.layout == GRID_QUADS)) { *out = c.dst; *out_layout = c.layout; return VPT_OK; }
+        const size_t entries = (size_t)t.width * (t.height + 1) * (t.depth + 1);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+        const bool quads_fit = entries < ((size_t)1 << 32) && entries * 16 <= free_b / 2;
+        const int bx = (t.width + 3) / 4, by = (t.height + 3) / 4, bz = (t.depth + 3) / 4;
+        const size_t btotal = (size_t)bx * by * bz * 64;
+        if (ctx->grid_layout != GRID_BRICKS && quads_fit) {
+            float4* dst = nullptr;
+            HIPCHK(ctx, hipMalloc(&dst, entries * sizeof(float4)));
+            ctx->bricked.push_back(dst);
+            hipLaunchKernelGGL(quads_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, ctx->stream, t.data, dst, t.width, t.height, t.depth, entries);
+            HIPCHK(ctx, hipGetLastError());
+            *out = reinterpret_cast<const float*>(dst);
+            *out_layout = GRID_QUADS;
+        } else if (bricks_allowed && ctx->grid_layout != GRID_QUADS && btotal < ((size_t)1 << 32)) {
+            float* dst = nullptr;
+            HIPCHK(ctx, hipMalloc(&dst, btotal * sizeof(float)));
+            ctx->bricked.push_back(dst);
+            hipLaunchKernelGGL(brick_kernel, dim3((unsigned)((btotal + 255) / 256)), dim3(256), 0, ctx->stream, t.data, dst, t.width, t.height, t.depth, bx, by, btotal);
+            HIPCHK(ctx, hipGetLastError());
+            *out = dst;
+            *out_layout = GRID_BRICKS;
+        }
+        if (*out_layout != GRID_DENSE) relaid.push_back({t.data, *out, *out_layout});
+        return VPT_OK;
+    };
     for (int i = 0; i < num_volumes; ++i) {
         const vpt_vdb_info& vi = volumes[i].vdb_info;
         DVolume& d = dv[i];
@@ -453,33 +504,20 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             return VPT_E_INVALID;
         }
         d.density = t.data;
-        if ((size_t)t.width * t.height * t.depth * sizeof(float) >= brick_min && (size_t)t.width * t.height * t.depth < ((size_t)1 << 31)) {
-            const int bx = (t.width + 3) / 4, by = (t.height + 3) / 4, bz = (t.depth + 3) / 4;
-            const size_t total = (size_t)bx * by * bz * 64;
-            const float* tiled = nullptr;
-            for (auto& c : brick_cache)
-                if (c.first == t.data) tiled = c.second;
-            if (!tiled && total < ((size_t)1 << 32)) {
-                float* dst = nullptr;
-                HIPCHK(ctx, hipMalloc(&dst, total * sizeof(float)));
-                ctx->bricked.push_back(dst);
-                hipLaunchKernelGGL(brick_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, t.data, dst, t.width, t.height, t.depth, bx, by, total);
-                HIPCHK(ctx, hipGetLastError());
-                brick_cache.push_back({t.data, dst});
-                tiled = dst;
-            }
-            if (tiled) {
-                d.density = tiled;
-                d.bricked = 1;
-                d.bdim[0] = bx; d.bdim[1] = by;
-            }
+        {
+            int layout = GRID_DENSE;
+            const float* laid = nullptr;
+            if (int rc = relay(t, true, &laid, &layout)) return rc;
+            d.density = laid;
+            d.layout = layout;
+            d.bdim[0] = (t.width + 3) / 4; d.bdim[1] = (t.height + 3) / 4;
         }
         if (vi.has_emission) {
             if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1) {
                 set_error(ctx, "vpt_scene_set_volumes: volume %d has_emission but no f32 emission texture", i);
                 return VPT_E_INVALID;
             }
-            d.emission = t.data;
+            if (int rc = relay(t, false, &d.emission, &d.elayout)) return rc;
             d.edim[0] = t.width; d.edim[1] = t.height; d.edim[2] = t.depth;
             d.has_emission = 1;
             ctx->any_emission = true;
@@ -499,7 +537,9 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             auto fits = [](const int* g) { return g[0] == 0 || ((long long)g[0] < (1 << 24) && (long long)g[1] * g[2] < (1 << 24)); };
             const int ddim[3] = {vi.dim.x, vi.dim.y, vi.dim.z};
             bool ok = fits(ddim) && fits(d.edim) && fits(d.cdim);
-            if (d.bricked) ok = ok && (long long)d.bdim[0] * d.bdim[1] * 64 < (1 << 24);
+            if (d.layout == GRID_BRICKS) ok = ok && (long long)d.bdim[0] * d.bdim[1] * 64 < (1 << 24);
+            if (d.layout == GRID_QUADS) ok = ok && (long long)(ddim[1] + 1) * (ddim[2] + 1) < (1 << 24);
+            if (d.elayout == GRID_QUADS) ok = ok && (long long)(d.edim[1] + 1) * (d.edim[2] + 1) < (1 << 24);
             if (ctx->force_no_addr24) ok = false;                // tests: force the 32-bit index arithmetic
             d.addr24 = ok ? 1 : 0;
         }

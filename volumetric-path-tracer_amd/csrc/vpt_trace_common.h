@@ -224,6 +224,7 @@ template <bool A24> VPT_D uint32_t imul(uint32_t a, uint32_t b) { return A24 ? _
 
 struct Taps {
     int i0, i1, j0, j1, k0, k1;
+    int jr, kr;           // floor of the y / z texel coordinate before clamping (GRID_QUADS rows)
     float ax, ay, az;
 };
 VPT_D Taps make_taps(const int* dim, f3 u) {
@@ -242,6 +243,8 @@ VPT_D Taps make_taps(const int* dim, f3 u) {
     t.j1 = min(max(j + 1, 0), dim[1] - 1);
     t.k0 = min(max(k, 0), dim[2] - 1);
     t.k1 = min(max(k + 1, 0), dim[2] - 1);
+    t.jr = j;
+    t.kr = k;
     return t;
 }
 // trilinear f32 fetch: CUDA "linear, normalised, clamp" addressing, fp32 weights, nested
@@ -288,6 +291,29 @@ VPT_D float fetch_f32_bricked(const float* __restrict__ g_, const DVolume& v, co
     const float c1 = c01 + (c11 - c01) * t.ay;
     return c0 + (c1 - c0) * t.az;
 }
+// GRID_QUADS (vpt_device.h): the footprint is the two float4 entries (i0, i1) of row (kr+1, jr+1); same texels, same lerp order.
+// The entry index stays below 2^32 (host check), the byte offset does not: 64-bit addressing.
+template <bool A24>
+VPT_D void quad_entries(const int* dim, const Taps& t, uint32_t& e0, uint32_t& e1) {
+    const uint32_t jc = (uint32_t)min(max(t.jr + 1, 0), dim[1]), kc = (uint32_t)min(max(t.kr + 1, 0), dim[2]);
+    const uint32_t row = imul<A24>(imul<A24>(kc, (uint32_t)dim[1] + 1u) + jc, (uint32_t)dim[0]);
+    e0 = row + (uint32_t)t.i0;
+    e1 = row + (uint32_t)t.i1;
+}
+template <bool A24>
+VPT_D float fetch_f32_quads(const float* __restrict__ g_, const int* dim, const Taps& t) {
+    const gptr_f4 g = (gptr_f4)g_;
+    uint32_t e0, e1;
+    quad_entries<A24>(dim, t, e0, e1);
+    const v4f q0 = g[(size_t)e0], q1 = g[(size_t)e1];
+    const float c00 = q0.x + (q1.x - q0.x) * t.ax;
+    const float c10 = q0.y + (q1.y - q0.y) * t.ax;
+    const float c01 = q0.z + (q1.z - q0.z) * t.ax;
+    const float c11 = q0.w + (q1.w - q0.w) * t.ax;
+    const float c0 = c00 + (c10 - c00) * t.ay;
+    const float c1 = c01 + (c11 - c01) * t.ay;
+    return c0 + (c1 - c0) * t.az;
+}
 // The same fetch in two halves (split-phase look-up, vpt_walk.h): `issue` requests the eight texels, `lerp8` interpolates them with
 // the operation order of fetch_f32 -- whatever runs between the two overlaps the memory latency.
 struct Pending {
@@ -298,7 +324,15 @@ struct Pending {
 template <bool A24>
 VPT_D void issue_f32(const float* __restrict__ g_, const DVolume& v, const Taps& t, Pending& pd) {
     const gptr_f g = (gptr_f)g_;
-    if (v.bricked) {
+    if (v.layout == GRID_QUADS) {
+        uint32_t e0, e1;
+        quad_entries<A24>(v.dim, t, e0, e1);
+        const v4f q0 = ((gptr_f4)g_)[(size_t)e0], q1 = ((gptr_f4)g_)[(size_t)e1];
+        pd.c[0] = q0.x; pd.c[1] = q1.x;
+        pd.c[2] = q0.y; pd.c[3] = q1.y;
+        pd.c[4] = q0.z; pd.c[5] = q1.z;
+        pd.c[6] = q0.w; pd.c[7] = q1.w;
+    } else if (v.layout == GRID_BRICKS) {
         const uint32_t row = (uint32_t)v.bdim[0] * 64u, slab = (uint32_t)v.bdim[1] * row;
         const uint32_t x0 = (((uint32_t)t.i0 >> 2) << 6) + ((uint32_t)t.i0 & 3u), x1 = (((uint32_t)t.i1 >> 2) << 6) + ((uint32_t)t.i1 & 3u);
         const uint32_t y0 = imul<A24>((uint32_t)t.j0 >> 2, row) + (((uint32_t)t.j0 & 3u) << 2), y1 = imul<A24>((uint32_t)t.j1 >> 2, row) + (((uint32_t)t.j1 & 3u) << 2);
@@ -375,7 +409,9 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (FC) count_fetch(P, 0, inside);
         if (inside) {
             const Taps t = make_taps(v.dim, u);
-            density += v.bricked ? fetch_f32_bricked<A24>(v.density, v, t) : fetch_f32<A24>(v.density, v.dim, t);
+            density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
+                       : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)
+                                                 : fetch_f32<A24>(v.density, v.dim, t);
         }
     }
     if (COLOR && COUNT && count_color && v.has_color) n_c++;      // the reference looks the colour up here (see walk_step)
@@ -394,7 +430,8 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             if (COUNT) n_e++;
             if (FC) count_fetch(P, 2, inside);
             if (inside) {
-                float index = fetch_f32<A24>(v.emission, v.edim, make_taps(v.edim, u));
+                const Taps t = make_taps(v.edim, u);
+                float index = v.elayout == GRID_QUADS ? fetch_f32_quads<A24>(v.emission, v.edim, t) : fetch_f32<A24>(v.emission, v.edim, t);
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
                 const int e = 3 * (int)index;
                 if (ELDS) emission += mk3(s_emission_lut[e], s_emission_lut[e + 1], s_emission_lut[e + 2]) * P.emission_scale;

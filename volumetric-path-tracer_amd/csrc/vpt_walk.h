@@ -128,23 +128,27 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
     if (!inside) return;
     const DVolume& v = P.vol0;
     const Taps t = make_taps(v.dim, u);
-    // float index of the 8 taps in the layout actually used
+    // 128-byte line of each of the 8 taps in the layout actually used
     uint32_t a[8];
-    if (v.bricked) {
+    if (v.layout == GRID_QUADS) {
+        uint32_t e0, e1;
+        quad_entries<A24>(v.dim, t, e0, e1);
+        for (int q = 0; q < 8; ++q) a[q] = ((q & 1) ? e1 : e0) >> 3;            // 8 float4 entries per line
+    } else if (v.layout == GRID_BRICKS) {
         const uint32_t row = (uint32_t)v.bdim[0] * 64u, slab = (uint32_t)v.bdim[1] * row;
         const uint32_t x[2] = {(((uint32_t)t.i0 >> 2) << 6) + ((uint32_t)t.i0 & 3u), (((uint32_t)t.i1 >> 2) << 6) + ((uint32_t)t.i1 & 3u)};
         const uint32_t y[2] = {((uint32_t)t.j0 >> 2) * row + (((uint32_t)t.j0 & 3u) << 2), ((uint32_t)t.j1 >> 2) * row + (((uint32_t)t.j1 & 3u) << 2)};
         const uint32_t z[2] = {((uint32_t)t.k0 >> 2) * slab + (((uint32_t)t.k0 & 3u) << 4), ((uint32_t)t.k1 >> 2) * slab + (((uint32_t)t.k1 & 3u) << 4)};
-        for (int q = 0; q < 8; ++q) a[q] = z[q >> 2] + y[(q >> 1) & 1] + x[q & 1];
+        for (int q = 0; q < 8; ++q) a[q] = (z[q >> 2] + y[(q >> 1) & 1] + x[q & 1]) >> 5;
     } else {
         const uint32_t dx = (uint32_t)v.dim[0], dy = (uint32_t)v.dim[1];
         const uint32_t x[2] = {(uint32_t)t.i0, (uint32_t)t.i1}, y[2] = {(uint32_t)t.j0, (uint32_t)t.j1}, z[2] = {(uint32_t)t.k0, (uint32_t)t.k1};
-        for (int q = 0; q < 8; ++q) a[q] = (z[q >> 2] * dy + y[(q >> 1) & 1]) * dx + x[q & 1];
+        for (int q = 0; q < 8; ++q) a[q] = ((z[q >> 2] * dy + y[(q >> 1) & 1]) * dx + x[q & 1]) >> 5;
     }
     uint32_t own_lines = 0;
     for (int q = 0; q < 8; ++q) {
         bool seen = false;
-        for (int r = 0; r < q; ++r) seen = seen || (a[r] >> 5) == (a[q] >> 5);
+        for (int r = 0; r < q; ++r) seen = seen || a[r] == a[q];
         own_lines += seen ? 0u : 1u;
     }
     const uint32_t b8 = (((uint32_t)t.k0 >> 3) * 4096u + ((uint32_t)t.j0 >> 3)) * 4096u + ((uint32_t)t.i0 >> 3);
@@ -167,9 +171,9 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
         const unsigned long long m = __ballot(done != 0xffu);
         if (m == 0ull) break;
         uint32_t cand = 0;
-        for (int q = 7; q >= 0; --q) cand = ((done >> q) & 1u) ? cand : (a[q] >> 5);       // lowest tap not yet counted
+        for (int q = 7; q >= 0; --q) cand = ((done >> q) & 1u) ? cand : a[q];       // lowest tap not yet counted
         const uint32_t id = (uint32_t)__shfl((int)cand, __ffsll((long long)m) - 1);
-        for (int q = 0; q < 8; ++q) done |= ((a[q] >> 5) == id) ? (1u << q) : 0u;
+        for (int q = 0; q < 8; ++q) done |= (a[q] == id) ? (1u << q) : 0u;
         dl++;
     }
     const int leader = __ffsll((long long)act) - 1;
