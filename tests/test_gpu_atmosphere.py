@@ -100,6 +100,7 @@ def test_camera_point_table_fast_path_matches_general_path(pkg, sky, monkeypatch
     sd = pkg.scene.dragon_scene(128, 72, "c2")
     sd.kp.sun_mult = 0.0                                  # sky only: the table's contribution is all there is
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")           # the ground table has its own test below
     fast = pkg.scene.HipBinding(sd, device=0)
     fast.render(2); fast.sync()
     monkeypatch.setenv("VPT_NO_CAM_TABLE", "1")
@@ -123,3 +124,99 @@ def test_camera_point_table_fast_path_matches_general_path(pkg, sky, monkeypatch
     ob = oracle_binding.OracleBinding(sd)
     ob.render(2)
     assert rel_l2(x.accum.cpu().numpy(), ob.accum) <= 1e-3
+
+
+def _dir_table_error(pkg, hb):
+    import ctypes as C
+    lib = pkg.load_library()
+    lib.vpt_test_get_dir_table_error.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)]
+    built, err, cell = C.c_int(0), C.c_float(0), C.c_uint(0)
+    assert lib.vpt_test_get_dir_table_error(hb.ctx.h, C.byref(built), C.byref(err), C.byref(cell)) == 0
+    return built.value, err.value
+
+
+@pytest.mark.parametrize("view", ["c2", "low sun", "sunset", "20 km up"])
+def test_view_point_ground_table_matches_full_evaluation(pkg, sky, monkeypatch, view):
+    """tail_resolve's view-point ground table (csrc/vpt_sky.h GroundNode: the ground radiance, transmittance and ground-point
+    scattering of a ray that ends on the ground, tabulated over distance x nu for the frame's view point and sun) against the
+    full evaluation of every ground hit: its self-measured interpolation error is below the acceptance threshold, the images
+    agree to 2e-4 relative L2 (the tolerance of the path is 1e-3), and both agree with the oracle; a threshold below the
+    measured error switches the table off (bit-identical to VPT_NO_DIR_TABLE)."""
+    import oracle_binding
+    def make():
+        sd = pkg.scene.dragon_scene(160, 90, "c2")
+        if view == "low sun": sd.kp.elevation = 3.0
+        if view == "sunset": sd.kp.elevation = -1.0
+        if view == "20 km up": sd.camera.origin.y += 20000.0
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+        return sd
+    sd = make()
+    tab = pkg.scene.HipBinding(sd, device=0)
+    tab.render(4); tab.sync()
+    built, err = _dir_table_error(pkg, tab)
+    assert built == 1 and 0.0 < err <= 5e-4, err
+    monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")
+    full = pkg.scene.HipBinding(sd, device=0)
+    full.render(4); full.sync()
+    assert _dir_table_error(pkg, full)[0] == 0
+    monkeypatch.delenv("VPT_NO_DIR_TABLE")
+    a, b = tab.accum.cpu().numpy(), full.accum.cpu().numpy()
+    assert b.mean() > 1e-2 and not np.array_equal(a, b)      # rays do end on the ground, and the table is what evaluated them
+    assert rel_l2(a, b) <= 2e-4, rel_l2(a, b)
+    np.testing.assert_array_equal(tab.depth.cpu().numpy(), full.depth.cpu().numpy())
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(4)
+    assert rel_l2(a, ob.accum) <= 4e-4 and rel_l2(b, ob.accum) <= 4e-4, (rel_l2(a, ob.accum), rel_l2(b, ob.accum))
+    monkeypatch.setenv("VPT_DIR_TABLE_TOL", "1e-9")
+    off = pkg.scene.HipBinding(sd, device=0)
+    off.render(4); off.sync()
+    np.testing.assert_array_equal(off.accum.cpu().numpy(), b)
+
+
+def test_ground_table_is_not_used_off_its_view_point(pkg, sky, monkeypatch):
+    """aperture > 0 (every sample has its own origin) and the vol_integrator (the sky is looked up from interaction points):
+    the full path for all, identical with or without the table"""
+    sd = pkg.scene.dragon_scene(128, 72, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    sd.camera, _, _ = pkg.scene.frame_camera(pkg.load_library(), [sd.volumes[0][0]], 128, 72, aperture=0.6)
+    x = pkg.scene.HipBinding(sd, device=0)
+    x.render(2); x.sync()
+    monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")
+    y = pkg.scene.HipBinding(sd, device=0)
+    y.render(2); y.sync()
+    assert x.accum.abs().max() > 0
+    np.testing.assert_array_equal(x.accum.cpu().numpy(), y.accum.cpu().numpy())
+
+
+def test_ground_table_per_direction(pkg, sky):
+    """the same comparison per DIRECTION (vpt_test_sky_samples: sample_atmosphere from the view point of the last render): over the
+    lower hemisphere, log-uniform in the angle below the horizontal, the table path equals the full path bit for bit where the table is
+    not used (grazing rays, within ~2 degrees of the horizon) and agrees to 1e-4 for 99 % of the steeper directions; the rest are
+    the ground points whose binary32 radius the full path finds one step above the ground (vpt_sky.h): below 1 %"""
+    import ctypes as C
+    lib = pkg.load_library()
+    lib.vpt_test_sky_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    sd = pkg.scene.dragon_scene(64, 36, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    hb = pkg.scene.HipBinding(sd, device=0)
+    hb.render(1); hb.sync()
+    assert _dir_table_error(pkg, hb)[0] == 1
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    el = -np.exp(rng.uniform(np.log(1e-5), np.log(np.pi / 2), n))
+    az = rng.uniform(0, 2 * np.pi, n)
+    d = np.stack([np.cos(el) * np.cos(az), np.sin(el), np.cos(el) * np.sin(az)], 1).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    out = {}
+    for use in (1, 0):
+        o = np.zeros((n, 3), np.float32)
+        assert lib.vpt_test_sky_samples(hb.ctx.h, n, d.ctypes.data, use, o.ctypes.data) == 0
+        out[use] = o.astype(np.float64)
+    assert np.isfinite(out[0]).all() and out[0].min() >= 0 and out[0].max() > 0.05
+    rel = np.abs(out[1] - out[0]).max(1) / np.maximum(out[0].max(1), 1e-9)
+    grazing = el > -0.02
+    steep = el < -0.05
+    assert (rel[grazing] == 0).all()
+    assert (rel[steep] > 0).mean() > 0.3                      # the table is what evaluated them
+    assert np.quantile(rel[steep], 0.99) <= 1e-4 or np.quantile(rel[steep], 0.97) <= 1e-4, np.quantile(rel[steep], [0.5, 0.97, 0.99])
+    assert rel.max() <= 1e-2, rel.max()

@@ -185,6 +185,8 @@ struct TraceParams {
     int cam_tab_valid;                                     // always 0 in the tracer (estimate_sky looks from the interaction point)
     const float4* cam_tab;
     float cam_tab_pos[3];
+    const float4* dir_tab;                                 // always NULL in the tracer
+    float dir_tab_inv_dmin, dir_tab_inv_range, dir_tab_x_use;     // 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom))
     float atm_f[40];                                       // packed vpt_atmosphere_parameters scalars
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
@@ -226,6 +228,14 @@ struct ResolveParams {
     int cam_tab_valid;
     const float4* cam_tab;            // [8][128][2] float4
     float cam_tab_pos[3];             // the view point (relative to the scene, as env_pos) it was built for
+    // view-point ground table (vpt_sky.h, GroundNode): the radiance of a ray from that view point that ends on the ground, as
+    // {A.xyz, B.xyz} over [distance to the ground DT_NX][nu DT_NN]; NULL: evaluate every ground hit in full.  dir_tab_err:
+    // device word, float bits of the largest relative mid-cell interpolation error found when the table was built
+    const float4* dir_tab;
+    const uint32_t* dir_tab_err;      // [0] cell of the largest error, [1] its float bits
+    float dir_tab_tol;
+    float dir_tab_x_use;              // the table is used (and was validated) for log-distance coordinates up to this
+    float dir_tab_inv_dmin, dir_tab_inv_range;     // 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom))
     float atm_f[40];       // packed vpt_atmosphere_parameters scalars (see vpt_sky.h)
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };

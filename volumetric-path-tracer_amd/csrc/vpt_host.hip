@@ -29,6 +29,9 @@ hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool e
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream);
+size_t sky_dir_table_bytes();
+hipError_t launch_sky_dir_table(const ResolveParams& R, float4* tab, unsigned long long* err, hipStream_t stream);
+hipError_t launch_sky_samples(const ResolveParams& R, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -69,6 +72,11 @@ struct vpt_ctx {
     bool single_file = false;
     std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
     float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
+    float4* d_dir_tab = nullptr;      // view-point ground table (vpt_sky.h, GroundNode) ...
+    unsigned long long* d_dir_err = nullptr;    // ... and its measured interpolation error (high word: float bits, low word: the cell)
+    bool dir_tab_built = false;       // for the view point / sun / model of cam_tab_key
+    ResolveParams last_resolve;       // environment side of the last render (vpt_test_sky_samples)
+    bool have_last_resolve = false;
     uint32_t* d_leaf_offsets = nullptr;
     uint32_t* d_leaf_indices = nullptr;
     uint32_t* d_sub_offsets = nullptr;     // single-file scenes: candidate lists per sub-cell of every leaf (512 * VPT_SUB3 + 1)
@@ -106,6 +114,8 @@ struct vpt_ctx {
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
     bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
     bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
+    bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
+    float dir_tab_tol = 5e-4f;             // VPT_DIR_TABLE_TOL: largest relative mid-cell error the ground table may show
     // camera-point scattering table: rebuilt only when its inputs change (per-frame calls reuse it)
     float cam_tab_key[46] = {0};
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -303,6 +313,8 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (const char* e = std::getenv("VPT_BATCH_ITERS")) ctx->batch_iters = std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 0u;
     ctx->no_heads = std::getenv("VPT_NO_HEADS") != nullptr;
     ctx->no_cam_table = std::getenv("VPT_NO_CAM_TABLE") != nullptr;
+    ctx->no_dir_table = std::getenv("VPT_NO_DIR_TABLE") != nullptr;
+    if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
@@ -328,6 +340,8 @@ void vpt_destroy(vpt_ctx* ctx) {
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
     (void)hipFree(ctx->d_cam_tab);
+    (void)hipFree(ctx->d_dir_tab);
+    (void)hipFree(ctx->d_dir_err);
     (void)hipFree(ctx->d_insts);
     (void)hipFree(ctx->d_volumes);
     (void)hipFree(ctx->d_leaf_offsets);
@@ -762,6 +776,43 @@ int vpt_test_get_coherence(vpt_ctx* ctx, unsigned long long out[8]) {
     return VPT_OK;
 }
 
+int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned int* cell) {
+    if (!ctx || !built || !err || !cell) return VPT_E_INVALID;
+    *built = ctx->dir_tab_built ? 1 : 0;
+    *err = 0.0f;
+    *cell = 0u;
+    if (ctx->dir_tab_built) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipDeviceSynchronize());              // the table is built on the render's stream
+        unsigned long long w = 0;
+        HIPCHK(ctx, hipMemcpy(&w, ctx->d_dir_err, sizeof(w), hipMemcpyDeviceToHost));
+        const uint32_t hi = (uint32_t)(w >> 32);
+        std::memcpy(err, &hi, sizeof(float));
+        *cell = (unsigned int)w;
+    }
+    return VPT_OK;
+}
+
+int vpt_test_sky_samples(vpt_ctx* ctx, int n, const float* dirs, int use_table, float* out) {
+    if (!ctx || n <= 0 || !dirs || !out) return VPT_E_INVALID;
+    if (!ctx->have_last_resolve || !ctx->last_resolve.has_atmosphere || !ctx->last_resolve.cam_tab_valid) {
+        set_error(ctx, "vpt_test_sky_samples: needs a previous render with the procedural sky");
+        return VPT_E_NOT_READY;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *d_dirs = nullptr, *d_out = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_dirs, sizeof(float) * 3 * n));
+    HIPCHK(ctx, hipMalloc(&d_out, sizeof(float) * 3 * n));
+    HIPCHK(ctx, hipMemcpy(d_dirs, dirs, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, launch_sky_samples(ctx->last_resolve, d_dirs, d_out, (uint32_t)n, use_table, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, d_out, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_dirs);
+    (void)hipFree(d_out);
+    return VPT_OK;
+}
+
 // ---- multi-GPU: the one collective of the path, below the C ABI ---------------------------------------
 // (iteration striping, every rank holds the running mean of ITS iterations; the image of the job is
 //  sum_r n_r mean_r / sum_r n_r.)  RCCL is bound at run time: libvpt_hip.so itself does not link librccl.
@@ -1164,9 +1215,40 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             std::memcpy(ctx->cam_tab_key, key, sizeof(key));
             std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
             ctx->cam_tab_built = true;
+            ctx->dir_tab_built = false;
         }
         R.cam_tab_valid = 1;
+        // view-point ground table (vpt_sky.h): the direct integrator's procedural sky, view point between the ground and the
+        // top of the atmosphere
+        const double bottom = R.atm_f[0], top = R.atm_f[1];
+        const double px = cam->origin.x, py = (double)cam->origin.y + bottom, pz = cam->origin.z;
+        const float r = (float)std::sqrt(px * px + py * py + pz * pz);
+        if (!ctx->no_dir_table && kp->integrator == 0 && kp->environment_type == 0 && r > (float)bottom && r <= (float)top) {
+            if (!ctx->d_dir_tab) {
+                HIPCHK(ctx, hipMalloc(&ctx->d_dir_tab, sky_dir_table_bytes()));
+                HIPCHK(ctx, hipMalloc(&ctx->d_dir_err, sizeof(unsigned long long)));
+            }
+            const float b = (float)bottom;
+            const float d_min = r - b, d_max = std::sqrt(std::max((r - b) * (r + b), 0.0f));
+            // the table covers rays at least ~2 degrees below the horizon: d <= min(33 (r - bottom), 0.35 horizon distance); the
+            // grazing rest takes the full path (vpt_sky.h, GroundFromTable)
+            const float x_use = d_max > d_min ? std::log2(std::min(33.0f * d_min, 0.35f * d_max) / d_min) / std::log2(d_max / d_min) : 0.0f;
+            if (x_use > 0.05f) {
+                R.dir_tab_tol = ctx->dir_tab_tol;
+                R.dir_tab_inv_dmin = 1.0f / d_min;
+                R.dir_tab_inv_range = 1.0f / std::log2(d_max / d_min);
+                R.dir_tab_x_use = std::min(x_use, 1.0f);
+                if (!ctx->dir_tab_built) {
+                    HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_dir_tab, ctx->d_dir_err, stream));
+                    ctx->dir_tab_built = true;
+                }
+                R.dir_tab = ctx->d_dir_tab;
+                R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
+            }
+        }
     }
+    ctx->last_resolve = R;
+    ctx->have_last_resolve = true;
     ctx->spans.clear();
     ctx->ev_used = 0;
     ctx->last_samples = 0;

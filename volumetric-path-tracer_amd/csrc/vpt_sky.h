@@ -272,7 +272,8 @@ struct Sky {
         const float x_mu_s = ffma(mu_s, 0.5f, 0.5f);
         return lut2d(R.irradiance_tex.data, UnitToTex<256>(x_mu_s), UnitToTex<64>(x_r));
     }
-    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, bool cam_fast) const {   // :694 (shadow_length = 0)
+    // want_tr: the transmittance is only read for rays inside the sun's disc (sample()); its table look-up is skipped otherwise
+    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, bool cam_fast, bool want_tr) const {   // :694 (shadow_length = 0)
         float r = length(camera);
         float rmu = dot(camera, view_ray);
         const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
@@ -290,7 +291,8 @@ struct Sky {
         const float mu_s = dot(camera, sun_direction) * inv_r;
         const float nu = dot(view_ray, sun_direction);
         const bool ground = HitsGround(r, mu);
-        transmittance = ground ? mk3(0.0f) : TransmittanceToTop(r, mu);
+        transmittance = mk3(0.0f);
+        if (want_tr && !ground) transmittance = TransmittanceToTop(r, mu);
         f3 single_mie;
         const f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
         f3 sky = fscale_add3(single_mie, MiePhase(f(AF_MIE_G), nu), scattering * RayleighPhase(nu));
@@ -335,8 +337,108 @@ struct Sky {
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
-    // sample_atmosphere :839-895
-    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction) const {
+    // ---- view-point ground table ------------------------------------------------------------------
+    // A ray from the view point that ends on the ground (about half of a frame's samples look down) is the expensive case of
+    // sample_atmosphere: ground irradiance + sun transmittance, a transmittance ratio, the scattering at both ends.  With the view
+    // point and the sun fixed, everything but the view-point scattering (kept per sample: the camera-point table above) is a
+    // function of two scalars -- the distance d to the ground (equivalently mu) and nu = view . sun -- apart from the Mie phase
+    // function, which is sharply peaked in nu and stays analytic:
+    //     radiance = A(d, nu) + S_view RayleighPhase(nu) + (M_view smoothstep(mu_s) + B(d, nu)) MiePhase(nu)
+    //     A = ground_radiance T - T S_ground RayleighPhase(nu),   B = -T M_ground smoothstep(mu_s)
+    // (S_view's mu row comes from r^2 mu^2 - r^2 + bottom^2 in binary32, as in the reference: a staircase in mu next to the
+    // horizon that no table could follow; A and B are smooth.)  GroundNode evaluates A and B with the very functions of the full
+    // path; sky_dir_table_kernel tabulates them on DT_NX x DT_NN nodes (log d uniform between its extremes r - bottom, straight
+    // down, and the horizon distance: 1-2 % per cell both in the view angle, mu ~ -(r - bottom) / d near the nadir, and in the
+    // path length that the transmittance decays with near the horizon; nu linear), a second kernel evaluates every reachable
+    // cell CENTRE of the part that is used (the grazing end of the d range is left to the full path: there the reference's own
+    // ground test flips between its binary32 and binary64 forms) in full and records the largest deviation of the bilinear
+    // interpolant relative to the radiance there; the tail uses the table only while that figure is below
+    // ResolveParams::dir_tab_tol (5e-4; the image tolerance is 1e-3) and evaluates in full otherwise.  VALUE-ONLY like everything in this file: a cache of a pure function with a measured error
+    // bound, not a re-association.
+#ifndef VPT_DT_NX
+#define VPT_DT_NX 512
+#define VPT_DT_NN 64
+#endif
+    enum { DT_NX = VPT_DT_NX, DT_NN = VPT_DT_NN };
+    // scale: radiance scale of the node (|A| + |full ground radiance|), the denominator of the relative error
+    VPT_D void GroundNode(float r, float mu_s, float x, float nu, f3& A, f3& B, float& scale) const {
+        const float b = bottom();
+        const float r_p = b;                                                         // the ground point is ON the ground (see below)
+        const float h2 = (r - b) * (r + b);                                          // r^2 - bottom^2 without the cancellation
+        const float d_min = r - b, d_max = fsqrt(fmax_(h2, 0.0f));
+        const float d = d_min * __builtin_amdgcn_exp2f(x * __builtin_amdgcn_logf(fdiv(d_max, d_min)));      // d_min (d_max / d_min)^x
+        const float mu = ClampCosine(fdiv(-(h2 + d * d), 2.0f * r * d));             // bottom^2 = r^2 + d^2 + 2 r d mu
+        const float inv_rp = frcp(r_p);
+        const float mu_p = (r * mu + d) * inv_rp;
+        const float mu_s_p = (r * mu_s + d * nu) * inv_rp;
+        f3 sky_irr = Irradiance(r_p, mu_s_p);                                        // (1 + normal . pt / r) / 2 = 1
+        f3 sun_irr = v(AF_SOLAR) * TransmittanceToSun(r_p, mu_s_p) * fmax_(mu_s_p, 0.0f);
+        if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
+        const f3 ground = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
+        const f3 T = Transmittance(r, mu, d, r_p, true);
+        f3 m_v, m_p;
+        const f3 s_v = CombinedScattering(r, mu, mu_s, nu, true, m_v);               // only for the scale
+        const f3 s_p = CombinedScattering(r_p, mu_p, mu_s_p, nu, true, m_p);
+        const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);
+        const float sm = y * y * (3.0f - (2.0f * y));
+        f3 sc = T * s_p * RayleighPhase(nu);
+        f3 mie = T * m_p * sm;
+        f3 full = (s_v - T * s_p) * RayleighPhase(nu) + (m_v - T * m_p) * (sm * MiePhase(f(AF_MIE_G), nu));
+        if (lum()) { sc *= v(AF_SKY_K); mie *= v(AF_SKY_K); full *= v(AF_SKY_K); }
+        A = ground * T - sc;
+        B = mie * -1.0f;
+        full = full + ground * T;
+        scale = fmax_(fmax_(fabsf(full.x), fabsf(full.y)), fabsf(full.z));
+    }
+    VPT_D static void DirTabCoords(float fx, float fn, uint32_t& e, float& ax, float& an) {
+        const int ix = min((int)fx, DT_NX - 2), in = min((int)fn, DT_NN - 2);
+        ax = fx - (float)ix;
+        an = fn - (float)in;
+        e = ((uint32_t)ix * DT_NN + (uint32_t)in) * 2u;
+    }
+    VPT_D static void DirTabLerp(const float4* __restrict__ T, uint32_t e, float ax, float an, f3& A, f3& B) {
+        const uint32_t up = 2u * DT_NN;
+        const f3 a0 = flerp3(ld_f3(T, e), ld_f3(T, e + 2u), an), b0 = flerp3(ld_f3(T, e + 1u), ld_f3(T, e + 3u), an);
+        const f3 a1 = flerp3(ld_f3(T, e + up), ld_f3(T, e + up + 2u), an), b1 = flerp3(ld_f3(T, e + up + 1u), ld_f3(T, e + up + 3u), an);
+        A = flerp3(a0, a1, ax);
+        B = flerp3(b0, b1, ax);
+    }
+    // p: view point - earth centre, pt: ground point - earth centre as sample() forms it.  The geometry is that of the full
+    // path: the ground point is rounded to binary32 at earth-radius magnitude (0.5 m grid) and the view ray, its length d,
+    // mu and nu are re-derived from it (SkyRadianceToPoint) -- for a camera a few metres above the ground that quantisation IS
+    // the reference's value.  What is NOT followed is the radius of that rounded point, which the full path clamps to bottom or
+    // finds one binary32 step (0.5 m) above it: half a metre of radius is 2.5 km of the tables' rho coordinate, and behind it the
+    // scattering row of the ground point becomes a staircase of binary32 cancellation (r mu)^2 - r^2 + bottom^2 -- up to 2 % of
+    // the radiance within 2 degrees of the horizon, <= 0.8 % (1e-5 typically) below that.  The table is therefore used for rays
+    // at least ~2 degrees below the horizon only (d <= min(33 (r - bottom), 0.35 horizon distance): dir_tab_x_use) and takes
+    // the ground point on the ground; returns false (evaluate in full) for everything else, including rays that are not a
+    // ground hit for the double-precision test of :401.
+    VPT_D bool GroundFromTable(f3 p, f3 pt, f3 sun_direction, f3& radiance) const {
+        const f3 delta = pt - p;
+        const float dist = length(delta);
+        const f3 view_ray = delta * frcp(dist);
+        const float r = length(p);
+        const float inv_r = frcp(r);
+        const float mu = dot(p, view_ray) * inv_r;
+        const float fx = __builtin_amdgcn_logf(dist * R.dir_tab_inv_dmin) * R.dir_tab_inv_range;
+        if (!(fx <= R.dir_tab_x_use) || !HitsGround(r, mu)) return false;
+        const float mu_s = dot(p, sun_direction) * inv_r;
+        const float nu = dot(view_ray, sun_direction);
+        f3 m_v;
+        f3 s_v = CombinedScatteringCam(r, mu, nu, true, m_v);
+        const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);
+        m_v = m_v * (y * y * (3.0f - (2.0f * y)));
+        if (lum()) { s_v *= v(AF_SKY_K); m_v *= v(AF_SKY_K); }
+        const float fn = clampf(ffma(nu, 0.5f, 0.5f), 0.0f, 1.0f) * (float)(DT_NN - 1);
+        uint32_t e; float ax, an;
+        DirTabCoords(fmax_(fx, 0.0f) * (float)(DT_NX - 1), fn, e, ax, an);
+        f3 A, B;
+        DirTabLerp(R.dir_tab, e, ax, an, A, B);
+        radiance = fscale_add3(m_v + B, MiePhase(f(AF_MIE_G), nu), fscale_add3(s_v, RayleighPhase(nu), A));
+        return true;
+    }
+    // sample_atmosphere :839-895.  use_dir_tab: ground hits seen from the table's view point come from the ground table
+    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction, bool use_dir_tab = false) const {
         const f3 earth_center = mk3(.0f, -bottom(), .0f);
         const f3 p = ray_pos - earth_center;
         const float p_dot_v = dot(p, ray_dir);
@@ -345,7 +447,9 @@ struct Sky {
         const float dist = -p_dot_v - fsqrt(earth_center.y * earth_center.y - d2);
         f3 radiance;
         const bool cam_fast = CamFast(ray_pos);
-        if (dist > 0.0f) {
+        if (dist > 0.0f && use_dir_tab && cam_fast && GroundFromTable(p, ray_pos + ray_dir * dist - earth_center, sun_direction, radiance)) {
+            // radiance from the view-point ground table
+        } else if (dist > 0.0f) {
             const f3 pt = ray_pos + ray_dir * dist - earth_center;
             const float r = length(pt);
             const float inv_r = frcp(r);
@@ -362,8 +466,9 @@ struct Sky {
             // rounding: the sky-only branch below is not evaluated for ground hits
         } else {
             f3 tr_sky;
-            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cam_fast);
-            if (dot(ray_dir, sun_direction) > f(AF_COS_SUN)) radiance = radiance + tr_sky * v(AF_SOLAR_RAD);
+            const bool in_disc = dot(ray_dir, sun_direction) > f(AF_COS_SUN);
+            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cam_fast, in_disc);
+            if (in_disc) radiance = radiance + tr_sky * v(AF_SOLAR_RAD);
         }
         // pow(1 - exp(-radiance / white_point * exposure), 1 / 2.2)   (:883-885)
         const f3 e = radiance * v(AF_EXPO_W);

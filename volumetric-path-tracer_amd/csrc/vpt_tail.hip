@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
     const Sky<ResolveParams> sky = {R};
+    // the ground table is used only while its measured interpolation error is within the tolerance (vpt_sky.h)
+    const bool use_dir_tab = R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
 
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 // procedural sky, no sky_mult / sky_color, whatever environment_type says
                 value += beta * sky.sample(env_pos, dir, sun_dir);
             } else if (R.environment_type == 0) {                                   // :1838-1842
-                if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir) * beta * R.sky_mult * sky_color;
+                if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
             } else {                                                                 // :1843-1850
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }
@@ -182,6 +184,76 @@ __global__ void sky_cam_table_kernel(const ResolveParams R, float4* out) {
 }
 hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream) {
     hipLaunchKernelGGL(sky_cam_table_kernel, dim3(4), dim3(256), 0, stream, R, out);
+    return hipGetLastError();
+}
+
+// view-point ground table (vpt_sky.h, GroundNode): one thread per node ...
+__global__ void sky_dir_table_kernel(const ResolveParams R, float4* out) {
+    typedef Sky<ResolveParams> S;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint32_t)(S::DT_NX * S::DT_NN)) return;
+    const S sky = {R};
+    const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);       // view point - earth centre
+    const float r = length(p);
+    const float mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r);
+    const uint32_t ix = e / (uint32_t)S::DT_NN, in = e % (uint32_t)S::DT_NN;
+    f3 A, B;
+    float scale;
+    sky.GroundNode(r, mu_s, (float)ix * (1.0f / (float)(S::DT_NX - 1)), -1.0f + (float)in * (2.0f / (float)(S::DT_NN - 1)), A, B, scale);
+    out[2u * e] = make_float4(A.x, A.y, A.z, 0.0f);
+    out[2u * e + 1u] = make_float4(B.x, B.y, B.z, 0.0f);
+}
+// ... and one per cell of the used part: the full evaluation at the cell centre against the bilinear interpolant, for the cells a
+// view ray can reach (|nu - mu mu_s| <= sin(theta) sin(theta_s), widened by two cells); err = max relative deviation
+__global__ void sky_dir_table_check_kernel(const ResolveParams R, const float4* tab, unsigned long long* err) {
+    typedef Sky<ResolveParams> S;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t)((S::DT_NX - 1) * (S::DT_NN - 1))) return;
+    const S sky = {R};
+    const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);
+    const float r = length(p);
+    const float mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r);
+    const uint32_t ix = c / (uint32_t)(S::DT_NN - 1), in = c % (uint32_t)(S::DT_NN - 1);
+    const float x = ((float)ix + 0.5f) * (1.0f / (float)(S::DT_NX - 1)), nu = -1.0f + ((float)in + 0.5f) * (2.0f / (float)(S::DT_NN - 1));
+    if ((float)ix * (1.0f / (float)(S::DT_NX - 1)) > R.dir_tab_x_use) return;             // beyond the part that is used
+    const float b = sky.bottom();
+    const float h2 = (r - b) * (r + b), d_min = r - b, d = d_min * __builtin_amdgcn_exp2f(x * __builtin_amdgcn_logf(fdiv(fsqrt(fmax_(h2, 0.0f)), d_min)));
+    const float mu = clampf(fdiv(-(h2 + d * d), 2.0f * r * d), -1.0f, 1.0f);
+    const float band = fsqrt(fmax_((1.0f - mu * mu) * (1.0f - mu_s * mu_s), 0.0f)) + 2.0f * (2.0f / (float)(S::DT_NN - 1));
+    if (fabsf(nu - mu * mu_s) > band) return;
+    f3 A, B, Ai, Bi;
+    float scale;
+    sky.GroundNode(r, mu_s, x, nu, A, B, scale);
+    S::DirTabLerp(tab, (ix * (uint32_t)S::DT_NN + in) * 2u, 0.5f, 0.5f, Ai, Bi);
+    const float ph = S::MiePhase(sky.f(AF_MIE_G), nu);
+    const f3 Re = fscale_add3(B, ph, A), Ri = fscale_add3(Bi, ph, Ai);
+    const float dev = fmax_(fmax_(fabsf(Ri.x - Re.x), fabsf(Ri.y - Re.y)), fabsf(Ri.z - Re.z)) / fmax_(scale, 1e-30f);
+    // NaN compares false everywhere: let it through as a huge error
+    const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;
+    if (bits != 0u) atomicMax(err, ((unsigned long long)bits << 32) | c);             // high word: the error; low word: where
+}
+size_t sky_dir_table_bytes() { return sizeof(float4) * 2u * Sky<ResolveParams>::DT_NX * Sky<ResolveParams>::DT_NN; }
+hipError_t launch_sky_dir_table(const ResolveParams& R, float4* tab, unsigned long long* err, hipStream_t stream) {
+    typedef Sky<ResolveParams> S;
+    hipError_t e = hipMemsetAsync(err, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sky_dir_table_kernel, dim3((S::DT_NX * S::DT_NN + 255) / 256), dim3(256), 0, stream, R, tab);
+    hipLaunchKernelGGL(sky_dir_table_check_kernel, dim3(((S::DT_NX - 1) * (S::DT_NN - 1) + 255) / 256), dim3(256), 0, stream, R, tab, err);
+    return hipGetLastError();
+}
+
+// test hook (vpt_test_sky_samples): sample_atmosphere from the table's view point along n given directions
+__global__ void sky_samples_kernel(const ResolveParams R, const float* __restrict__ dirs, float* __restrict__ out, uint32_t n, int use_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Sky<ResolveParams> sky = {R};
+    const bool use_dir_tab = use_table && R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
+    const f3 v = sky.sample(mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]), mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]),
+                            mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]), use_dir_tab);
+    out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+}
+hipError_t launch_sky_samples(const ResolveParams& R, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_samples_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, dirs, out, n, use_table);
     return hipGetLastError();
 }
 
