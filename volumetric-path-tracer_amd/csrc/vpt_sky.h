@@ -411,8 +411,7 @@ struct Sky {
     // scattering row of the ground point becomes a staircase of binary32 cancellation (r mu)^2 - r^2 + bottom^2 -- up to 2 % of
     // the radiance within 2 degrees of the horizon, <= 0.8 % (1e-5 typically) below that.  The table is therefore used for rays
     // at least ~2 degrees below the horizon only (d <= min(33 (r - bottom), 0.35 horizon distance): dir_tab_x_use) and takes
-    // the ground point on the ground; returns false (evaluate in full) for everything else, including rays that are not a
-    // ground hit for the double-precision test of :401.
+    // the ground point on the ground; returns false (evaluate in full) for everything else.
     VPT_D bool GroundFromTable(f3 p, f3 pt, f3 sun_direction, f3& radiance) const {
         const f3 delta = pt - p;
         const float dist = length(delta);
@@ -421,7 +420,8 @@ struct Sky {
         const float inv_r = frcp(r);
         const float mu = dot(p, view_ray) * inv_r;
         const float fx = __builtin_amdgcn_logf(dist * R.dir_tab_inv_dmin) * R.dir_tab_inv_range;
-        if (!(fx <= R.dir_tab_x_use) || !HitsGround(r, mu)) return false;
+        // (within dir_tab_x_use |mu| is at least 1.6 times the horizon's: the double-precision ground test of :401 holds)
+        if (!(fx <= R.dir_tab_x_use)) return false;
         const float mu_s = dot(p, sun_direction) * inv_r;
         const float nu = dot(view_ray, sun_direction);
         f3 m_v;
@@ -464,6 +464,10 @@ struct Sky {
             radiance = radiance * tr + in_scatter;
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits
+#ifdef VPT_EXPERIMENT_NO_SKY               // perf study only (wrong image): what do the rays that end in the sky cost?
+        } else if (true) {
+            radiance = ray_dir;
+#endif
         } else {
             f3 tr_sky;
             const bool in_disc = dot(ray_dir, sun_direction) > f(AF_COS_SUN);
