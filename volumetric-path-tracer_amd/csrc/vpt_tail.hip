@@ -52,6 +52,9 @@ VPT_D f3 tonemap(f3 acc, float exposure_scale, unsigned int& packed) {
 #ifndef VPT_TAIL_WAVES_PER_EU
 #define VPT_TAIL_WAVES_PER_EU 4
 #endif
+// HEADS: samples that start no walk arrive as 16-byte heads (+ origins when the lens is open) instead of 64-byte records
+// (ResolveParams).  Two instantiations: each keeps its own register budget (the kernel spills at 4 waves per SIMD).
+template <bool HEADS>
 __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
@@ -68,14 +71,14 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
     // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
-    float4 h_next = R.heads ? R.heads[idx] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    float4 h_next = HEADS ? R.heads[idx] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
         const uint32_t local_it = local_it0 + k;
         const size_t slot = (size_t)k * R.n_pixels + idx;
         float4 q0, q1, q2, q3;
         bool from_record = true;
-        if (R.heads) {
+        if (HEADS) {
             const float4 h = h_next;
             if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
             if (h.w != -1.0f) {
@@ -258,7 +261,9 @@ hipError_t launch_sky_samples(const ResolveParams& R, const float* dirs, float* 
 }
 
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream) {
-    hipLaunchKernelGGL(tail_resolve_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
+    const dim3 grid((R.n_pixels + 255u) / 256u), block(256);
+    if (R.heads) hipLaunchKernelGGL(tail_resolve_kernel<true>, grid, block, 0, stream, R);
+    else hipLaunchKernelGGL(tail_resolve_kernel<false>, grid, block, 0, stream, R);
     return hipGetLastError();
 }
 
