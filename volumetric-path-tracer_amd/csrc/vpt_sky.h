@@ -464,10 +464,6 @@ struct Sky {
             radiance = radiance * tr + in_scatter;
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits
-#ifdef VPT_EXPERIMENT_NO_SKY               // perf study only (wrong image): what do the rays that end in the sky cost?
-        } else if (true) {
-            radiance = ray_dir;
-#endif
         } else {
             f3 tr_sky;
             const bool in_disc = dot(ray_dir, sun_direction) > f(AF_COS_SUN);
