@@ -220,3 +220,25 @@ def test_ground_table_per_direction(pkg, sky):
     assert (rel[steep] > 0).mean() > 0.3                      # the table is what evaluated them
     assert np.quantile(rel[steep], 0.99) <= 1e-4 or np.quantile(rel[steep], 0.97) <= 1e-4, np.quantile(rel[steep], [0.5, 0.97, 0.99])
     assert rel.max() <= 1e-2, rel.max()
+
+
+def test_ground_table_with_a_luminance_sky_model(pkg, monkeypatch):
+    """the same with a sky model other than the defaults (vpt_atmosphere_model: luminance APPROXIMATE, no ozone, constant solar
+    spectrum): the luminance factors multiply inside the table; table vs full evaluation, and both vs the oracle"""
+    import oracle_binding
+    sd = pkg.scene.dragon_scene(160, 90, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0, use_luminance=1, use_ozone=0, use_constant_solar_spectrum=1)
+    assert sd.atmosphere.use_luminance == 1
+    tab = pkg.scene.HipBinding(sd, device=0)
+    tab.render(4); tab.sync()
+    built, err = _dir_table_error(pkg, tab)
+    assert built == 1 and 0.0 < err <= 5e-4, err
+    monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")
+    full = pkg.scene.HipBinding(sd, device=0)
+    full.render(4); full.sync()
+    a, b = tab.accum.cpu().numpy(), full.accum.cpu().numpy()
+    assert b.mean() > 1e-2 and not np.array_equal(a, b)
+    assert rel_l2(a, b) <= 2e-4, rel_l2(a, b)
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(4)
+    assert rel_l2(a, ob.accum) <= 1e-3 and rel_l2(b, ob.accum) <= 1e-3, (rel_l2(a, ob.accum), rel_l2(b, ob.accum))

@@ -53,13 +53,13 @@ def precompute(ctx, params=None, orders=4):
     return p, luts
 
 
-def attach_default_atmosphere(sd, device=0):
-    """Fill sd.atmosphere (scalars) and sd.atm_luts (numpy tables) with the reference's default sky;
-    the tables are computed once per process on `device`."""
-    key = int(device)
+def attach_default_atmosphere(sd, device=0, **model_options):
+    """Fill sd.atmosphere (scalars) and sd.atm_luts (numpy tables) with the reference's default sky -- or, with model_options, the
+    sky of model(**model_options); the tables are computed once per process, device and option set."""
+    key = (int(device), tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in model_options.items())))
     if key not in _cache:
         ctx = Context(device)
-        p, luts = precompute(ctx)
+        p, luts = precompute(ctx, model(**model_options) if model_options else None)
         scal = AtmosphereParameters.from_buffer_copy(p)
         for f in ("delta_irradience_buffer", "delta_rayleigh_scattering_buffer", "delta_mie_scattering_buffer", "delta_scattering_density_buffer",
                   "delta_multiple_scattering_buffer", "transmittance_buffer", "irradiance_buffer", "scattering_buffer", "optional_mie_single_scattering_buffer"):
