@@ -37,10 +37,10 @@ int vpt_test_get_coherence(vpt_ctx *ctx, unsigned long long out[8]);
  * largest relative deviation of its bilinear interpolant from the full evaluation at the cell centres (the table is used while
  * err <= the tolerance, 5e-4 unless VPT_DIR_TABLE_TOL says otherwise), *cell = where: distance index * (DT_NN - 1) + nu index */
 int vpt_test_get_dir_table_error(vpt_ctx *ctx, int *built, float *err, unsigned int *cell);
-/* sample_atmosphere (render_kernel.cu:839-895) as the environment tail of the last render evaluates it, from that render's view
- * point along n unit directions dirs[3n] -> out[3n]; use_table: ground hits through the view-point ground table (when the last
- * render had one within tolerance), else in full */
-int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *dirs, int use_table, float *out);
+/* sample_atmosphere (render_kernel.cu:839-895) as the environment tail of the last render evaluates it, along n unit directions
+ * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
+ * hits through the view-point ground tables (when the last render had them within tolerance), else in full */
+int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float *dirs, int use_table, float *out);
 #ifdef __cplusplus
 }
 #endif

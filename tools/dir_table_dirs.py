@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 lib = pkg.load_library()
-lib.vpt_test_sky_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+lib.vpt_test_sky_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 sd = pkg.scene.dragon_scene(64, 36, "c2")
+LENS = float(os.environ.get("LENS", "0"))                 # aperture: origins spread over a disc of that diameter around the camera
 if len(sys.argv) > 1: sd.camera.origin.y += float(sys.argv[1])
+if LENS: sd.camera, _, _ = pkg.scene.frame_camera(lib, [sd.volumes[0][0]], 64, 36, aperture=LENS)
 pkg.atmosphere.attach_default_atmosphere(sd, device=0)
 hb = pkg.scene.HipBinding(sd, device=0)
 hb.render(1); hb.sync()
@@ -18,10 +20,16 @@ el = -np.exp(rng.uniform(np.log(1e-5), np.log(np.pi / 2), n))
 az = rng.uniform(0, 2 * np.pi, n)
 d = np.stack([np.cos(el) * np.cos(az), np.sin(el), np.cos(el) * np.sin(az)], 1).astype(np.float32)
 d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+org = None
+if LENS:
+    c = sd.camera
+    ph, rr = rng.uniform(0, 2 * np.pi, n), 0.5 * LENS * np.sqrt(rng.uniform(0, 1, n))
+    U = np.array([c.u.x, c.u.y, c.u.z]); V = np.array([c.v.x, c.v.y, c.v.z])
+    org = (np.array([c.origin.x, c.origin.y, c.origin.z])[None, :] + (rr * np.cos(ph))[:, None] * U + (rr * np.sin(ph))[:, None] * V).astype(np.float32)
 out = {}
 for use in (1, 0):
     o = np.zeros((n, 3), np.float32)
-    rc = lib.vpt_test_sky_samples(hb.ctx.h, n, d.ctypes.data, use, o.ctypes.data)
+    rc = lib.vpt_test_sky_samples(hb.ctx.h, n, org.ctypes.data if org is not None else None, d.ctypes.data, use, o.ctypes.data)
     assert rc == 0, rc
     out[use] = o.astype(np.float64)
 rel = np.abs(out[1] - out[0]).max(1) / np.maximum(out[0].max(1), 1e-9)

@@ -10,7 +10,7 @@ lib = pkg.load_library()
 NN = int(os.environ.get('DT_NN', '64'))
 lib.vpt_test_get_dir_table_error.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)]
 for name, tweak in (("c2", None), ("c2 low sun", lambda sd: setattr(sd.kp, "elevation", 3.0)), ("c2 sunset", lambda sd: setattr(sd.kp, "elevation", -1.0)),
-                    ("c2 high camera", "high")):
+                    ("c2 high camera", "high"), ("c2 aperture 2", "lens")):
     imgs = {}
     for mode in ("table", "full"):
         if mode == "full": os.environ["VPT_NO_DIR_TABLE"] = "1"
@@ -19,6 +19,8 @@ for name, tweak in (("c2", None), ("c2 low sun", lambda sd: setattr(sd.kp, "elev
         if callable(tweak): tweak(sd)
         if tweak == "high":
             sd.camera.origin.y += 20000.0
+        if tweak == "lens":
+            sd.camera, _, _ = pkg.scene.frame_camera(lib, [sd.volumes[0][0]], W, H, aperture=2.0)
         pkg.atmosphere.attach_default_atmosphere(sd, device=0)
         hb = pkg.scene.HipBinding(sd, device=0)
         hb.render(spp); hb.sync()

@@ -23,6 +23,16 @@ namespace vpt {
 
 enum { GRID_DENSE = 0, GRID_BRICKS = 1, GRID_QUADS = 2 };
 
+// view point of the environment tail's per-frame tables (vpt_sky.h), device-resident
+enum { SKY_VIEW_MAX_K = 4 };
+struct SkyView {
+    float r, mu_s;         // of the camera origin, with the tail's own arithmetic
+    int k;                 // variants: r + (-k .. k) binary32 steps
+    int pad_;
+    float4 tab[2 * SKY_VIEW_MAX_K + 1];   // per variant: 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom)), log-distance coordinate up to
+                                          // which the ground table is used (and was validated), 1 if the variant has a ground table
+};
+
 struct DVolume {
     const float* density;
     const float* emission;
@@ -186,7 +196,7 @@ struct TraceParams {
     const float4* cam_tab;
     float cam_tab_pos[3];
     const float4* dir_tab;                                 // always NULL in the tracer
-    float dir_tab_inv_dmin, dir_tab_inv_range, dir_tab_x_use;     // 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom))
+    const SkyView* sky_view;                               // always NULL in the tracer     // 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom))
     float atm_f[40];                                       // packed vpt_atmosphere_parameters scalars
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };
@@ -234,8 +244,11 @@ struct ResolveParams {
     const float4* dir_tab;
     const uint32_t* dir_tab_err;      // [0] cell of the largest error, [1] its float bits
     float dir_tab_tol;
-    float dir_tab_x_use;              // the table is used (and was validated) for log-distance coordinates up to this
-    float dir_tab_inv_dmin, dir_tab_inv_range;     // 1 / (r - bottom), 1 / log2(horizon distance / (r - bottom))
+    // Both tables exist in 2k+1 VARIANTS, one per binary32 value of the view point's radius r within k steps of the camera's:
+    // with an open lens every sample starts on the lens disc, whose height above the ground spans a few binary32 steps of r
+    // (0.5 m at earth-radius magnitude) while mu_s moves by 1e-7 -- a sample whose (r, mu_s) matches a variant looks from "the"
+    // view point as far as the table coordinates can tell.  k = 0 with a closed lens.  Written by sky_view_kernel.
+    const SkyView* sky_view;
     float atm_f[40];       // packed vpt_atmosphere_parameters scalars (see vpt_sky.h)
     DTexture transmittance_tex, scattering_tex, irradiance_tex, single_mie_tex;
 };

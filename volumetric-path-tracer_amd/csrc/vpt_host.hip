@@ -28,10 +28,11 @@ hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit,
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
-hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream);
+hipError_t launch_sky_cam_table(const ResolveParams& R, SkyView* view, float4* out, int k, hipStream_t stream);
+size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
-hipError_t launch_sky_dir_table(const ResolveParams& R, float4* tab, unsigned long long* err, hipStream_t stream);
-hipError_t launch_sky_samples(const ResolveParams& R, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
+hipError_t launch_sky_dir_table(const ResolveParams& R, const SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
+hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -71,7 +72,8 @@ struct vpt_ctx {
     float4* d_insts = nullptr;        // compact per-instance matrices (TraceParams::insts)
     bool single_file = false;
     std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
-    float4* d_cam_tab = nullptr;      // camera-point scattering table, 8 x 128 x 2 float4 (vpt_sky.h)
+    float4* d_cam_tab = nullptr;      // camera-point scattering tables, (2 k + 1) x 8 x 128 x 2 float4 (vpt_sky.h)
+    SkyView* d_sky_view = nullptr;    // their view point and variants
     float4* d_dir_tab = nullptr;      // view-point ground table (vpt_sky.h, GroundNode) ...
     unsigned long long* d_dir_err = nullptr;    // ... and its measured interpolation error (high word: float bits, low word: the cell)
     bool dir_tab_built = false;       // for the view point / sun / model of cam_tab_key
@@ -117,7 +119,7 @@ struct vpt_ctx {
     bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
     float dir_tab_tol = 5e-4f;             // VPT_DIR_TABLE_TOL: largest relative mid-cell error the ground table may show
     // camera-point scattering table: rebuilt only when its inputs change (per-frame calls reuse it)
-    float cam_tab_key[46] = {0};
+    float cam_tab_key[47] = {0};
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
     bool cam_tab_built = false;
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
@@ -340,6 +342,7 @@ void vpt_destroy(vpt_ctx* ctx) {
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
     (void)hipFree(ctx->d_cam_tab);
+    (void)hipFree(ctx->d_sky_view);
     (void)hipFree(ctx->d_dir_tab);
     (void)hipFree(ctx->d_dir_err);
     (void)hipFree(ctx->d_insts);
@@ -793,23 +796,28 @@ int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned 
     return VPT_OK;
 }
 
-int vpt_test_sky_samples(vpt_ctx* ctx, int n, const float* dirs, int use_table, float* out) {
+int vpt_test_sky_samples(vpt_ctx* ctx, int n, const float* origins, const float* dirs, int use_table, float* out) {
     if (!ctx || n <= 0 || !dirs || !out) return VPT_E_INVALID;
     if (!ctx->have_last_resolve || !ctx->last_resolve.has_atmosphere || !ctx->last_resolve.cam_tab_valid) {
         set_error(ctx, "vpt_test_sky_samples: needs a previous render with the procedural sky");
         return VPT_E_NOT_READY;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    float *d_dirs = nullptr, *d_out = nullptr;
+    float *d_dirs = nullptr, *d_out = nullptr, *d_org = nullptr;
     HIPCHK(ctx, hipMalloc(&d_dirs, sizeof(float) * 3 * n));
     HIPCHK(ctx, hipMalloc(&d_out, sizeof(float) * 3 * n));
     HIPCHK(ctx, hipMemcpy(d_dirs, dirs, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    if (origins) {
+        HIPCHK(ctx, hipMalloc(&d_org, sizeof(float) * 3 * n));
+        HIPCHK(ctx, hipMemcpy(d_org, origins, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx, hipDeviceSynchronize());
-    HIPCHK(ctx, launch_sky_samples(ctx->last_resolve, d_dirs, d_out, (uint32_t)n, use_table, ctx->stream));
+    HIPCHK(ctx, launch_sky_samples(ctx->last_resolve, d_org, d_dirs, d_out, (uint32_t)n, use_table, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out, d_out, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
     (void)hipFree(d_dirs);
     (void)hipFree(d_out);
+    (void)hipFree(d_org);
     return VPT_OK;
 }
 
@@ -1198,53 +1206,52 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.blue_noise = ctx->d_bn_table;
     R.records = ctx->d_records;
 
-    // camera-point scattering table (vpt_sky.h): valid for samples whose env_pos is the camera origin
+    // per-frame sky tables (vpt_sky.h): valid for samples whose env_pos has the camera origin's (r, mu_s) -- or, behind an open
+    // lens, an r within k binary32 steps of it (the lens disc spans lens_radius of height: k = that in steps of r, + 1)
     if (R.has_atmosphere && !ctx->no_cam_table) {
-        if (!ctx->d_cam_tab) HIPCHK(ctx, hipMalloc(&ctx->d_cam_tab, sizeof(float4) * 8 * 128 * 2));
+        if (!ctx->d_cam_tab) {
+            HIPCHK(ctx, hipMalloc(&ctx->d_cam_tab, sky_cam_table_bytes()));
+            HIPCHK(ctx, hipMalloc(&ctx->d_sky_view, sizeof(SkyView)));
+        }
         R.cam_tab = ctx->d_cam_tab;
+        R.sky_view = ctx->d_sky_view;
         R.cam_tab_pos[0] = cam->origin.x; R.cam_tab_pos[1] = cam->origin.y; R.cam_tab_pos[2] = cam->origin.z;
-        // the table is a function of the view point, the sun direction, the model scalars and the two 4-D tables: a frame
-        // loop that changes none of them (main.cpp:1822-1829, one launch per iteration) builds it once
-        float key[46];
+        int view_k = 0;
+        if (cam->lens_radius != 0.0f) {
+            const double py = (double)cam->origin.y + (double)R.atm_f[0], r = std::sqrt((double)cam->origin.x * cam->origin.x + py * py + (double)cam->origin.z * cam->origin.z);
+            const double step = std::ldexp(1.0, std::ilogb(r) - 23);                  // binary32 spacing at r
+            view_k = (int)std::min<double>((double)SKY_VIEW_MAX_K, std::ceil(std::fabs((double)cam->lens_radius) / step) + 1.0);
+        }
+        // the tables are a function of the view point, the lens (variants), the sun direction, the model scalars and the two 4-D
+        // tables: a frame loop that changes none of them (main.cpp:1822-1829, one launch per iteration) builds them once
+        float key[47];
         std::memcpy(key, R.cam_tab_pos, sizeof(float) * 3);
         std::memcpy(key + 3, R.sun_dir, sizeof(float) * 3);
         std::memcpy(key + 6, R.atm_f, sizeof(float) * 40);
+        key[46] = (float)view_k;
         const void* tex[4] = {R.transmittance_tex.data, R.scattering_tex.data, R.irradiance_tex.data, R.single_mie_tex.data};
         if (!ctx->cam_tab_built || std::memcmp(key, ctx->cam_tab_key, sizeof(key)) != 0 || std::memcmp(tex, ctx->cam_tab_tex, sizeof(tex)) != 0) {
-            HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_cam_tab, stream));
+            HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_sky_view, ctx->d_cam_tab, view_k, stream));
             std::memcpy(ctx->cam_tab_key, key, sizeof(key));
             std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
             ctx->cam_tab_built = true;
             ctx->dir_tab_built = false;
         }
         R.cam_tab_valid = 1;
-        // view-point ground table (vpt_sky.h): the direct integrator's procedural sky, view point between the ground and the
-        // top of the atmosphere
-        const double bottom = R.atm_f[0], top = R.atm_f[1];
-        const double px = cam->origin.x, py = (double)cam->origin.y + bottom, pz = cam->origin.z;
-        const float r = (float)std::sqrt(px * px + py * py + pz * pz);
-        if (!ctx->no_dir_table && kp->integrator == 0 && kp->environment_type == 0 && r > (float)bottom && r <= (float)top) {
+        // view-point ground tables (vpt_sky.h): the direct integrator's procedural sky; which variants get one (view point between
+        // the ground and the top of the atmosphere) is sky_view_kernel's decision
+        if (!ctx->no_dir_table && kp->integrator == 0 && kp->environment_type == 0) {
             if (!ctx->d_dir_tab) {
                 HIPCHK(ctx, hipMalloc(&ctx->d_dir_tab, sky_dir_table_bytes()));
                 HIPCHK(ctx, hipMalloc(&ctx->d_dir_err, sizeof(unsigned long long)));
             }
-            const float b = (float)bottom;
-            const float d_min = r - b, d_max = std::sqrt(std::max((r - b) * (r + b), 0.0f));
-            // the table covers rays at least ~2 degrees below the horizon: d <= min(33 (r - bottom), 0.35 horizon distance); the
-            // grazing rest takes the full path (vpt_sky.h, GroundFromTable)
-            const float x_use = d_max > d_min ? std::log2(std::min(33.0f * d_min, 0.35f * d_max) / d_min) / std::log2(d_max / d_min) : 0.0f;
-            if (x_use > 0.05f) {
-                R.dir_tab_tol = ctx->dir_tab_tol;
-                R.dir_tab_inv_dmin = 1.0f / d_min;
-                R.dir_tab_inv_range = 1.0f / std::log2(d_max / d_min);
-                R.dir_tab_x_use = std::min(x_use, 1.0f);
-                if (!ctx->dir_tab_built) {
-                    HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_dir_tab, ctx->d_dir_err, stream));
-                    ctx->dir_tab_built = true;
-                }
-                R.dir_tab = ctx->d_dir_tab;
-                R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
+            R.dir_tab_tol = ctx->dir_tab_tol;
+            if (!ctx->dir_tab_built) {
+                HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_sky_view, ctx->d_dir_tab, ctx->d_dir_err, view_k, stream));
+                ctx->dir_tab_built = true;
             }
+            R.dir_tab = ctx->d_dir_tab;
+            R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
         }
     }
     ctx->last_resolve = R;

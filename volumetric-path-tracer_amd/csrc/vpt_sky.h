@@ -89,6 +89,11 @@ VPT_D f3 lut2d(const float* data, float u, float v) {
 template <class RP>
 struct Sky {
     const RP& R;
+    // view point of the per-frame tables (SkyView, loaded once per thread by the tail); view_k < 0: no tables (the tracer)
+    float view_r = 0.0f, view_mu_s = 0.0f;
+    int view_k = -1;
+    bool view_multi = false;                        // view_k > 0 (open lens); a compile-time constant of the tail's instantiations
+    float4 view_vt0 = {0.0f, 0.0f, 0.0f, 0.0f};     // SkyView::tab[0] when !view_multi (closed lens: one variant, kept in registers)
     VPT_D float f(int i) const { return R.atm_f[i]; }
     VPT_D f3 v(int i) const { return mk3(R.atm_f[i], R.atm_f[i + 1], R.atm_f[i + 2]); }
     VPT_D float bottom() const { return f(AF_BOTTOM); }
@@ -219,11 +224,15 @@ struct Sky {
     // along those two axes; a look-up from the view point then needs 4 table entries (2 mu rows x 2 nu
     // slices) instead of 16 texels per table.  Multilinear interpolation commutes, so this is the same
     // value up to rounding (value-only arithmetic).  Any other view point takes the general path.
-    VPT_D bool CamFast(f3 camera_rel_scene) const {
-        return R.cam_tab_valid && camera_rel_scene.x == R.cam_tab_pos[0] && camera_rel_scene.y == R.cam_tab_pos[1] &&
-               camera_rel_scene.z == R.cam_tab_pos[2];
+    // The tables exist in 2k+1 variants, one per binary32 value of r within k steps of the camera origin's (SkyView): behind an
+    // open lens the samples start on the lens disc, whose height spans a few binary32 steps of r (0.5 m at earth-radius magnitude)
+    // while mu_s moves by ~1e-7, far below what the mu_s axis of the tables resolves.  Returns the variant, or -1: general path.
+    VPT_D int CamVariant(float r, float mu_s) const {
+        if (view_k < 0) return -1;
+        const int k = (int)(__float_as_uint(r) - __float_as_uint(view_r)) + view_k;
+        return (k >= 0 && k <= 2 * view_k && fabsf(mu_s - view_mu_s) <= 1e-6f) ? k : -1;
     }
-    VPT_D f3 CombinedScatteringCam(float r, float mu, float nu, bool ground, f3& single_mie) const {
+    VPT_D f3 CombinedScatteringCam(float r, float mu, float nu, bool ground, f3& single_mie, int cv) const {
         // u_mu of ScatteringUvwz (:520-546); u_r and u_mu_s are baked into the table
         const float H = f(AF_H);
         const float rho = SafeSqrt(r * r - bottom() * bottom());
@@ -246,7 +255,7 @@ struct Sky {
         const float lerp = tex_coord_x - tex_x;
         const uint32_t n0 = (uint32_t)tex_x, n1 = min(n0 + 1u, 7u);
         const Tap ty = lut_tap<128, false>(u_mu);
-        const float4* __restrict__ T = R.cam_tab;
+        const float4* __restrict__ T = view_multi ? R.cam_tab + (uint32_t)cv * (8u * 128u * 2u) : R.cam_tab;
         auto row = [&](uint32_t n, f3& sc, f3& mie) {
             const uint32_t e0 = (n * 128u + ty.i0) * 2u, e1 = (n * 128u + ty.i1) * 2u;
             sc = ld_f3(T, e0);
@@ -273,7 +282,7 @@ struct Sky {
         return lut2d(R.irradiance_tex.data, UnitToTex<256>(x_mu_s), UnitToTex<64>(x_r));
     }
     // want_tr: the transmittance is only read for rays inside the sun's disc (sample()); its table look-up is skipped otherwise
-    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, bool cam_fast, bool want_tr) const {   // :694 (shadow_length = 0)
+    VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, int cv, bool want_tr) const {   // :694 (shadow_length = 0)
         float r = length(camera);
         float rmu = dot(camera, view_ray);
         const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
@@ -281,7 +290,7 @@ struct Sky {
             camera = camera + view_ray * dtop;
             r = top();
             rmu += dtop;
-            cam_fast = false;
+            cv = -1;
         } else if (r > top()) {
             transmittance = mk3(1.0f);
             return mk3(0.0f);
@@ -294,12 +303,12 @@ struct Sky {
         transmittance = mk3(0.0f);
         if (want_tr && !ground) transmittance = TransmittanceToTop(r, mu);
         f3 single_mie;
-        const f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        const f3 scattering = cv >= 0 ? CombinedScatteringCam(r, mu, nu, ground, single_mie, cv) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
         f3 sky = fscale_add3(single_mie, MiePhase(f(AF_MIE_G), nu), scattering * RayleighPhase(nu));
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
-    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, bool cam_fast) const {   // :749 (shadow_length = 0)
+    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, int cv) const {   // :749 (shadow_length = 0)
         const f3 delta = point - camera;
         float d = length(delta);
         const f3 view_ray = delta * frcp(d);
@@ -311,7 +320,7 @@ struct Sky {
             r = top();
             rmu += dtop;
             d = length(point - camera);
-            cam_fast = false;
+            cv = -1;
         }
         const float inv_r = frcp(r);
         const float mu = rmu * inv_r;
@@ -321,7 +330,7 @@ struct Sky {
         const float r_d = ClampRadius(RadiusAt(r, mu, d));
         transmittance = Transmittance(r, mu, d, r_d, ground);
         f3 single_mie;
-        f3 scattering = cam_fast ? CombinedScatteringCam(r, mu, nu, ground, single_mie) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
+        f3 scattering = cv >= 0 ? CombinedScatteringCam(r, mu, nu, ground, single_mie, cv) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
         d = fmax_(d, 0.0f);
         const float r_p = r_d;
         const float inv_rp = frcp(r_p);
@@ -408,24 +417,24 @@ struct Sky {
     // mu and nu are re-derived from it (SkyRadianceToPoint) -- for a camera a few metres above the ground that quantisation IS
     // the reference's value.  What is NOT followed is the radius of that rounded point, which the full path clamps to bottom or
     // finds one binary32 step (0.5 m) above it: half a metre of radius is 2.5 km of the tables' rho coordinate, and behind it the
-    // scattering row of the ground point becomes a staircase of binary32 cancellation (r mu)^2 - r^2 + bottom^2 -- up to 2 % of
-    // the radiance within 2 degrees of the horizon, <= 0.8 % (1e-5 typically) below that.  The table is therefore used for rays
-    // at least ~2 degrees below the horizon only (d <= min(33 (r - bottom), 0.35 horizon distance): dir_tab_x_use) and takes
+    // scattering row of the ground point becomes a staircase of binary32 cancellation (r mu)^2 - r^2 + bottom^2 (following the
+    // step in the transmittance alone, through a table of ratios over d, changed nothing: measured) -- up to 2 % of the radiance
+    // within 2 degrees of the horizon, <= 0.8 % (1e-5 typically) below that from the camera origin, ~1 % for a few per cent of the
+    // origins on an open lens' disc.  The table is therefore used for rays at least ~2 degrees below the horizon only (d <= min(33 (r - bottom), 0.35 horizon distance): SkyView::tab[].z) and takes
     // the ground point on the ground; returns false (evaluate in full) for everything else.
-    VPT_D bool GroundFromTable(f3 p, f3 pt, f3 sun_direction, f3& radiance) const {
+    VPT_D bool GroundFromTable(f3 p, float r, float mu_s, f3 pt, f3 sun_direction, int cv, f3& radiance) const {
         const f3 delta = pt - p;
         const float dist = length(delta);
         const f3 view_ray = delta * frcp(dist);
-        const float r = length(p);
         const float inv_r = frcp(r);
         const float mu = dot(p, view_ray) * inv_r;
-        const float fx = __builtin_amdgcn_logf(dist * R.dir_tab_inv_dmin) * R.dir_tab_inv_range;
-        // (within dir_tab_x_use |mu| is at least 1.6 times the horizon's: the double-precision ground test of :401 holds)
-        if (!(fx <= R.dir_tab_x_use)) return false;
-        const float mu_s = dot(p, sun_direction) * inv_r;
+        const float4 vt = view_multi ? R.sky_view->tab[cv] : view_vt0;               // 1 / d_min, 1 / log2(d_max / d_min), x_use, has a table
+        const float fx = __builtin_amdgcn_logf(dist * vt.x) * vt.y;
+        // (within x_use |mu| is at least 1.6 times the horizon's: the double-precision ground test of :401 holds)
+        if (!(fx <= vt.z) || vt.w == 0.0f) return false;
         const float nu = dot(view_ray, sun_direction);
         f3 m_v;
-        f3 s_v = CombinedScatteringCam(r, mu, nu, true, m_v);
+        f3 s_v = CombinedScatteringCam(r, mu, nu, true, m_v, cv);
         const float y = clampf(mu_s * 100.0f, 0.0f, 1.0f);
         m_v = m_v * (y * y * (3.0f - (2.0f * y)));
         if (lum()) { s_v *= v(AF_SKY_K); m_v *= v(AF_SKY_K); }
@@ -433,7 +442,7 @@ struct Sky {
         uint32_t e; float ax, an;
         DirTabCoords(fmax_(fx, 0.0f) * (float)(DT_NX - 1), fn, e, ax, an);
         f3 A, B;
-        DirTabLerp(R.dir_tab, e, ax, an, A, B);
+        DirTabLerp(view_multi ? R.dir_tab + (uint32_t)cv * (2u * DT_NX * DT_NN) : R.dir_tab, e, ax, an, A, B);
         radiance = fscale_add3(m_v + B, MiePhase(f(AF_MIE_G), nu), fscale_add3(s_v, RayleighPhase(nu), A));
         return true;
     }
@@ -446,8 +455,21 @@ struct Sky {
         const float d2 = p_dot_p - p_dot_v * p_dot_v;
         const float dist = -p_dot_v - fsqrt(earth_center.y * earth_center.y - d2);
         f3 radiance;
-        const bool cam_fast = CamFast(ray_pos);
-        if (dist > 0.0f && use_dir_tab && cam_fast && GroundFromTable(p, ray_pos + ray_dir * dist - earth_center, sun_direction, radiance)) {
+        int cv = -1;
+        float r_view = 0.0f, mu_s_view = 0.0f;
+        if (view_k >= 0 && !view_multi) {
+            // closed lens: one variant, the camera origin itself
+            if (ray_pos.x == R.cam_tab_pos[0] && ray_pos.y == R.cam_tab_pos[1] && ray_pos.z == R.cam_tab_pos[2]) {
+                cv = 0;
+                r_view = view_r;
+                mu_s_view = view_mu_s;
+            }
+        } else if (view_k >= 0) {
+            r_view = length(p);
+            mu_s_view = dot(p, sun_direction) * frcp(r_view);
+            cv = CamVariant(r_view, mu_s_view);
+        }
+        if (dist > 0.0f && use_dir_tab && cv >= 0 && GroundFromTable(p, r_view, mu_s_view, ray_pos + ray_dir * dist - earth_center, sun_direction, cv, radiance)) {
             // radiance from the view-point ground table
         } else if (dist > 0.0f) {
             const f3 pt = ray_pos + ray_dir * dist - earth_center;
@@ -460,14 +482,14 @@ struct Sky {
             if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
             radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
             f3 tr;
-            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr, cam_fast);
+            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr, cv);
             radiance = radiance * tr + in_scatter;
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits
         } else {
             f3 tr_sky;
             const bool in_disc = dot(ray_dir, sun_direction) > f(AF_COS_SUN);
-            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cam_fast, in_disc);
+            radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cv, in_disc);
             if (in_disc) radiance = radiance + tr_sky * v(AF_SOLAR_RAD);
         }
         // pow(1 - exp(-radiance / white_point * exposure), 1 / 2.2)   (:883-885)
@@ -480,13 +502,10 @@ struct Sky {
 };
 
 // One entry of the camera-point table: both 4-D tables interpolated along r (z) and mu_s (x within a nu
-// slice) at the view point `cam` (scene coordinates), for mu row j and nu slice n.
+// slice) at the view point's (r, mu_s), for mu row j and nu slice n.
 template <class RP>
-VPT_D void sky_cam_table_entry(const RP& R, f3 cam, f3 sun_direction, uint32_t n, uint32_t j, f3& sc, f3& mie) {
+VPT_D void sky_cam_table_entry(const RP& R, float r, float mu_s, uint32_t n, uint32_t j, f3& sc, f3& mie) {
     const Sky<RP> sky = {R};
-    const f3 p = cam - mk3(.0f, -sky.bottom(), .0f);
-    const float r = length(p);
-    const float mu_s = dot(p, sun_direction) * frcp(r);
     const f4 uvwz = sky.ScatteringUvwz(r, 0.0f, mu_s, 0.0f, false);          // only u_mu_s (y) and u_r (w) are used
     const Tap tz = lut_tap<32, false>(uvwz.w);
     const Tap tm = lut_tap<256, false>(uvwz.y * 0.125f);                       // the tap inside nu slice 0: index < 32

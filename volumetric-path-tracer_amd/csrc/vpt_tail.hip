@@ -52,9 +52,21 @@ VPT_D f3 tonemap(f3 acc, float exposure_scale, unsigned int& packed) {
 #ifndef VPT_TAIL_WAVES_PER_EU
 #define VPT_TAIL_WAVES_PER_EU 4
 #endif
+// LENS: the tables have one variant per binary32 step of r across the lens disc (SkyView); else one, the camera origin's
+template <bool LENS>
+VPT_D void load_sky_view(const ResolveParams& R, Sky<ResolveParams>& sky) {
+    sky.view_multi = LENS;
+    if (R.cam_tab_valid) {
+        sky.view_r = R.sky_view->r;
+        sky.view_mu_s = R.sky_view->mu_s;
+        sky.view_k = LENS ? R.sky_view->k : 0;
+        if (!LENS) sky.view_vt0 = R.sky_view->tab[0];
+    }
+}
+
 // HEADS: samples that start no walk arrive as 16-byte heads (+ origins when the lens is open) instead of 64-byte records
 // (ResolveParams).  Two instantiations: each keeps its own register budget (the kernel spills at 4 waves per SIMD).
-template <bool HEADS>
+template <bool HEADS, bool LENS>
 __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
@@ -64,7 +76,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     float tr_last = 0.0f;
     const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
-    const Sky<ResolveParams> sky = {R};
+    Sky<ResolveParams> sky = {R};
+    load_sky_view<LENS>(R, sky);
     // the ground table is used only while its measured interpolation error is within the tolerance (vpt_sky.h)
     const bool use_dir_tab = R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
 
@@ -176,49 +189,81 @@ hipError_t launch_display(const float* accum, unsigned int* display, float* raw,
     return hipGetLastError();
 }
 
-// camera-point scattering table (vpt_sky.h): 8 nu slices x 128 mu rows, one thread per entry
-__global__ void sky_cam_table_kernel(const ResolveParams R, float4* out) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 8u * 128u) return;
-    f3 sc, mie;
-    sky_cam_table_entry(R, mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]), mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]), e >> 7, e & 127u, sc, mie);
-    out[2u * e] = make_float4(sc.x, sc.y, sc.z, 0.0f);
-    out[2u * e + 1u] = make_float4(mie.x, mie.y, mie.z, 0.0f);
+// view point of the per-frame tables: (r, mu_s) of the camera origin with this file's own arithmetic, and per variant of r (one
+// per binary32 step within k of it) the ground table's log-distance map -- thread v = variant
+__global__ void sky_view_kernel(const ResolveParams R, SkyView* out, int k) {
+    typedef Sky<ResolveParams> S;
+    const int v = (int)threadIdx.x;
+    const S sky = {R};
+    const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);       // view point - earth centre
+    const float r0 = length(p);
+    if (v == 0) {
+        out->r = r0;
+        out->mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r0);
+        out->k = k;
+        out->pad_ = 0;
+    }
+    if (v > 2 * k) return;
+    const float r = __uint_as_float(__float_as_uint(r0) + (uint32_t)(v - k));
+    const float b = sky.bottom();
+    const float d_min = r - b, d_max = fsqrt(fmax_((r - b) * (r + b), 0.0f));
+    // the ground table covers rays at least ~2 degrees below the horizon: d <= min(33 (r - bottom), 0.35 horizon distance); the
+    // grazing rest takes the full path (vpt_sky.h, GroundFromTable).  No table from outside the atmosphere or on the ground.
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r > b && r <= sky.top() && d_max > d_min) {
+        const float inv_range = frcp(__builtin_amdgcn_logf(fdiv(d_max, d_min)));
+        const float x_use = fmin_(__builtin_amdgcn_logf(fdiv(fmin_(33.0f * d_min, 0.35f * d_max), d_min)) * inv_range, 1.0f);
+        t = make_float4(frcp(d_min), inv_range, x_use, x_use > 0.05f ? 1.0f : 0.0f);
+    }
+    out->tab[v] = t;
 }
-hipError_t launch_sky_cam_table(const ResolveParams& R, float4* out, hipStream_t stream) {
-    hipLaunchKernelGGL(sky_cam_table_kernel, dim3(4), dim3(256), 0, stream, R, out);
+// camera-point scattering table (vpt_sky.h): per variant 8 nu slices x 128 mu rows, one thread per entry
+__global__ void sky_cam_table_kernel(const ResolveParams R, const SkyView* view, float4* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t variant = t >> 10, e = t & 1023u;
+    if (variant > 2u * (uint32_t)view->k) return;
+    const float r = __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)view->k);
+    f3 sc, mie;
+    sky_cam_table_entry(R, r, view->mu_s, e >> 7, e & 127u, sc, mie);
+    out[2u * t] = make_float4(sc.x, sc.y, sc.z, 0.0f);
+    out[2u * t + 1u] = make_float4(mie.x, mie.y, mie.z, 0.0f);
+}
+hipError_t launch_sky_cam_table(const ResolveParams& R, SkyView* view, float4* out, int k, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_view_kernel, dim3(1), dim3(64), 0, stream, R, view, k);
+    hipLaunchKernelGGL(sky_cam_table_kernel, dim3(4 * (2 * k + 1)), dim3(256), 0, stream, R, view, out);
     return hipGetLastError();
 }
 
-// view-point ground table (vpt_sky.h, GroundNode): one thread per node ...
-__global__ void sky_dir_table_kernel(const ResolveParams R, float4* out) {
+// view-point ground table (vpt_sky.h, GroundNode): one thread per node and variant ...
+__global__ void sky_dir_table_kernel(const ResolveParams R, const SkyView* view, float4* out) {
     typedef Sky<ResolveParams> S;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint32_t)(S::DT_NX * S::DT_NN)) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nodes = (uint32_t)(S::DT_NX * S::DT_NN);
+    const uint32_t variant = t / nodes, e = t % nodes;
+    if (variant > 2u * (uint32_t)view->k || view->tab[variant].w == 0.0f) return;
     const S sky = {R};
-    const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);       // view point - earth centre
-    const float r = length(p);
-    const float mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r);
+    const float r = __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)view->k);
     const uint32_t ix = e / (uint32_t)S::DT_NN, in = e % (uint32_t)S::DT_NN;
     f3 A, B;
     float scale;
-    sky.GroundNode(r, mu_s, (float)ix * (1.0f / (float)(S::DT_NX - 1)), -1.0f + (float)in * (2.0f / (float)(S::DT_NN - 1)), A, B, scale);
-    out[2u * e] = make_float4(A.x, A.y, A.z, 0.0f);
-    out[2u * e + 1u] = make_float4(B.x, B.y, B.z, 0.0f);
+    sky.GroundNode(r, view->mu_s, (float)ix * (1.0f / (float)(S::DT_NX - 1)), -1.0f + (float)in * (2.0f / (float)(S::DT_NN - 1)), A, B, scale);
+    out[2u * t] = make_float4(A.x, A.y, A.z, 0.0f);
+    out[2u * t + 1u] = make_float4(B.x, B.y, B.z, 0.0f);
 }
 // ... and one per cell of the used part: the full evaluation at the cell centre against the bilinear interpolant, for the cells a
-// view ray can reach (|nu - mu mu_s| <= sin(theta) sin(theta_s), widened by two cells); err = max relative deviation
-__global__ void sky_dir_table_check_kernel(const ResolveParams R, const float4* tab, unsigned long long* err) {
+// view ray can reach (|nu - mu mu_s| <= sin(theta) sin(theta_s), widened by two cells); err = max relative deviation over all variants
+__global__ void sky_dir_table_check_kernel(const ResolveParams R, const SkyView* view, const float4* tab, unsigned long long* err) {
     typedef Sky<ResolveParams> S;
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (uint32_t)((S::DT_NX - 1) * (S::DT_NN - 1))) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cells = (uint32_t)((S::DT_NX - 1) * (S::DT_NN - 1));
+    const uint32_t variant = t / cells, c = t % cells;
+    if (variant > 2u * (uint32_t)view->k || view->tab[variant].w == 0.0f) return;
     const S sky = {R};
-    const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);
-    const float r = length(p);
-    const float mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r);
+    const float r = __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)view->k);
+    const float mu_s = view->mu_s;
     const uint32_t ix = c / (uint32_t)(S::DT_NN - 1), in = c % (uint32_t)(S::DT_NN - 1);
     const float x = ((float)ix + 0.5f) * (1.0f / (float)(S::DT_NX - 1)), nu = -1.0f + ((float)in + 0.5f) * (2.0f / (float)(S::DT_NN - 1));
-    if ((float)ix * (1.0f / (float)(S::DT_NX - 1)) > R.dir_tab_x_use) return;             // beyond the part that is used
+    if ((float)ix * (1.0f / (float)(S::DT_NX - 1)) > view->tab[variant].z) return;           // beyond the part that is used
     const float b = sky.bottom();
     const float h2 = (r - b) * (r + b), d_min = r - b, d = d_min * __builtin_amdgcn_exp2f(x * __builtin_amdgcn_logf(fdiv(fsqrt(fmax_(h2, 0.0f)), d_min)));
     const float mu = clampf(fdiv(-(h2 + d * d), 2.0f * r * d), -1.0f, 1.0f);
@@ -227,7 +272,7 @@ __global__ void sky_dir_table_check_kernel(const ResolveParams R, const float4* 
     f3 A, B, Ai, Bi;
     float scale;
     sky.GroundNode(r, mu_s, x, nu, A, B, scale);
-    S::DirTabLerp(tab, (ix * (uint32_t)S::DT_NN + in) * 2u, 0.5f, 0.5f, Ai, Bi);
+    S::DirTabLerp(tab + variant * (2u * S::DT_NX * S::DT_NN), (ix * (uint32_t)S::DT_NN + in) * 2u, 0.5f, 0.5f, Ai, Bi);
     const float ph = S::MiePhase(sky.f(AF_MIE_G), nu);
     const f3 Re = fscale_add3(B, ph, A), Ri = fscale_add3(Bi, ph, Ai);
     const float dev = fmax_(fmax_(fabsf(Ri.x - Re.x), fabsf(Ri.y - Re.y)), fabsf(Ri.z - Re.z)) / fmax_(scale, 1e-30f);
@@ -235,35 +280,42 @@ __global__ void sky_dir_table_check_kernel(const ResolveParams R, const float4* 
     const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;
     if (bits != 0u) atomicMax(err, ((unsigned long long)bits << 32) | c);             // high word: the error; low word: where
 }
-size_t sky_dir_table_bytes() { return sizeof(float4) * 2u * Sky<ResolveParams>::DT_NX * Sky<ResolveParams>::DT_NN; }
-hipError_t launch_sky_dir_table(const ResolveParams& R, float4* tab, unsigned long long* err, hipStream_t stream) {
+size_t sky_cam_table_bytes() { return sizeof(float4) * 2u * 8u * 128u * (2u * SKY_VIEW_MAX_K + 1u); }
+size_t sky_dir_table_bytes() { return sizeof(float4) * 2u * Sky<ResolveParams>::DT_NX * Sky<ResolveParams>::DT_NN * (2u * SKY_VIEW_MAX_K + 1u); }
+hipError_t launch_sky_dir_table(const ResolveParams& R, const SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream) {
     typedef Sky<ResolveParams> S;
     hipError_t e = hipMemsetAsync(err, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sky_dir_table_kernel, dim3((S::DT_NX * S::DT_NN + 255) / 256), dim3(256), 0, stream, R, tab);
-    hipLaunchKernelGGL(sky_dir_table_check_kernel, dim3(((S::DT_NX - 1) * (S::DT_NN - 1) + 255) / 256), dim3(256), 0, stream, R, tab, err);
+    const int variants = 2 * k + 1;
+    hipLaunchKernelGGL(sky_dir_table_kernel, dim3((variants * S::DT_NX * S::DT_NN + 255) / 256), dim3(256), 0, stream, R, view, tab);
+    hipLaunchKernelGGL(sky_dir_table_check_kernel, dim3((variants * (S::DT_NX - 1) * (S::DT_NN - 1) + 255) / 256), dim3(256), 0, stream, R, view, tab, err);
     return hipGetLastError();
 }
 
 // test hook (vpt_test_sky_samples): sample_atmosphere from the table's view point along n given directions
-__global__ void sky_samples_kernel(const ResolveParams R, const float* __restrict__ dirs, float* __restrict__ out, uint32_t n, int use_table) {
+__global__ void sky_samples_kernel(const ResolveParams R, const float* __restrict__ origins, const float* __restrict__ dirs, float* __restrict__ out, uint32_t n, int use_table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Sky<ResolveParams> sky = {R};
+    Sky<ResolveParams> sky = {R};
+    load_sky_view<true>(R, sky);
     const bool use_dir_tab = use_table && R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
-    const f3 v = sky.sample(mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]), mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]),
+    const f3 from = origins ? mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]) : mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]);
+    const f3 v = sky.sample(from, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]),
                             mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]), use_dir_tab);
     out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
 }
-hipError_t launch_sky_samples(const ResolveParams& R, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream) {
-    hipLaunchKernelGGL(sky_samples_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, dirs, out, n, use_table);
+hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_samples_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, origins, dirs, out, n, use_table);
     return hipGetLastError();
 }
 
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream) {
     const dim3 grid((R.n_pixels + 255u) / 256u), block(256);
-    if (R.heads) hipLaunchKernelGGL(tail_resolve_kernel<true>, grid, block, 0, stream, R);
-    else hipLaunchKernelGGL(tail_resolve_kernel<false>, grid, block, 0, stream, R);
+    const bool lens = R.lens_radius != 0.0f;             // the host builds k > 0 table variants exactly then
+    if (R.heads && lens) hipLaunchKernelGGL((tail_resolve_kernel<true, true>), grid, block, 0, stream, R);
+    else if (R.heads) hipLaunchKernelGGL((tail_resolve_kernel<true, false>), grid, block, 0, stream, R);
+    else if (lens) hipLaunchKernelGGL((tail_resolve_kernel<false, true>), grid, block, 0, stream, R);
+    else hipLaunchKernelGGL((tail_resolve_kernel<false, false>), grid, block, 0, stream, R);
     return hipGetLastError();
 }
 
