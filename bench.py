@@ -259,6 +259,17 @@ def main():
                            "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
                 "roofline": roofline,
             }
+            # per-frame sky tables of the environment tail: were ground tables in use, and their self-measured error
+            try:
+                import ctypes as C
+                lib = pkg.load_library()
+                lib.vpt_test_get_dir_table_error.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)]
+                built, err, cell = C.c_int(0), C.c_float(0), C.c_uint(0)
+                if lib.vpt_test_get_dir_table_error(hb.ctx.h, C.byref(built), C.byref(err), C.byref(cell)) == 0:
+                    out["config"]["sky_ground_table"] = {"built": bool(built.value), "max_relative_error_at_cell_centres": float(err.value),
+                                                         "accepted_below": 5e-4}
+            except Exception as e:                                    # reporting only
+                out["config"]["sky_ground_table"] = {"error": str(e)}
             if with_extras and not multi and not args.no_per_frame:
                 out["per_frame"] = per_frame(hb, sd, bn0, W, H)
             if with_extras and not multi and not args.no_cpu_baseline:
