@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             // path ends with L = 0, beta = 1, alpha = 0, depth = 0 and its primary ray -- exactly what a ray that misses the box
             // ends with.  27 % of config 2's traced rays are of this kind (the dragon fills a fraction of its padded bounding
             // box); their pushes are walked here, with the tracer's own operations, and they never enter the queue.
-            // ... and a ray that does reach a leaf keeps the position its pushes took it to: behind a closed lens the origin is a
-            // launch constant, so the record carries the advanced position in its place (flag + push count in the obj word) and the
-            // tracer's first walk starts there instead of repeating the pushes at its own lane occupancy.
+            // ... and a ray that does reach a leaf keeps the position its pushes took it to: the record of a box-first ray has three
+            // idle words (t_hit is only used to form the start position, depth is 0, t_box is the vol_integrator's), so it carries the
+            // advanced position in them (flag + push count in the obj word) and the tracer's first walk starts there instead of
+            // repeating the pushes at its own lane occupancy.
             f3 adv_pos = mk3(0.0f);
             uint32_t adv = 0u;
             if (traced && P.integrator == 0 && obj == 1 && !P.octree_full_single) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                         traced = false;
                         if (COUNT) n_empty_skips += 2u * pushes;                    // depth pass + integrator: the reference walks them twice
                     }
-                } else if (closed && pushes != 0u) {
+                } else if (pushes != 0u) {
                     adv_pos = pos;
                     adv = 0x80u | (pushes << 8);
                 }
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                 r3 = make_float4(dir0.x, dir0.y, dir0.z, 0.0f);
                 n_final++;
             } else {
-                r0 = adv ? make_float4(adv_pos.x, adv_pos.y, adv_pos.z, t_hit) : make_float4(org0.x, org0.y, org0.z, t_hit);
+                r0 = make_float4(org0.x, org0.y, org0.z, adv ? adv_pos.x : t_hit);
                 r1 = make_float4(dir0.x, dir0.y, dir0.z, __uint_as_float((uint32_t)obj | adv));
                 r2 = make_float4(__uint_as_float(rng.o0), __uint_as_float(rng.o1), __uint_as_float(rng.o2), __uint_as_float(rng.o3));
-                r3 = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), depth, t_box);
+                r3 = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), adv ? adv_pos.y : depth, adv ? adv_pos.z : t_box);
                 enqueue = true;
             }
             if (P.heads) {
@@ -349,11 +350,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
                         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-                        // obj word: bit 7 = q0.xyz is the position raygen's empty-node pushes reached (closed lens: the origin is the
-                        // camera's), bits 8.. = how many pushes that took
+                        // obj word: bit 7 = (q0.w, q3.z, q3.w) is the position raygen's empty-node pushes reached (a box-first ray:
+                        // depth 0, t_hit used up), bits 8.. = how many pushes that took
                         const uint32_t objw = __float_as_uint(q1.w);
                         const bool advanced = (objw & 0x80u) != 0u;
-                        const f3 origin = advanced ? ld3(P.cam.origin) + mk3(0.0f) : mk3(q0.x, q0.y, q0.z);
+                        const f3 origin = mk3(q0.x, q0.y, q0.z);
                         org0 = origin;
                         gco_t = q0.w;
                         dir0 = mk3(q1.x, q1.y, q1.z);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         rng.c0 = __float_as_uint(q3.x);
                         rng.idx = __float_as_uint(q3.y);
                         rng.carry = 0u; rng.has_carry = 0u;
-                        depth = q3.z;
+                        depth = advanced ? 0.0f : q3.z;
                         draws = rng.c0 * 4u + rng.idx - iteration * 4096u;
                         cam_draws_p = (int)draws;                    // draws consumed by camera::get_ray
                         // depth_calculator :1859-1889 and direct_integrator :1772-1785 start from the
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         cnt.n_d = cnt.n_c = cnt.n_e = cnt.n_steps = cnt.n_skips = 0;
                         if (gco_obj == 1) {
                             if (advanced) {
-                                w.pos = mk3(q0.x, q0.y, q0.z);
+                                w.pos = mk3(q0.w, q3.z, q3.w);
                                 if (COUNT) cnt.n_skips = objw >> 8;
                             } else {
                                 w.pos += w.dir * (gco_t + VPT_EPS);
