@@ -146,7 +146,7 @@ def _dir_table_error(pkg, hb):
     return built.value, err.value
 
 
-@pytest.mark.parametrize("view", ["c2", "low sun", "sunset", "20 km up"])
+@pytest.mark.parametrize("view", ["c2", "low sun", "sunset", "20 km up", "horizon in view"])
 def test_view_point_ground_table_matches_full_evaluation(pkg, sky, monkeypatch, view):
     """tail_resolve's view-point ground table (csrc/vpt_sky.h GroundNode: the ground radiance, transmittance and ground-point
     scattering of a ray that ends on the ground, tabulated over distance x nu for the frame's view point and sun) against the
@@ -159,6 +159,12 @@ def test_view_point_ground_table_matches_full_evaluation(pkg, sky, monkeypatch, 
         if view == "low sun": sd.kp.elevation = 3.0
         if view == "sunset": sd.kp.elevation = -1.0
         if view == "20 km up": sd.camera.origin.y += 20000.0
+        if view == "horizon in view":
+            # a level, wide view from 3 m above the ground: the horizon crosses the image, so the grazing rays the table leaves to
+            # the full path, the table's far end and the sky branch all take part
+            import ctypes as C
+            from vpt_amd.abi import Float3
+            pkg.load_library().vpt_camera_update(C.byref(sd.camera), Float3(40.0, 3.0, 5.0), Float3(0.0, 3.0, 0.0), Float3(0, 1, 0), 70.0, 160.0 / 90.0, 0.0)
         pkg.atmosphere.attach_default_atmosphere(sd, device=0)
         return sd
     sd = make()
