@@ -362,8 +362,8 @@ struct Sky {
     // cell CENTRE of the part that is used (the grazing end of the d range is left to the full path: there the reference's own
     // ground test flips between its binary32 and binary64 forms) in full and records the largest deviation of the bilinear
     // interpolant relative to the radiance there; the tail uses the table only while that figure is below
-    // ResolveParams::dir_tab_tol (5e-4; the image tolerance is 1e-3) and evaluates in full otherwise.  VALUE-ONLY like everything in this file: a cache of a pure function with a measured error
-    // bound, not a re-association.
+    // ResolveParams::dir_tab_tol (5e-4; the image tolerance is 1e-3) and evaluates in full otherwise.  VALUE-ONLY like
+    // everything in this file: a cache of a pure function with a measured error bound, not a re-association.
 #ifndef VPT_DT_NX
 #define VPT_DT_NX 512
 #define VPT_DT_NN 64
@@ -420,8 +420,9 @@ struct Sky {
     // scattering row of the ground point becomes a staircase of binary32 cancellation (r mu)^2 - r^2 + bottom^2 (following the
     // step in the transmittance alone, through a table of ratios over d, changed nothing: measured) -- up to 2 % of the radiance
     // within 2 degrees of the horizon, <= 0.8 % (1e-5 typically) below that from the camera origin, ~1 % for a few per cent of the
-    // origins on an open lens' disc.  The table is therefore used for rays at least ~2 degrees below the horizon only (d <= min(33 (r - bottom), 0.35 horizon distance): SkyView::tab[].z) and takes
-    // the ground point on the ground; returns false (evaluate in full) for everything else.
+    // origins on an open lens' disc.  The table is therefore used for rays at least ~2 degrees below the horizon only
+    // (d <= min(33 (r - bottom), 0.35 horizon distance): SkyView::tab[].z) and takes the ground point on the ground; returns
+    // false (evaluate in full) for everything else.
     VPT_D bool GroundFromTable(f3 p, float r, float mu_s, f3 pt, f3 sun_direction, int cv, f3& radiance) const {
         const f3 delta = pt - p;
         const float dist = length(delta);
