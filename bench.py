@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|sun|c1|c3|c4|c5|c3-sun|c5-sun] [--spp N]
                     [--scaling weak|strong] [--no-other-configs] [--no-cpu-baseline] [--no-per-frame]
+    python bench.py --gpus N                 (launches its own N ranks through torch.distributed.run) -- or, equivalently,
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one render of the named workload (default: BASELINE config 2 = dragon.vdb, 1920x1080, 64 spp, procedural
@@ -142,6 +143,20 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- the same command under torch.distributed.run, one rank per
+        # GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  exec: rank 0's JSON line is this
+        # process's stdout, the launcher's exit code is this command's.
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import numpy as np
     import torch
     import __graft_entry__ as ge
@@ -152,8 +167,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus N` plainly (it launches its own ranks) or "
+                         "under torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; VPT_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the
@@ -256,6 +271,10 @@ def main():
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": data,
                 "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp,
                            "parallelism": "iteration-striped x%d + 1 RCCL all-reduce under the C ABI" % world if world > 1 else "1 GPU",
+                           # what carried the reduce: the rank count read back from the context's RCCL communicator, or the
+                           # host-staged torch.distributed fallback (VPT_BENCH_BACKEND=gloo: ranks sharing one GPU)
+                           "collective": ({"backend": "rccl (vpt_allreduce_accum)", "comm_ranks": int(hb.ctx.comm_nranks)} if use_comm else
+                                          {"backend": backend + " (torch.distributed, host-staged)", "comm_ranks": world}) if multi else None,
                            "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
                 "roofline": roofline,
             }

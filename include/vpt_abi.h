@@ -251,6 +251,11 @@ int  vpt_texture_create(vpt_ctx *ctx, const vpt_texture_desc *desc, const float 
 int  vpt_texture_create_device(vpt_ctx *ctx, const vpt_texture_desc *desc,
                                const float *device_data, vpt_texture_t *out_tex);
 int  vpt_texture_destroy(vpt_ctx *ctx, vpt_texture_t tex);
+/* The renderer caches two per-frame sky tables (camera-point scattering table, view-point ground table) keyed on the camera
+ * origin, the sun direction, the model scalars and the device ADDRESSES of the four atmosphere tables.  Creating or destroying
+ * a texture and vpt_atmosphere_precompute drop that cache themselves; a host that rewrites the CONTENTS of an adopted device
+ * table in place (vpt_texture_create_device) calls this before its next render. */
+int  vpt_invalidate_sky_tables(vpt_ctx *ctx);
 
 /* ---- scene: instances + octree ---------------------------------------------------------
  * replaces: cuMemAlloc+HtoD of instances[] (source/main.cpp:1301-1303) and

@@ -32,6 +32,22 @@ def test_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["spp_per_gpu"] == 2 and d["value"] > 0
 
 
+def test_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a scaling run issues): bench.py re-executes itself under
+    torch.distributed.run, rank 0 prints ONE JSON line with n_gpus = 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VPT_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--width", "320", "--height", "180", "--spp", "4", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["spp_per_gpu"] == 2 and d["value"] > 0
+    assert d["config"]["collective"]["comm_ranks"] == 2
+
+
 def test_striped_ranks_equal_single_rank(pkg):
     """the image of 2 striped ranks + combine_means == 1 rank with twice the iterations"""
     import torch

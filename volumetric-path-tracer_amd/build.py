@@ -50,7 +50,8 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     experiments: select it at run time with VPT_LIB_PATH)."""
     global OBJ, OUT
     if variant:
-        OBJ = os.path.join(HERE, "_obj_" + variant)
+        # objects of a study build live outside the tree (nothing to clean up, nothing extra for gpurun to push)
+        OBJ = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vpt_obj_" + variant)
         OUT = os.path.join(HERE, "libvpt_hip_%s.so" % variant)
     os.makedirs(OBJ, exist_ok=True)
     common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]

@@ -393,6 +393,7 @@ extern "C" {
 // implemented in vpt_host.hip
 int vpt_texture_create_device(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* device_data, vpt_texture_t* out_tex);
 void* vpt_stream(vpt_ctx* ctx);
+int vpt_invalidate_sky_tables(vpt_ctx* ctx);
 
 int vpt_atmosphere_default_model(vpt_atmosphere_parameters* p) {
     if (!p) return VPT_E_INVALID;
@@ -621,6 +622,7 @@ int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int nu
     if (!ctx || !p) return VPT_E_INVALID;
     if (num_scattering_orders < 1) num_scattering_orders = 4;
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
+    vpt_invalidate_sky_tables(ctx);      // the per-frame sky tables are keyed on the buffers' addresses, which a re-run keeps
     const size_t n2t = (size_t)TW * TH, n2i = (size_t)IW * IH, n3 = (size_t)SW * SH * SD;
     float4** bufs2t[] = {(float4**)&p->transmittance_buffer};
     float4** bufs2i[] = {(float4**)&p->delta_irradience_buffer, (float4**)&p->irradiance_buffer};

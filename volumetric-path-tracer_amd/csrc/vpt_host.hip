@@ -122,6 +122,8 @@ struct vpt_ctx {
     float cam_tab_key[47] = {0};
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
     bool cam_tab_built = false;
+    hipEvent_t tab_event = nullptr;        // recorded behind the table kernels; a render on ANOTHER stream waits for it
+    hipStream_t tab_stream = nullptr;      // the stream the tables were built on
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
     // stats
     bool counting = false;
@@ -360,11 +362,24 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_lights);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->tab_event) (void)hipEventDestroy(ctx->tab_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// The per-frame sky tables (camera-point scattering table, view-point ground table) are cached on the view point, the sun, the
+// model scalars and the ADDRESSES of the four look-up tables -- not on the tables' contents.  Whatever can change those
+// contents behind an unchanged address drops the cache: every texture create / destroy (a re-upload of the same size
+// usually lands on the address just freed), vpt_atmosphere_precompute (it refills the buffers it is handed), and this
+// entry point for a host that rewrites a device table in place.
+int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
+    if (!ctx) return VPT_E_INVALID;
+    ctx->cam_tab_built = false;
+    ctx->dir_tab_built = false;
+    return VPT_OK;
+}
 
 int vpt_sync(vpt_ctx* ctx) {
     if (!ctx) return VPT_E_INVALID;
@@ -411,6 +426,7 @@ static int texture_add(vpt_ctx* ctx, const vpt_texture_desc* desc, const float* 
     }
     ctx->textures.push_back(te);
     *out = (vpt_texture_t)ctx->textures.size();
+    vpt_invalidate_sky_tables(ctx);
     return VPT_OK;
 }
 
@@ -429,6 +445,7 @@ int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
     }
     t.live = false;
     t.owned = nullptr;
+    vpt_invalidate_sky_tables(ctx);
     return VPT_OK;
 }
 
@@ -651,10 +668,6 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         // slot per LIST ENTRY, in list order: a candidate's matrix is read at the list position itself.
         std::vector<BoxD> domain(num_volumes);
         for (int v = 0; v < num_volumes; ++v) domain[v] = lookup_domain_bounds(volumes[v], bounds[v]);
-#ifdef VPT_EXPERIMENT_SUBLIST_AABB      // the round-1 behaviour (lists filtered with Bounds() only): shows that the shell test sees it
-        for (int v = 0; v < num_volumes; ++v)
-            domain[v] = BoxD{{bounds[v].lo.x, bounds[v].lo.y, bounds[v].lo.z}, {bounds[v].hi.x, bounds[v].hi.y, bounds[v].hi.z}};
-#endif
         std::vector<uint32_t> sub_offsets((size_t)512 * VPT_SUB3 + 1, 0);
         std::vector<uint32_t> sub_entries;
         for (int p3 = 0; p3 < 512; ++p3) {
@@ -1230,7 +1243,11 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         std::memcpy(key + 6, R.atm_f, sizeof(float) * 40);
         key[46] = (float)view_k;
         const void* tex[4] = {R.transmittance_tex.data, R.scattering_tex.data, R.irradiance_tex.data, R.single_mie_tex.data};
+        bool tables_written = false;
         if (!ctx->cam_tab_built || std::memcmp(key, ctx->cam_tab_key, sizeof(key)) != 0 || std::memcmp(tex, ctx->cam_tab_tex, sizeof(tex)) != 0) {
+            // a rebuild overwrites tables a render on the previous stream may still be reading
+            if (ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+            tables_written = true;
             HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_sky_view, ctx->d_cam_tab, view_k, stream));
             std::memcpy(ctx->cam_tab_key, key, sizeof(key));
             std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
@@ -1247,11 +1264,22 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             }
             R.dir_tab_tol = ctx->dir_tab_tol;
             if (!ctx->dir_tab_built) {
+                if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+                tables_written = true;
                 HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_sky_view, ctx->d_dir_tab, ctx->d_dir_err, view_k, stream));
                 ctx->dir_tab_built = true;
             }
             R.dir_tab = ctx->d_dir_tab;
             R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
+        }
+        // stream order: the tables are built on the stream of the render that needed them; a later render on another stream
+        // reuses them only behind the event recorded after that build
+        if (tables_written) {
+            if (!ctx->tab_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->tab_event, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventRecord(ctx->tab_event, stream));
+            ctx->tab_stream = stream;
+        } else if (ctx->tab_event && ctx->tab_stream != stream) {
+            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->tab_event, 0));
         }
     }
     ctx->last_resolve = R;

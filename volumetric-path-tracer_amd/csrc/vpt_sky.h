@@ -51,9 +51,6 @@ VPT_D f3 flerp3(f3 a, f3 b, float t) { return mk3(flerp(a.x, b.x, t), flerp(a.y,
 VPT_D f3 fscale_add3(f3 a, float s, f3 b) { return mk3(ffma(a.x, s, b.x), ffma(a.y, s, b.y), ffma(a.z, s, b.z)); }
 // texel fetch through a 32-bit BYTE offset (tables are <= 16 MiB): SGPR base + VGPR offset addressing
 VPT_D f3 ld_f3(const float4* __restrict__ p, uint32_t i) {
-#ifdef VPT_EXPERIMENT_TABLE_BROADCAST      // perf study only (wrong values): every lane reads texel (i & 7): how much of the tail is L1 gather traffic?
-    i &= 7u;
-#endif
     const uint32_t off = i << 4;
     const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + off);
     return mk3(v.x, v.y, v.z);

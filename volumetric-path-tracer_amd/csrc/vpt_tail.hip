@@ -111,13 +111,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
             }
         }
         if (from_record) {
-#ifdef VPT_EXPERIMENT_TAIL_NO_RECORDS      // perf study only (wrong image): how much of the tail is the latency of the record reads?
-            q0 = make_float4(0.1f, 0.1f, 0.1f, 0.5f); q1 = make_float4(0.5f, 0.5f, 0.5f, 1.0f);
-            q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(1u)); q3 = make_float4(h_next.y, h_next.z, h_next.x, 0.0f);
-#else
             const float4* rec = reinterpret_cast<const float4*>(R.records + slot);
             q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-#endif
         }
         f3 value = mk3(q0.x, q0.y, q0.z);
         float tr = q0.w;

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(HERE, "libvpt_hip.so")
 # every symbol include/vpt_abi.h declares
 ABI_SYMBOLS = [
     "vpt_create", "vpt_destroy", "vpt_last_error", "vpt_abi_version", "vpt_stream", "vpt_sync",
-    "vpt_texture_create", "vpt_texture_create_device", "vpt_texture_destroy",
+    "vpt_texture_create", "vpt_texture_create_device", "vpt_texture_destroy", "vpt_invalidate_sky_tables",
     "vpt_scene_set_volumes", "vpt_scene_get_root", "vpt_scene_get_octree_stats",
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
@@ -62,6 +62,7 @@ def load_library(path=None):
     lib.vpt_texture_create.argtypes = [vp, C.POINTER(TextureDesc), vp, C.POINTER(vpt_texture_t)]
     lib.vpt_texture_create_device.argtypes = [vp, C.POINTER(TextureDesc), vp, C.POINTER(vpt_texture_t)]
     lib.vpt_texture_destroy.argtypes = [vp, vpt_texture_t]
+    lib.vpt_invalidate_sky_tables.argtypes = [vp]
     lib.vpt_scene_set_volumes.argtypes = [vp, C.POINTER(GpuVdb), C.c_int]
     lib.vpt_scene_get_root.argtypes = [vp, C.POINTER(Float3), C.POINTER(Float3), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.vpt_scene_get_octree_stats.argtypes = [vp, C.POINTER(C.c_int * 3)]
