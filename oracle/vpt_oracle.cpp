@@ -1342,6 +1342,13 @@ int orc_render(const vpt_camera* cam, const vpt_light_list* lights, const vpt_gp
                const vpt_sphere* ref_sphere, const vpt_atmosphere_parameters* atmosphere,
                const vpt_kernel_params* kp_in, unsigned int iter_count, unsigned int iter_stride, int nthreads,
                orc_stats* stats) {
+    return orc_render_subset(cam, lights, volumes, num_volumes, ref_sphere, atmosphere, kp_in, iter_count, iter_stride, nthreads, 1u, stats);
+}
+
+int orc_render_subset(const vpt_camera* cam, const vpt_light_list* lights, const vpt_gpu_vdb* volumes, int num_volumes,
+                      const vpt_sphere* ref_sphere, const vpt_atmosphere_parameters* atmosphere,
+                      const vpt_kernel_params* kp_in, unsigned int iter_count, unsigned int iter_stride, int nthreads,
+                      unsigned int pixel_step, orc_stats* stats) {
     if (!cam || !lights || !volumes || num_volumes <= 0 || !ref_sphere || !atmosphere || !kp_in) return VPT_E_INVALID;
     if (iter_stride == 0) iter_stride = 1;
     // vol_integrator's tail is always sample_atmosphere (:1752), whatever environment_type says
@@ -1377,6 +1384,7 @@ int orc_render(const vpt_camera* cam, const vpt_light_list* lights, const vpt_gp
             for (int y = 0; y < H; ++y) {
                 for (int x = 0; x < W; ++x) {
                     const unsigned int idx = y * W + x;
+                    if (pixel_step > 1u && idx % pixel_step != 0u) continue;      // a lattice of the frame (bounded CPU samples of big frames)
                     PixelOut o = trace_pixel(c, *cam, x, y, bn.data());
                     c.st.samples++;
                     c.st.rng_draws += o.draws;

@@ -86,6 +86,14 @@ int orc_render(const vpt_camera *cam, const vpt_light_list *lights,
                const vpt_kernel_params *kp, unsigned int iter_count, unsigned int iter_stride,
                int nthreads, orc_stats *stats);
 
+/* the same for the pixels whose index y*W + x is a multiple of pixel_step only (every other pixel's buffers stay untouched):
+ * a bounded CPU sample of a big frame over MANY iterations (bench.py: parity of configs 3 and 5 across record chunks) */
+int orc_render_subset(const vpt_camera *cam, const vpt_light_list *lights,
+                      const vpt_gpu_vdb *volumes, int num_volumes,
+                      const vpt_sphere *ref_sphere, const vpt_atmosphere_parameters *atmosphere,
+                      const vpt_kernel_params *kp, unsigned int iter_count, unsigned int iter_stride,
+                      int nthreads, unsigned int pixel_step, orc_stats *stats);
+
 /* one pixel-sample, returning the integrator's value before accumulation (debugging
  * and per-sample parity tests): out = {L.x, L.y, L.z, tr, depth} */
 int orc_sample_pixel(const vpt_camera *cam, const vpt_light_list *lights,

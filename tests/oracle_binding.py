@@ -60,6 +60,7 @@ def load_oracle():
     render_args = [C.POINTER(abi.Camera), C.POINTER(abi.LightList), C.POINTER(abi.GpuVdb), C.c_int, C.POINTER(abi.Sphere),
                    C.POINTER(abi.AtmosphereParameters), C.POINTER(abi.KernelParams)]
     o.orc_render.argtypes = render_args + [C.c_uint, C.c_uint, C.c_int, C.POINTER(OrcStats)]
+    o.orc_render_subset.argtypes = render_args + [C.c_uint, C.c_uint, C.c_int, C.c_uint, C.POINTER(OrcStats)]
     o.orc_sample_pixel.argtypes = render_args + [C.c_int, C.c_int, C.POINTER(C.c_float * 5)]
     _orc = o
     return o
@@ -129,13 +130,15 @@ class OracleBinding:
         desc = abi.TextureDesc(dims[0], dims[1], dims[2], channels, int(normalized), int(linear), (C.c_int * 3)(*address))
         return self.o.orc_texture_create(C.byref(desc), _ptr(a))
 
-    def render(self, iter_count, iter_stride=1, iteration=None, nthreads=0):
+    def render(self, iter_count, iter_stride=1, iteration=None, nthreads=0, pixel_step=1):
+        """pixel_step > 1: only the pixels whose index is a multiple of it (orc_render_subset)"""
         if iteration is not None:
             self.kp.iteration = int(iteration)
         if nthreads <= 0:
             nthreads = os.cpu_count() or 1
-        rc = self.o.orc_render(C.byref(self.sd.camera), C.byref(self.lights), self.volumes, len(self.volumes), C.byref(self.sd.sphere),
-                               C.byref(self.atmosphere), C.byref(self.kp), int(iter_count), int(iter_stride), int(nthreads), C.byref(self.stats))
+        rc = self.o.orc_render_subset(C.byref(self.sd.camera), C.byref(self.lights), self.volumes, len(self.volumes), C.byref(self.sd.sphere),
+                                      C.byref(self.atmosphere), C.byref(self.kp), int(iter_count), int(iter_stride), int(nthreads), int(pixel_step),
+                                      C.byref(self.stats))
         if rc != 0:
             raise RuntimeError("orc_render -> %d" % rc)
         self.kp.iteration += int(iter_count) * int(iter_stride)

@@ -215,3 +215,40 @@ def test_striped_batches_spanning_chunks(pkg, monkeypatch):
     ob.render(5, iter_stride=3, iteration=1)
     assert rel_l2(a.accum.cpu().numpy(), ob.accum) <= 2e-6
     np.testing.assert_array_equal(a.blue_noise.cpu().numpy(), ob.blue_noise)
+
+
+@pytest.mark.parametrize("scene", ["dragon", "fireball", "instanced", "sphere_lights"])
+def test_pool_tracer_is_bit_identical_to_lane_tracer(pkg, monkeypatch, scene):
+    """VPT_TRACER=pool runs direct_integrator with the rays in an LDS pool per CU (csrc/vpt_trace_pool.hip: waves claim
+    phase-homogeneous batches of rays; measured slower than the lane-bound tracer, DESIGN 4.7, kept for A/B runs).  Same
+    per-ray operations in the same order: every buffer and every look-up / step / skip count must be bit-identical."""
+    def make():
+        if scene == "dragon":
+            return pkg.scene.dragon_scene(160, 90, "sun")
+        if scene == "fireball":
+            return pkg.scene.fireball_scene(96, 64, n=37)                 # emission march
+        if scene == "instanced":
+            return pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)    # colour grids, open lens (primary ray re-read)
+        sd = pkg.scene.dragon_scene(128, 72, "c1")                        # point light + the reference sphere in view
+        sd.kp.ray_depth = 3
+        sd.kp.volume_depth = 2
+        return sd
+    sd = make()
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.ctx.set_counting(True)
+    a.render(5); a.sync()
+    sa = a.ctx.stats()
+    monkeypatch.setenv("VPT_TRACER", "pool")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.ctx.set_counting(True)
+    b.render(5); b.sync()
+    sb = b.ctx.stats()
+    assert a.accum.abs().max() > 0
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())
+    for k in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+        assert getattr(sa, k) == getattr(sb, k), k
+    # non-counting instantiation too (13 rays per lane index instead of 12)
+    c = pkg.scene.HipBinding(sd, device=0)
+    c.render(5); c.sync()
+    np.testing.assert_array_equal(a.accum.cpu().numpy(), c.accum.cpu().numpy())

@@ -69,10 +69,13 @@ def test_config3_fireball_1080p_sun_and_sky(pkg):
     assert st.emission_lookups > 0
 
 
-def test_config4_cloud_half_size_grid_1080p(pkg):
+def _cloud_scene_1080p(pkg, shape):
+    """config 4's stand-in with a HOST copy of the (GPU-generated) grid, so that HIP and oracle render the same voxels"""
     import torch
-    shape = (608, 352, 512)
-    grid = pkg.scene.cloud_grid_torch(shape, device=torch.device("cuda", 0)).cpu().numpy()       # one grid for both sides
+    gdev = pkg.scene.cloud_grid_torch(shape, device=torch.device("cuda", 0))
+    grid = gdev.cpu().numpy()                          # one grid for both sides
+    del gdev
+    torch.cuda.empty_cache()
     S = pkg.scene
     sd = S.SceneDesc()
     sd.width, sd.height = 1920, 1080
@@ -88,9 +91,54 @@ def test_config4_cloud_half_size_grid_1080p(pkg):
     sd.env_map = S.hdri_map(2048, 1024)
     S._finish(sd)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    return sd, grid
+
+
+def test_config4_cloud_half_size_grid_1080p(pkg):
+    sd, grid = _cloud_scene_1080p(pkg, (608, 352, 512))
     assert grid.nbytes >= (8 << 20)                   # above VPT_RELAID_MIN_BYTES: the corner-quad layout is what runs
     e, st = _compare(pkg, sd, 1)
     assert st.tracking_steps > st.density_lookups      # vol_integrator's runs of empty sample() calls
+
+
+def test_config4_cloud_benchmark_size_grid_1080p(pkg, monkeypatch):
+    """The grid bench.py's config 4 renders, 1024x704x1216 (3.5 GB): its corner quads are 14 GB, addressed with byte offsets
+    far above 4 GiB (vpt_trace_common.h: fetch_f32_quads).  One iteration of the whole 1080p frame:
+      * corner quads vs the dense layout (VPT_GRID_LAYOUT=dense, 32-bit texel indices): every buffer and count bit-identical,
+      * against the oracle walking a host copy of the same grid: depth and alpha bit-identical, counts equal, accum <= 1e-3."""
+    import oracle_binding
+    sd, grid = _cloud_scene_1080p(pkg, (1216, 704, 1024))
+    assert grid.nbytes * 4 > (4 << 30)
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.ctx.set_counting(True)
+    a.render(1); a.sync()
+    sa = a.ctx.stats()
+    bufs = {k: getattr(a, k).cpu().numpy().copy() for k in ("accum", "depth", "raw", "display")}
+    a.ctx.close()
+    del a
+    monkeypatch.setenv("VPT_GRID_LAYOUT", "dense")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.ctx.set_counting(True)
+    b.render(1); b.sync()
+    sb = b.ctx.stats()
+    for k, v in bufs.items():
+        np.testing.assert_array_equal(v, getattr(b, k).cpu().numpy(), err_msg=k)
+    counts = ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays", "density_fetches")
+    for c in counts:
+        assert getattr(sa, c) == getattr(sb, c), c
+    b.ctx.close()
+    del b
+    ob = oracle_binding.OracleBinding(sd)
+    ob.render(1)
+    assert np.isfinite(bufs["accum"]).all() and ob.accum.max() > 0
+    np.testing.assert_array_equal(bufs["depth"], ob.depth)
+    np.testing.assert_array_equal(bufs["raw"][:, 3], ob.raw[:, 3])
+    assert sa.samples == ob.stats.samples == 1920 * 1080
+    for c in ("density_lookups", "tracking_steps", "skip_steps"):
+        assert getattr(sa, c) == getattr(ob.stats, c), (c, getattr(sa, c), getattr(ob.stats, c))
+    assert sa.tracking_steps > sa.density_lookups > 0
+    e = rel_l2(bufs["accum"], ob.accum)
+    assert e <= 1e-3, e
 
 
 def test_config5_100_instances_4k_dof_sun_and_sky(pkg):

@@ -116,6 +116,9 @@ struct Counters {
     unsigned long long fetches[4];
 };
 
+#ifndef VPT_CHUNK
+#define VPT_CHUNK 256        // queue entries a wave claims per global atomic (<= 256: a lane buffers 4 entries); TraceParams::chunk
+#endif
 #ifndef VPT_SUB
 #define VPT_SUB 4            // sub-cells per leaf and axis of the refined candidate lists (host builder and tracer agree on it)
 #endif
@@ -130,6 +133,7 @@ struct TraceParams {
     int render;
     uint32_t regen_min;              // refill when at least this many lanes of a wave are idle
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
+    uint32_t chunk;                  // queue entries a wave claims per global atomic: VPT_CHUNK, half of it for launches of a few iterations
     uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor
@@ -140,6 +144,7 @@ struct TraceParams {
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
     Counters* prof;                  // section cycle counters of -DVPT_PROFILE_SECTIONS builds (else unused)
+    float* pool_hist;                // pool tracer (vpt_trace_pool.hip): density histories of the fused first walk, [workgroup][entry][ray]
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera
     DCamera cam;

@@ -25,6 +25,9 @@
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
+hipError_t launch_trace_pool(const TraceParams& P, bool multi, bool color, bool emit, int blocks, int threads, hipStream_t stream);
+size_t trace_pool_hist_floats_per_block();
+bool trace_pool_supports(const TraceParams& P);
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
@@ -63,6 +66,11 @@ struct vpt_ctx {
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
     uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
+    // pool tracer (vpt_trace_pool.hip): direct_integrator with the rays in an LDS pool per CU
+    bool use_pool = false;         // VPT_TRACER=pool: measured slower than the lane-bound tracer, kept as the evidence and for A/B runs
+    int pool_waves = 12;           // VPT_POOL_WAVES: waves of the one workgroup per CU (8..12)
+    uint32_t pool_min_lanes = 40;  // VPT_POOL_MIN_LANES: fewest lanes a pass starts with while other waves still hold rays
+    float* d_pool_hist = nullptr;
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene
@@ -310,6 +318,9 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = ctx->trans_min_vol = (uint32_t)std::atoi(trm);
+    if (const char* e = std::getenv("VPT_TRACER")) ctx->use_pool = std::strcmp(e, "pool") == 0;
+    if (const char* e = std::getenv("VPT_POOL_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) ctx->pool_waves = v; }
+    if (const char* e = std::getenv("VPT_POOL_MIN_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->pool_min_lanes = (uint32_t)v; }
     if (const char* e = std::getenv("VPT_RELAID_MIN_BYTES")) ctx->relaid_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VPT_GRID_LAYOUT"))
         ctx->grid_layout = !std::strcmp(e, "dense") ? GRID_DENSE : !std::strcmp(e, "bricks") ? GRID_BRICKS : !std::strcmp(e, "quads") ? GRID_QUADS : -1;
@@ -356,6 +367,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_heads);
     (void)hipFree(ctx->d_head_org);
     (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_pool_hist);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);
@@ -1088,6 +1100,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
     P.prof = ctx->d_counters;
+    P.pool_hist = nullptr;
     P.vdc_tables = ctx->d_vdc;
     static_assert(sizeof(DCamera) == sizeof(vpt_camera), "camera layout");
     std::memcpy(&P.cam, cam, sizeof(DCamera));
@@ -1325,6 +1338,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             ev[i] = a;
             if (i + 1 < 5) ev[i + 1] = b;
         }
+        P.chunk = total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK;
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
@@ -1332,8 +1346,18 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         // with one volume, the vol tracer's non-generic variant
         const bool kernel_multi = kp->integrator != 0 ? (multi || color || emit) : multi;
         if (kernel_multi) P.octree_full_single = 0;
-        if (kp->integrator != 0) HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
-        else HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
+        if (kp->integrator != 0) {
+            HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
+        } else if (ctx->use_pool && trace_pool_supports(P)) {
+            // one workgroup per CU, each with its own pool of rays in LDS
+            if (!ctx->d_pool_hist) HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus));
+            P.pool_hist = ctx->d_pool_hist;
+            P.trans_min = ctx->pool_min_lanes;
+            const int pool_blocks = (int)std::min<unsigned long long>((total + 831) / 832, (unsigned long long)ctx->num_cus);
+            HIPCHK(ctx, launch_trace_pool(P, multi, color, emit, std::max(pool_blocks, 1), 64 * ctx->pool_waves, stream));
+        } else {
+            HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
         HIPCHK(ctx, launch_tail_resolve(R, stream));             // environment tail + resolve, fused
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));

@@ -27,18 +27,19 @@ struct LdsI {
     VPT_D void operator++(int) const { *p += 1; }
     VPT_D void operator--(int) const { *p -= 1; }
 };
-struct LdsF3 {
-    float* p;                                   // x at p[0], y at p[256], z at p[512]
-    VPT_D operator f3() const { return mk3(p[0], p[256], p[512]); }
-    VPT_D void operator=(f3 v) const { p[0] = v.x; p[256] = v.y; p[512] = v.z; }
-    VPT_D void operator+=(f3 v) const { p[0] += v.x; p[256] += v.y; p[512] += v.z; }
-    VPT_D void operator*=(f3 v) const { p[0] *= v.x; p[256] *= v.y; p[512] *= v.z; }
+template <int S>                                // S: floats between two fields of a column (threads of the block / rays of the pool)
+struct LdsF3S {
+    float* p;                                   // x at p[0], y at p[S], z at p[2 S]
+    VPT_D operator f3() const { return mk3(p[0], p[S], p[2 * S]); }
+    VPT_D void operator=(f3 v) const { p[0] = v.x; p[S] = v.y; p[2 * S] = v.z; }
+    VPT_D void operator+=(f3 v) const { p[0] += v.x; p[S] += v.y; p[2 * S] += v.z; }
+    VPT_D void operator*=(f3 v) const { p[0] *= v.x; p[S] *= v.y; p[2 * S] *= v.z; }
 };
+typedef LdsF3S<256> LdsF3;
 
 #ifndef VPT_HIST_CAP
 #define VPT_HIST_CAP 12
 #endif
-#define VPT_CHUNK 256        // queue entries a wave claims per global atomic
 
 VPT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
@@ -197,15 +198,17 @@ VPT_D void split_slot(const TraceParams& P, uint32_t slot, uint32_t& kiter, uint
 // ---- work distribution ---------------------------------------------------------------------------------
 // The compacted ray queue is in tile-major order (raygen_kernel); a wave claims VPT_CHUNK consecutive
 // entries with one leader atomic on a single global cursor, so the rays in flight across the whole GPU
-// always come from a few neighbouring tiles.  (Partitioning the queue per XCD -- blockIdx % 8, own L2
+// always come from a few neighbouring tiles.  P.chunk = VPT_CHUNK for batches; launches that give a wave fewer than ~6000
+// samples (the per-frame call: 600 k rays for 3072 waves) claim half as many at a time, so that every wave gets work and
+// the last chunks are shorter (per-frame tracer 0.215 -> 0.17 ms on config 2; profiles/r03_small_launch.txt).  (Partitioning the queue per XCD -- blockIdx % 8, own L2
 // -- with stealing was measured: load imbalance between image regions cost more than the L2 locality
 // gained, +4..6 % tracer time on configs 2-4.)
 VPT_D void claim_chunk(const TraceParams& P, uint32_t total, int lane, int leader, uint32_t& chunk_next, uint32_t& chunk_end, bool& more) {
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(P.work_counter, (uint32_t)VPT_CHUNK);
+    if (lane == leader) base = atomicAdd(P.work_counter, P.chunk);
     base = __shfl(base, leader);
     chunk_next = min(base, total);
-    chunk_end = min(base + (uint32_t)VPT_CHUNK, total);
+    chunk_end = min(base + P.chunk, total);
     if (chunk_end == total) more = false;
 }
 
