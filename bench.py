@@ -2,7 +2,7 @@
 """bench.py -- Msamples/s of the hot path (BASELINE.json metric) on N GPUs of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|sun|c1|c3|c4|c5|c3-sun|c5-sun] [--spp N]
-                    [--scaling weak|strong] [--no-other-configs] [--no-cpu-baseline] [--no-per-frame]
+                    [--scaling weak|strong] [--no-other-configs] [--no-cpu-baseline] [--no-per-frame] [--no-parity]
     python bench.py --gpus N                 (launches its own N ranks through torch.distributed.run) -- or, equivalently,
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
@@ -10,7 +10,8 @@ A "step" = one render of the named workload (default: BASELINE config 2 = dragon
 sun + sky): `spp` iterations of `volume_rt_kernel` per rank (raygen + trace + tail/resolve kernels, inputs resident in
 HBM).  The JSON line of rank 0 carries, next to the headline:
   roofline       of the headline's dominant kernel (the tracer) -- three labelled fractions, see `roofline_block`
-  other_configs  BASELINE configs 3, 4, 5 on their synthetic stand-ins at spec size, 2 steps each, N = 1 only
+  other_configs  BASELINE configs 3, 4, 5 on their synthetic stand-ins at spec size, 2 steps each, N = 1 only, each with
+                 its own parity evidence at that size (`parity`: oracle on a pixel lattice across two record chunks / layout A-B)
   per_frame      the literal drop-in call: one vpt_render (1 iteration) + device sync per frame, as main.cpp:1822-1829
   cpu_baseline   the reference's own kernel built for the host (oracle/_ref) or the oracle, on a bounded sample of the same
                  frame -- and the HIP image of the SAME iterations compared with it (`parity_rel_l2`)
@@ -115,13 +116,23 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator)
             ipl = max(1, min(64, spp, (16 << 30) // (W * H * 64)))      # iterations per tracer launch: the chunk rule of vpt_render_batch
             launches = -(-spp // ipl)
             r["traffic"] = round(per_sample * samples_per_step / launches / 1e9, 4)
-            r["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+            r["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s at commit %s)" % (tj.get("source", "?"), tj.get("commit", "?"))
             r["launches_per_step"] = launches
             if trace_s > 0:
                 r["hbm_measured_frac"] = round(per_sample * samples_per_step / trace_s / 1e9 / HBM_PEAK_GBS, 5)
-            vk = (tj.get("valu") or {}).get(kernel_name)
-            if vk:
-                r["valu"] = vk
+            # the bound that binds: vector-instruction issue at partial lane occupancy.  ONE number per kernel:
+            #   useful_lane_issue = (fraction of the SIMDs' issue cycles spent on VALU instructions, priced at the kernel's
+            #                        static instruction mix) x (active lanes per VALU instruction / 64)
+            # from the SQ counters of the same rocprofv3 passes (profiles/<source>, taken at `commit`)
+            kernels = {}
+            for kname, vk in (tj.get("valu") or {}).items():
+                if "valu_issue_busy_static_mix" in vk:
+                    e = dict(vk)
+                    e["useful_lane_issue"] = round(vk["valu_issue_busy_static_mix"] * vk["active_lanes_per_valu_instruction"] / 64.0, 3)
+                    kernels[kname] = e
+            if kernel_name in kernels:
+                r["valu"] = {"bound": "VALU issue x lane occupancy", "kernel": kernel_name, "useful_lane_issue": kernels[kernel_name]["useful_lane_issue"],
+                             "kernels": kernels, "source": "profiles/" + tj.get("source", "?"), "commit": tj.get("commit")}
     return r
 
 
@@ -139,6 +150,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-per-frame", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the per-config parity leg of other_configs")
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
     args = ap.parse_args()
@@ -285,10 +297,20 @@ def main():
                 lib.vpt_test_get_dir_table_error.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)]
                 built, err, cell = C.c_int(0), C.c_float(0), C.c_uint(0)
                 if lib.vpt_test_get_dir_table_error(hb.ctx.h, C.byref(built), C.byref(err), C.byref(cell)) == 0:
-                    out["config"]["sky_ground_table"] = {"built": bool(built.value), "max_relative_error_at_cell_centres": float(err.value),
-                                                         "accepted_below": 5e-4}
+                    chk = (C.c_float * 8)()
+                    lib.vpt_test_get_dir_table_check.argtypes = [C.c_void_p, C.POINTER(C.c_float * 8)]
+                    lib.vpt_test_get_dir_table_check(hb.ctx.h, C.byref(chk))
+                    out["config"]["sky_ground_table"] = {
+                        "built": bool(built.value), "in_use": bool(chk[4]),
+                        "interpolation_error_at_cell_centres": float(err.value), "interpolation_error_accepted_below": 5e-4,
+                        "variants_in_use": int(chk[5]),
+                        "vs_full_path_along_real_rays": {"rays_centre_variant": int(chk[2]), "max_relative_difference": float(chk[1]), "accepted_below": 2e-2,
+                                                         "fraction_above_1e-3": (float(chk[3]) / float(chk[2])) if chk[2] else None, "accepted_fraction": 0.02,
+                                                         "all_variants_max": float(chk[6]), "all_variants_largest_fraction_above_1e-3": float(chk[7])}}
             except Exception as e:                                    # reporting only
                 out["config"]["sky_ground_table"] = {"error": str(e)}
+            if not with_extras and not multi and not args.no_parity:
+                out["parity"] = config_parity(cfg, hb, sd, bn0, W, H, spp)
             if with_extras and not multi and not args.no_per_frame:
                 out["per_frame"] = per_frame(hb, sd, bn0, W, H)
             if with_extras and not multi and not args.no_cpu_baseline:
@@ -317,6 +339,56 @@ def main():
         return {"value": round(W * H * args.frames / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(dt / args.frames * 1e3, 4),
                 "frames": args.frames, "kernels_ms_last_frame": {"raygen": round(st.raygen_ms, 4), "trace": round(st.trace_ms, 4), "tail_resolve": round(st.tail_ms, 4)},
                 "call": "vpt_render (iter_count 1) + vpt_sync per frame, as source/main.cpp:1822-1829"}
+
+    def config_parity(cfg, hb, sd, bn0, W, H, spp):
+        """parity evidence of configs 3-5 AT THE SIZE THAT IS TIMED, carried in the bench line:
+        device-side grids (config 4): the corner-quad layout against a counted pass of the dense layout -- same counts, same bits;
+        host grids (configs 3, 5): two record chunks (a launch boundary at full size) against the oracle on a lattice of the frame"""
+        ipl = max(1, min(64, spp, (16 << 30) // (W * H * 64)))
+        host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)
+        counts = ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays", "density_fetches")
+        if not host_grids:
+            def counted(h):
+                h.ctx.set_counting(True)
+                h.blue_noise.copy_(bn0)
+                torch.cuda.synchronize(dev)
+                h.render(2, iteration=0)
+                h.sync()
+                return h.ctx.stats()
+            sa = counted(hb)
+            os.environ["VPT_GRID_LAYOUT"] = "dense"
+            try:
+                hd = pkg.scene.HipBinding(sd, device=local_rank)
+            finally:
+                del os.environ["VPT_GRID_LAYOUT"]
+            sb = counted(hd)
+            same_counts = all(getattr(sa, c) == getattr(sb, c) for c in counts)
+            same_bits = bool(torch.equal(hb.accum, hd.accum) and torch.equal(hb.depth, hd.depth))
+            hd.ctx.close()
+            hb.ctx.set_counting(False)
+            return {"kind": "layout", "iterations": 2, "counts_equal_dense_layout": same_counts, "buffers_bit_identical_dense_layout": same_bits,
+                    "note": "re-laid (corner-quad) density grid vs VPT_GRID_LAYOUT=dense on the same device grid; against the oracle: "
+                            "tests/test_gpu_fullsize.py::test_config4_cloud_benchmark_size_grid_1080p"}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding
+        step = {"c3": 17, "c5": 131}.get(cfg, 17)
+        iters = 2 * ipl
+        cores = os.cpu_count() or 1
+        ob = oracle_binding.OracleBinding(sd)
+        tc = time.perf_counter()
+        ob.render(iters, nthreads=cores, pixel_step=step)
+        dtc = time.perf_counter() - tc
+        hb.blue_noise.copy_(bn0)
+        torch.cuda.synchronize(dev)
+        hb.render(iters, iteration=0)
+        hb.sync()
+        got = hb.accum.cpu().numpy()[::step].astype(np.float64)
+        ref = ob.accum[::step].astype(np.float64)
+        rel = float(np.sqrt(((got - ref) ** 2).sum()) / max(1e-30, np.sqrt((ref ** 2).sum())))
+        dgot, dref = hb.depth.cpu().numpy()[::step], ob.depth[::step]
+        return {"kind": "oracle", "iterations": iters, "record_chunks": 2, "pixel_step": step, "pixels": int(got.shape[0]), "rel_l2": rel,
+                "depth_pixels_differing": int((dgot != dref).sum()), "tolerance": 1e-3, "cpu_seconds": round(dtc, 1),
+                "note": "HIP accum / depth after %d iterations (2 record chunks) vs the oracle on every %dth pixel of the %dx%d frame" % (iters, step, W, H)}
 
     def cpu_baseline(hb, sd, bn0, W, H, spp):
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)
@@ -357,7 +429,7 @@ def main():
             o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False)
             if o:
                 others.append({"config": o["config"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
-                               "warmup": o["warmup"], "data": o["data"], "roofline": o["roofline"]})
+                               "warmup": o["warmup"], "data": o["data"], "roofline": o["roofline"], "parity": o.get("parity")})
         if out is not None:
             out["other_configs"] = others
     if rank == 0 and out is not None:

@@ -246,8 +246,13 @@ int  vpt_sync(vpt_ctx *ctx);                      /* cudaDeviceSynchronize, main
  * (LayoutXYZ, gpu_vdb.cpp:179-212); it is copied to HBM. */
 int  vpt_texture_create(vpt_ctx *ctx, const vpt_texture_desc *desc, const float *data,
                         vpt_texture_t *out_tex);
-/* same, but `device_data` already lives in HBM and is adopted without a copy
- * (caller keeps ownership and must keep it alive) */
+/* same, but `device_data` already lives in HBM: no upload, the caller keeps ownership and must keep it alive.
+ * SNAPSHOT SEMANTICS for volume grids: vpt_scene_set_volumes re-lays every density / emission grid of 8 MiB or more into a
+ * float4 corner-quad copy owned by the context (4x the grid's bytes; DESIGN.md "Data layout in HBM") and renders from THAT copy.
+ * A host that rewrites such a grid in place (animated volumes, a tensor it keeps updating) calls vpt_scene_set_volumes again
+ * before the next render -- it rebuilds the copies -- or creates the context with VPT_GRID_LAYOUT=dense in the environment,
+ * which keeps rendering from the caller's memory at ~2x the look-up traffic.  Grids below 8 MiB, colour grids and the
+ * sky / environment tables are always read in place. */
 int  vpt_texture_create_device(vpt_ctx *ctx, const vpt_texture_desc *desc,
                                const float *device_data, vpt_texture_t *out_tex);
 int  vpt_texture_destroy(vpt_ctx *ctx, vpt_texture_t tex);
@@ -332,6 +337,10 @@ int  vpt_get_stats(vpt_ctx *ctx, vpt_render_stats *out);
  * with ONE RCCL all-reduce over xGMI (the image and the iteration count travel in one grouped call), enqueued on
  * `stream` (NULL = the context's stream) between a scale and a divide kernel -- no host synchronisation; a render
  * issued afterwards on the same stream is ordered behind it.  RCCL (librccl.so) is loaded on the first vpt_comm_* call.
+ * The reduce is TERMINAL for a progressive render: afterwards `accum` holds the JOB's mean, not this rank's -- a further
+ * vpt_render_batch into it would treat the job's mean as the rank's running mean, and a second reduce would count the other
+ * ranks twice.  To go on rendering, keep the rank-local mean in its own buffer and reduce a copy.  n_local_iterations x ranks
+ * must not exceed 2^24 (the count rides along as one binary32); a job in which every rank passes 0 leaves the buffers as they are.
  *   vpt_comm_unique_id: ncclGetUniqueId on ONE rank; the 128 bytes reach the other ranks by the host's own means
  *                       (MPI, a file, torch.distributed's store: see INTEGRATION.md).
  *   vpt_comm_init_rank: ncclCommInitRank for this context's device (collective: every rank calls it). */

@@ -37,10 +37,20 @@ int vpt_test_get_coherence(vpt_ctx *ctx, unsigned long long out[8]);
  * largest relative deviation of its bilinear interpolant from the full evaluation at the cell centres (the table is used while
  * err <= the tolerance, 5e-4 unless VPT_DIR_TABLE_TOL says otherwise), *cell = where: distance index * (DT_NN - 1) + nu index */
 int vpt_test_get_dir_table_error(vpt_ctx *ctx, int *built, float *err, unsigned int *cell);
+/* the whole build-time check of that table: out[0] = the interpolation error above; out[1] = the largest relative difference
+ * between the table path and the FULL path (the reference's arithmetic) of sample_atmosphere along real view rays from the
+ * camera origin, one per reachable cell centre; out[2] = rays compared; out[3] = rays that differ by more than 1e-3;
+ * out[4] = 1 when the tail uses the tables (out[0] <= tolerance and at least one variant passed: worst ray <= 2e-2, at most 2 % of
+ * its rays off by more than 1e-3 -- a variant that fails loses its table); out[5] = variants in use (1 behind a closed lens, up to
+ * 2 k + 1 behind an open one); out[6], out[7] = the worst ray and the largest share of rays above 1e-3 over ALL checked variants */
+int vpt_test_get_dir_table_check(vpt_ctx *ctx, float out[8]);
 /* sample_atmosphere (render_kernel.cu:839-895) as the environment tail of the last render evaluates it, along n unit directions
  * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
  * hits through the view-point ground tables (when the last render had them within tolerance), else in full */
 int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float *dirs, int use_table, float *out);
+/* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
+ * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */
+int vpt_io_test_blosc_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t nbytes_out);
 #ifdef __cplusplus
 }
 #endif

@@ -218,7 +218,9 @@ def test_ground_table_per_direction(pkg, sky):
     """the same comparison per DIRECTION (vpt_test_sky_samples: sample_atmosphere from the view point of the last render): over the
     lower hemisphere, log-uniform in the angle below the horizontal, the table path equals the full path bit for bit where the table is
     not used (grazing rays, within ~2 degrees of the horizon) and agrees to 1e-4 for 99 % of the steeper directions; the rest are
-    the ground points whose binary32 radius the full path finds one step above the ground (vpt_sky.h): below 1 %"""
+    the ground points whose binary32 radius the full path finds one step above the ground (vpt_sky.h): under 1 % of them differ by
+    more than 1e-3, none by more than 1e-2 -- the same figures the table's build-time check measures along its own real rays and
+    gates the table on (sky_dir_table_rays_kernel: worst ray <= 2e-2, at most 2 % above 1e-3)"""
     import ctypes as C
     lib = pkg.load_library()
     lib.vpt_test_sky_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -244,8 +246,16 @@ def test_ground_table_per_direction(pkg, sky):
     steep = el < -0.05
     assert (rel[grazing] == 0).all()
     assert (rel[steep] > 0).mean() > 0.3                      # the table is what evaluated them
-    assert np.quantile(rel[steep], 0.99) <= 1e-4 or np.quantile(rel[steep], 0.97) <= 1e-4, np.quantile(rel[steep], [0.5, 0.97, 0.99])
+    # measured (profiles/r03_sky_error_probe.txt): median 3e-6, 99th percentile 5e-5, 0.7 % of the steep directions above 1e-3, worst 7e-3
+    assert np.quantile(rel[steep], 0.99) <= 1e-4, np.quantile(rel[steep], [0.5, 0.97, 0.99])
+    assert (rel[steep] > 1e-3).mean() <= 0.02, (rel[steep] > 1e-3).mean()                 # the build-time gate's own bound (vpt_tail.hip)
     assert rel.max() <= 1e-2, rel.max()
+    # ... and the table's build-time check saw the same: real rays through both paths, worst ray and share above 1e-3 within the gate
+    chk = (C.c_float * 8)()
+    lib.vpt_test_get_dir_table_check.argtypes = [C.c_void_p, C.POINTER(C.c_float * 8)]
+    assert lib.vpt_test_get_dir_table_check(hb.ctx.h, C.byref(chk)) == 0
+    assert chk[4] == 1.0 and chk[5] == 1.0 and chk[2] > 5000
+    assert 0.0 < chk[1] <= 2e-2 and chk[3] <= 0.02 * chk[2], list(chk)
 
 
 def test_ground_table_with_a_luminance_sky_model(pkg, monkeypatch):
@@ -268,3 +278,65 @@ def test_ground_table_with_a_luminance_sky_model(pkg, monkeypatch):
     ob = oracle_binding.OracleBinding(sd)
     ob.render(4)
     assert rel_l2(a, ob.accum) <= 1e-3 and rel_l2(b, ob.accum) <= 1e-3, (rel_l2(a, ob.accum), rel_l2(b, ob.accum))
+
+
+def test_per_frame_sky_tables_follow_the_lut_contents(pkg):
+    """The camera-point and ground tables of the environment tail are cached on the view point, the sun, the model SCALARS and the
+    ADDRESSES of the four atmosphere tables (round-2 advisor finding: not on their contents).  Two skies with identical scalars and
+    different tables (ozone on / off changes only the absorption profile, which is not among the packed scalars):
+      * tables re-uploaded through destroy + create (the new allocation usually lands on the address just freed): the cache is
+        dropped by the texture calls themselves;
+      * a device table the host owns, rewritten IN PLACE: vpt_invalidate_sky_tables.
+    Either way the next render must equal a fresh context's, bit for bit."""
+    import torch
+    from vpt_amd import abi
+    wc = (abi.ADDR_WRAP, abi.ADDR_CLAMP, abi.ADDR_CLAMP)
+    sd = pkg.scene.dragon_scene(128, 72, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    sb = pkg.scene.dragon_scene(128, 72, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sb, device=0, use_ozone=0)
+    la, lb = sd.atm_luts, sb.atm_luts
+    assert not np.array_equal(la["scattering"], lb["scattering"])
+    # reference: a fresh context with A's scalars and B's tables
+    sc = pkg.scene.dragon_scene(128, 72, "c2")
+    sc.atmosphere = abi.AtmosphereParameters.from_buffer_copy(sd.atmosphere)
+    sc.atm_luts = lb
+    hc = pkg.scene.HipBinding(sc, device=0)
+    hc.render(2, iteration=0); hc.sync()
+    want = hc.accum.cpu().numpy()
+
+    def bind(hb, make):
+        hb.atmosphere.transmittance_texture = make("transmittance", wc)
+        hb.atmosphere.irradiance_texture = make("irradiance", wc)
+        hb.atmosphere.scattering_texture = make("scattering", (abi.ADDR_CLAMP,) * 3)
+        hb.atmosphere.single_mie_scattering_texture = make("single_mie", (abi.ADDR_CLAMP,) * 3)
+
+    # (1) destroy + create
+    hb = pkg.scene.HipBinding(sd, device=0)
+    bn0 = hb.blue_noise.clone()
+    hb.render(2, iteration=0); hb.sync()
+    first = hb.accum.cpu().numpy().copy()
+    assert not np.array_equal(first, want)
+    for t in (hb.atmosphere.transmittance_texture, hb.atmosphere.irradiance_texture, hb.atmosphere.scattering_texture,
+              hb.atmosphere.single_mie_scattering_texture):
+        assert hb.ctx.lib.vpt_texture_destroy(hb.ctx.h, t) == 0
+    bind(hb, lambda name, addr: hb.ctx.texture(lb[name], 4, address=addr))
+    hb.blue_noise.copy_(bn0); torch.cuda.synchronize()
+    hb.render(2, iteration=0); hb.sync()
+    np.testing.assert_array_equal(hb.accum.cpu().numpy(), want)
+
+    # (2) device tables rewritten in place
+    dev = {k: torch.from_numpy(la[k].copy()).to("cuda:0") for k in la}
+    hd = pkg.scene.HipBinding(sd, device=0)
+    dims = {"transmittance": (256, 64, 1), "irradiance": (256, 64, 1), "scattering": (256, 128, 32), "single_mie": (256, 128, 32)}
+    bind(hd, lambda name, addr: hd.ctx.texture_device(dev[name], dims[name], 4, address=addr))
+    torch.cuda.synchronize()
+    hd.render(2, iteration=0); hd.sync()
+    np.testing.assert_array_equal(hd.accum.cpu().numpy(), first)
+    for k in dev:
+        dev[k].copy_(torch.from_numpy(lb[k]))
+    torch.cuda.synchronize()
+    assert hd.ctx.lib.vpt_invalidate_sky_tables(hd.ctx.h) == 0
+    hd.blue_noise.copy_(bn0); torch.cuda.synchronize()
+    hd.render(2, iteration=0); hd.sync()
+    np.testing.assert_array_equal(hd.accum.cpu().numpy(), want)

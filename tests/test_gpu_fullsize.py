@@ -23,7 +23,15 @@ def rel_l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((b ** 2).sum())))
 
 
-def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False):
+def _per_pixel(got, ref):
+    """relative error per pixel (largest channel difference over the pixel's brightest channel), over the pixels above 1e-3"""
+    a = np.asarray(got, np.float64); b = np.asarray(ref, np.float64)
+    lum = b.max(1)
+    m = lum > 1e-3
+    return np.abs(a - b).max(1)[m] / lum[m]
+
+
+def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=1e-3, worst=1e-2):
     import oracle_binding
     hb = pkg.scene.HipBinding(sd, device=0)
     ob = oracle_binding.OracleBinding(sd)
@@ -42,6 +50,16 @@ def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False):
     np.testing.assert_array_equal(hb.raw.cpu().numpy()[:, 3], ob.raw[:, 3])               # alpha of the last iteration, bit for bit
     e = rel_l2(got, ob.accum)
     assert e <= tol, e
+    # ... and per PIXEL, not only per image: the value-only sky code (approximate divide / root, fp32 weights, the per-frame tables)
+    # against the oracle's strict arithmetic.  Measured on one iteration (profiles/r03_sky_error_probe.txt): config 2 median 7e-6,
+    # 99th percentile 6e-4, worst pixel 7e-3 (the same with the ground table switched off: the outliers are ground points whose
+    # binary32 radius flips between the two arithmetics, not the table); config 3 6e-4 / 2e-3; config 5 (open lens: table variants)
+    # 3.7e-3 / 5.2e-3 -- 7e-4 / 5.2e-3 without its ground tables.
+    rel = _per_pixel(got, ob.accum)
+    assert rel.size > 0.5 * got.shape[0] or ob.accum.max(1).mean() < 1e-3
+    if rel.size:
+        assert np.quantile(rel, 0.99) <= p99, np.quantile(rel, [0.5, 0.99, 0.999])
+        assert rel.max() <= worst, rel.max()
     if not per_frame:                                # a per-frame sequence reports the counts of its last launch only
         assert st.samples == ob.stats.samples == sd.width * sd.height * iterations
         for c in ("density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps"):
@@ -144,5 +162,5 @@ def test_config4_cloud_benchmark_size_grid_1080p(pkg, monkeypatch):
 def test_config5_100_instances_4k_dof_sun_and_sky(pkg):
     sd = pkg.scene.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0, sky=True)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    e, st = _compare(pkg, sd, 1)
+    e, st = _compare(pkg, sd, 1, p99=5e-3)                  # the open lens' ground-table variants: see _compare
     assert st.color_lookups > 0 and st.density_lookups > 2 * st.tracking_steps       # several instances per leaf and step

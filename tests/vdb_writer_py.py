@@ -109,7 +109,8 @@ def write_vdb(path, grids):
     for g in grids:
         ncomp = 3 if g["type"] == "vec3s" else 1
         half = bool(g.get("half", False))
-        meta = {"class": ("string", b"fog volume"), "is_saved_as_half_float": ("bool", b"\x01" if half else b"\x00")}
+        meta_half = bool(g.get("meta_half", half))               # (tests can make the metadatum contradict the descriptor suffix)
+        meta = {"class": ("string", b"fog volume"), "is_saved_as_half_float": ("bool", b"\x01" if meta_half else b"\x00")}
         a, b = _grid_bytes(g["leaves"], g.get("tiles3", {}), ncomp, g.get("background", 0.0), g.get("flags", 0),
                            g.get("map_type", "UniformScaleMap"), g["map_values"], meta, half)
         blobs.append((g, a, b))

@@ -49,7 +49,7 @@ out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 d = json.load(open(out_path)) if os.path.exists(out_path) else {}
 d[cfg] = {"width": w, "height": h, "iterations_per_launch": ipl, "samples_per_launch": w * h * ipl,
           "fetch_size_counter": fetch, "write_size_counter": write, "bytes_per_launch": bytes_per_launch,
-          "source": os.path.basename(path)}
+          "source": os.path.basename(path), "commit": os.environ.get("COMMIT", "unknown")}
 
 # VALU issue utilisation of the hot kernels from the same file's SQ passes.  A wave64 VALU instruction occupies its SIMD's issue
 # port for 2.2-2.5 cycles (fma / add / mul / mov / and / xor ...), 4.1-4.2 cycles (min / max / cvt / floor / shifts / mul24 /

@@ -16,8 +16,10 @@ run() {  # name, rocprof flags...
   find /tmp/rp_$name -name "*.db" | head -1
 }
 DB=$(run kt --kernel-trace --stats)
-[ -n "$DB" ] && python $REPO/profiles/summarize_rocprof.py kernel $DB > $OUT/${TAG}_kernel_trace.txt 2>&1
-: > $OUT/${TAG}_pmc.txt
+# every summary names the commit it was taken at (COMMIT: passed in by the caller, the GPU box has no .git)
+echo "# commit ${COMMIT:-unknown}; command: rocprofv3 --kernel-trace --stats -- python bench.py $ARGS" > $OUT/${TAG}_kernel_trace.txt
+[ -n "$DB" ] && python $REPO/profiles/summarize_rocprof.py kernel $DB >> $OUT/${TAG}_kernel_trace.txt 2>&1
+echo "# commit ${COMMIT:-unknown}; command: rocprofv3 --pmc <set> -- python bench.py $ARGS (one pass per set)" > $OUT/${TAG}_pmc.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do

@@ -25,6 +25,7 @@ enum { GRID_DENSE = 0, GRID_BRICKS = 1, GRID_QUADS = 2 };
 
 // view point of the environment tail's per-frame tables (vpt_sky.h), device-resident
 enum { SKY_VIEW_MAX_K = 4 };
+enum { SKY_DIR_ERR_WORDS = 8 + 4 * (2 * SKY_VIEW_MAX_K + 1) };   // u64 words of the ground table's build-time check (vpt_tail.hip: launch_sky_dir_table)
 struct SkyView {
     float r, mu_s;         // of the camera origin, with the tail's own arithmetic
     int k;                 // variants: r + (-k .. k) binary32 steps
@@ -247,7 +248,9 @@ struct ResolveParams {
     // {A.xyz, B.xyz} over [distance to the ground DT_NX][nu DT_NN]; NULL: evaluate every ground hit in full.  dir_tab_err:
     // device word, float bits of the largest relative mid-cell interpolation error found when the table was built
     const float4* dir_tab;
-    const uint32_t* dir_tab_err;      // [0] cell of the largest error, [1] its float bits
+    const uint32_t* dir_tab_err;      // u64 words [SKY_DIR_ERR_WORDS] seen as u32: [0] cell of the largest interpolation error, [1] its float bits,
+                                      // [2..7] the centre variant against real rays through the full path (max, rays, rays off by > 1e-3), [8] verdict,
+                                      // [10] variants in use; from u64 word 8: per variant {max | cell, rays, rays off by > 1e-3, -}
     float dir_tab_tol;
     // Both tables exist in 2k+1 VARIANTS, one per binary32 value of the view point's radius r within k steps of the camera's:
     // with an open lens every sample starts on the lens disc, whose height above the ground spans a few binary32 steps of r

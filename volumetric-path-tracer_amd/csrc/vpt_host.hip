@@ -34,7 +34,7 @@ hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_sky_cam_table(const ResolveParams& R, SkyView* view, float4* out, int k, hipStream_t stream);
 size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
-hipError_t launch_sky_dir_table(const ResolveParams& R, const SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
+hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
@@ -821,6 +821,37 @@ int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned 
     return VPT_OK;
 }
 
+int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    for (int i = 0; i < 8; ++i) out[i] = 0.0f;
+    if (!ctx->dir_tab_built) return VPT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    unsigned long long w[SKY_DIR_ERR_WORDS] = {0};
+    HIPCHK(ctx, hipMemcpy(w, ctx->d_dir_err, sizeof(w), hipMemcpyDeviceToHost));
+    const uint32_t a = (uint32_t)(w[0] >> 32), b = (uint32_t)(w[1] >> 32);
+    std::memcpy(&out[0], &a, sizeof(float));
+    std::memcpy(&out[1], &b, sizeof(float));
+    out[2] = (float)w[2];
+    out[3] = (float)w[3];
+    out[4] = (float)w[4];
+    out[5] = (float)w[5];
+    // over the variants that had a table to check: worst ray, and the largest share of rays off by more than 1e-3
+    float worst = 0.0f, share = 0.0f;
+    for (int v = 0; v < 2 * SKY_VIEW_MAX_K + 1; ++v) {
+        const unsigned long long* e = w + 8 + 4 * v;
+        if (e[1] == 0ull) continue;
+        const uint32_t bb = (uint32_t)(e[0] >> 32);
+        float f;
+        std::memcpy(&f, &bb, sizeof(float));
+        worst = std::max(worst, f);
+        share = std::max(share, (float)((double)e[2] / (double)e[1]));
+    }
+    out[6] = worst;
+    out[7] = share;
+    return VPT_OK;
+}
+
 int vpt_test_sky_samples(vpt_ctx* ctx, int n, const float* origins, const float* dirs, int use_table, float* out) {
     if (!ctx || n <= 0 || !dirs || !out) return VPT_E_INVALID;
     if (!ctx->have_last_resolve || !ctx->last_resolve.has_atmosphere || !ctx->last_resolve.cam_tab_valid) {
@@ -909,7 +940,8 @@ __global__ void comm_scale_kernel(float* __restrict__ accum, size_t n_floats, fl
 // accum[i] /= count[0] (IEEE divide: this file is built strict)
 __global__ void comm_divide_kernel(float* __restrict__ accum, size_t n_floats, const float* __restrict__ count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_floats) accum[i] = accum[i] / count[0];
+    // (a job in which no rank rendered anything: the buffers hold zeros times zero -- leave them, do not divide by zero)
+    if (i < n_floats && count[0] > 0.0f) accum[i] = accum[i] / count[0];
 }
 }  // namespace
 
@@ -957,6 +989,15 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     if (!ctx->comm) {
         set_error(ctx, "vpt_allreduce_accum: no communicator (vpt_comm_init_rank)");
         return VPT_E_NOT_READY;
+    }
+    // the iteration count travels as one binary32 next to the image: exact up to 2^24 per rank and for the job's sum
+    if (n_local_iterations > (1u << 24) / (unsigned)std::max(1, ctx->comm_nranks)) {
+        set_error(ctx, "vpt_allreduce_accum: %u iterations per rank x %d ranks exceeds the 2^24 the binary32 count carries exactly", n_local_iterations, ctx->comm_nranks);
+        return VPT_E_INVALID;
+    }
+    if ((n_floats + 255ull) / 256ull > 0x7fffffffull) {
+        set_error(ctx, "vpt_allreduce_accum: %llu floats is more than one launch covers", n_floats);
+        return VPT_E_INVALID;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
@@ -1273,9 +1314,11 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (!ctx->no_dir_table && kp->integrator == 0 && kp->environment_type == 0) {
             if (!ctx->d_dir_tab) {
                 HIPCHK(ctx, hipMalloc(&ctx->d_dir_tab, sky_dir_table_bytes()));
-                HIPCHK(ctx, hipMalloc(&ctx->d_dir_err, sizeof(unsigned long long)));
+                HIPCHK(ctx, hipMalloc(&ctx->d_dir_err, SKY_DIR_ERR_WORDS * sizeof(unsigned long long)));
             }
             R.dir_tab_tol = ctx->dir_tab_tol;
+            R.dir_tab = ctx->d_dir_tab;                  // (before the build: its check evaluates real rays through the table path)
+            R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
             if (!ctx->dir_tab_built) {
                 if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
                 tables_written = true;

@@ -395,7 +395,17 @@ void read_grid(Reader& r, Grid& g, int64_t grid_pos, int64_t block_pos, int64_t 
     for (uint32_t i = 0; i < meta_count; ++i) {
         const std::string mname = r.str();
         const std::string mtype = r.str();
-        (void)mname; (void)mtype;
+        if (mname == "is_saved_as_half_float" && mtype == "bool") {
+            // OpenVDB writes this metadatum and the descriptor suffix from the same flag (GridBase::saveFloatAsHalf); a file where
+            // they disagree would be decoded with the wrong value width and fail far away ("did not parse to its end offset")
+            const uint32_t size = r.get<uint32_t>();
+            const uint8_t* v = r.take(size);
+            const bool meta_half = size >= 1 && v[0] != 0;
+            if (meta_half != half)
+                throw ParseError("vdb: grid '" + g.name + "': descriptor type " + g.type + (half ? " says" : " does not say") +
+                                 " half-float values but its is_saved_as_half_float metadatum says " + (meta_half ? "true" : "false"));
+            continue;
+        }
         skip_meta_value(r);
     }
     read_transform(r, g);
@@ -500,7 +510,7 @@ extern "C" {
 
 const char* vpt_io_last_error(void) { return g_io_error.c_str(); }
 
-// test probe (not in include/vpt_io.h): one c-blosc chunk through the decoder; 0 on success, VPT_E_IO on a ParseError
+// test probe (include/vpt_testhooks.h): one c-blosc chunk through the decoder; 0 on success, VPT_E_IO on a ParseError
 int vpt_io_test_blosc_decode(const unsigned char* src, size_t n, unsigned char* dst, size_t nbytes_out) {
     try {
         blosc_decode(src, n, dst, nbytes_out);

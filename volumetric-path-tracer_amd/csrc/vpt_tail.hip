@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
     Sky<ResolveParams> sky = {R};
     load_sky_view<LENS>(R, sky);
-    // the ground table is used only while its measured interpolation error is within the tolerance (vpt_sky.h)
-    const bool use_dir_tab = R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
+    // the ground table is used only while it passed its build-time checks: interpolation error within the tolerance AND real rays
+    // through the full path agreeing (sky_dir_table_verdict_kernel)
+    const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
 
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
@@ -275,15 +276,104 @@ __global__ void sky_dir_table_check_kernel(const ResolveParams R, const SkyView*
     const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;
     if (bits != 0u) atomicMax(err, ((unsigned long long)bits << 32) | c);             // high word: the error; low word: where
 }
+// ... and against the path it replaces: for every reachable cell centre of every variant a real view ray with that distance to the
+// ground and that nu -- from the camera origin, displaced along the vertical by the variant's binary32 steps of r (and, behind an
+// open lens, horizontally within the lens radius) -- is evaluated
+// twice through sample_atmosphere: in full (the reference's arithmetic: binary32 ground point, its radius as the reference finds
+// it) and through the table; the two tone-curved radiances the tail would add to L are compared.  Per variant v, at err[8 + 4 v]:
+// largest relative difference (high word) and its cell, rays compared, rays off by more than 1e-3.  The interpolation check above
+// cannot see what this one sees: the rays whose binary32 ground point lies one step (0.5 m) above the ground (vpt_sky.h,
+// GroundFromTable) -- more of them from the off-centre origins of an open lens.
+template <bool LENS>
+__global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* view, unsigned long long* err) {
+    typedef Sky<ResolveParams> S;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cells = (uint32_t)((S::DT_NX - 1) * (S::DT_NN - 1));
+    const uint32_t variant = t / cells, c = t % cells;
+    const int k = view->k;
+    if (variant > 2u * (uint32_t)k) return;
+    S sky = {R};
+    load_sky_view<LENS>(R, sky);
+    const uint32_t ix = c / (uint32_t)(S::DT_NN - 1), in = c % (uint32_t)(S::DT_NN - 1);
+    const float x = ((float)ix + 0.5f) * (1.0f / (float)(S::DT_NX - 1)), nu = -1.0f + ((float)in + 0.5f) * (2.0f / (float)(S::DT_NN - 1));
+    const f3 cam = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]);
+    const f3 sun = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const f3 ec = mk3(0.0f, -sky.bottom(), 0.0f);
+    const f3 up0 = normalize(cam - ec);
+    // the origin: `variant - k` binary32 steps of r above / below the camera origin (which variant that lands on is the tail's own
+    // decision, below)
+    const float dr = __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)k) - view->r;
+    f3 pos = cam + up0 * dr;
+    if (LENS) {
+        // ... and, like the samples behind an open lens, somewhere within a lens radius of it horizontally (a fixed pseudo-random
+        // point per cell): the binary32 rounding of the ground point depends on where exactly the origin sits
+        const uint32_t h = (t * 2654435761u) ^ (t >> 13) * 40503u;
+        const float th = (float)(h & 0xffffu) * (6.2831853f / 65536.0f), rho = fsqrt((float)(h >> 16) * (1.0f / 65536.0f)) * fabsf(R.lens_radius);
+        const f3 t1 = normalize(cross(up0, fabsf(up0.x) < 0.9f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f))), t2 = cross(up0, t1);
+        pos = pos + (t1 * __builtin_cosf(th) + t2 * __builtin_sinf(th)) * rho;
+    }
+    const f3 p = pos - ec;
+    const float r = length(p);
+    int cv = 0;
+    if (LENS) {
+        cv = sky.CamVariant(r, dot(p, sun) * frcp(r));
+        if (cv < 0) return;
+    } else if (variant != 0u) {
+        return;
+    }
+    if (view->tab[cv].w == 0.0f || x > view->tab[cv].z) return;                                // no table / beyond the part that is used
+    const f3 up = p * frcp(r);
+    const float mu_s = dot(up, sun);
+    const float b = sky.bottom();
+    const float h2 = (r - b) * (r + b), d_min = r - b, d = d_min * __builtin_amdgcn_exp2f(x * __builtin_amdgcn_logf(fdiv(fsqrt(fmax_(h2, 0.0f)), d_min)));
+    const float mu = clampf(fdiv(-(h2 + d * d), 2.0f * r * d), -1.0f, 1.0f);
+    // a unit vector with view . up = mu and view . sun = nu (two solutions mirrored in the sun's vertical plane: take one)
+    const float sv = fsqrt(fmax_(1.0f - mu * mu, 0.0f)), ss = fsqrt(fmax_(1.0f - mu_s * mu_s, 0.0f));
+    if (!(sv * ss > 1e-6f)) return;
+    const float cphi = fdiv(nu - mu * mu_s, sv * ss);
+    if (!(fabsf(cphi) <= 1.0f)) return;                                                        // no view ray has this (mu, nu)
+    const f3 e1 = (sun - up * mu_s) * frcp(ss), e2 = cross(up, e1);
+    const f3 dir = normalize(up * mu + (e1 * cphi + e2 * fsqrt(fmax_(1.0f - cphi * cphi, 0.0f))) * sv);
+    const f3 full = sky.sample(pos, dir, sun, false), tab = sky.sample(pos, dir, sun, true);
+    const float dev = fmax_(fmax_(fabsf(tab.x - full.x), fabsf(tab.y - full.y)), fabsf(tab.z - full.z)) / fmax_(fmax_(fmax_(full.x, full.y), full.z), 1e-30f);
+    const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;
+    unsigned long long* e = err + 8 + 4 * cv;
+    if (bits != 0u) atomicMax(e, ((unsigned long long)bits << 32) | c);
+    atomicAdd(e + 1, 1ull);
+    if (!(dev <= 1e-3f)) atomicAdd(e + 2, 1ull);
+}
+// The verdicts the tail reads.  Per variant: against real rays through the full path no ray is off by more than 2 % and at most
+// 2 % of them by more than 1e-3 (the image tolerance is 1e-3 rel. L2) -- a variant that fails loses its table (SkyView::tab[v].w = 0:
+// its ground hits are evaluated in full).  err[4] = 1 when the interpolant follows its nodes (err[0] <= tol) and a variant is left;
+// err[1..3] = the centre variant's figures (vpt_test_get_dir_table_check), err[5] = variants in use.
+__global__ void sky_dir_table_verdict_kernel(unsigned long long* err, SkyView* view, float tol) {
+    const int k = view->k;
+    unsigned long long in_use = 0;
+    for (int v = 0; v <= 2 * k; ++v) {
+        const unsigned long long* e = err + 8 + 4 * v;
+        const float worst = __uint_as_float((uint32_t)(e[0] >> 32));
+        const bool ok = view->tab[v].w != 0.0f && e[1] > 0ull && worst <= 2e-2f && e[2] * 50ull <= e[1];
+        if (!ok) view->tab[v].w = 0.0f;
+        in_use += ok ? 1ull : 0ull;
+    }
+    err[1] = err[8 + 4 * k]; err[2] = err[8 + 4 * k + 1]; err[3] = err[8 + 4 * k + 2];
+    err[5] = in_use;
+    err[4] = (__uint_as_float((uint32_t)(err[0] >> 32)) <= tol && in_use != 0ull) ? 1ull : 0ull;
+}
 size_t sky_cam_table_bytes() { return sizeof(float4) * 2u * 8u * 128u * (2u * SKY_VIEW_MAX_K + 1u); }
 size_t sky_dir_table_bytes() { return sizeof(float4) * 2u * Sky<ResolveParams>::DT_NX * Sky<ResolveParams>::DT_NN * (2u * SKY_VIEW_MAX_K + 1u); }
-hipError_t launch_sky_dir_table(const ResolveParams& R, const SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream) {
+hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream) {
     typedef Sky<ResolveParams> S;
-    hipError_t e = hipMemsetAsync(err, 0, sizeof(unsigned long long), stream);
+    hipError_t e = hipMemsetAsync(err, 0, SKY_DIR_ERR_WORDS * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     const int variants = 2 * k + 1;
     hipLaunchKernelGGL(sky_dir_table_kernel, dim3((variants * S::DT_NX * S::DT_NN + 255) / 256), dim3(256), 0, stream, R, view, tab);
     hipLaunchKernelGGL(sky_dir_table_check_kernel, dim3((variants * (S::DT_NX - 1) * (S::DT_NN - 1) + 255) / 256), dim3(256), 0, stream, R, view, tab, err);
+    // real rays through both paths (R.dir_tab / R.sky_view / R.cam_tab must already point at the tables: the host sets them first)
+    const dim3 rg((variants * (S::DT_NX - 1) * (S::DT_NN - 1) + 255) / 256);
+    if (k > 0) hipLaunchKernelGGL(sky_dir_table_rays_kernel<true>, rg, dim3(256), 0, stream, R, view, err);
+    else hipLaunchKernelGGL(sky_dir_table_rays_kernel<false>, rg, dim3(256), 0, stream, R, view, err);
+    hipLaunchKernelGGL(sky_dir_table_verdict_kernel, dim3(1), dim3(1), 0, stream, err, view, R.dir_tab_tol);
     return hipGetLastError();
 }
 
@@ -293,7 +383,7 @@ __global__ void sky_samples_kernel(const ResolveParams R, const float* __restric
     if (i >= n) return;
     Sky<ResolveParams> sky = {R};
     load_sky_view<true>(R, sky);
-    const bool use_dir_tab = use_table && R.dir_tab != nullptr && __uint_as_float(R.dir_tab_err[1]) <= R.dir_tab_tol;
+    const bool use_dir_tab = use_table && R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
     const f3 from = origins ? mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]) : mk3(R.cam_tab_pos[0], R.cam_tab_pos[1], R.cam_tab_pos[2]);
     const f3 v = sky.sample(from, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]),
                             mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]), use_dir_tab);
