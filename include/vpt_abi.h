@@ -375,7 +375,7 @@ typedef struct vpt_atmosphere_model_options {
     int    use_constant_solar_spectrum;   /* 1 */
     int    use_ozone;                     /* 1 */
     int    do_white_balance;              /* 1 */
-    int    use_luminance;                 /* 0 NONE, 1 APPROXIMATE, 2 PRECOMPUTED (unsupported) */
+    int    use_luminance;                 /* 0 NONE, 1 APPROXIMATE, 2 PRECOMPUTED (tables through vpt_atmosphere_precompute_model) */
     int    half_precision;                /* 0 */
     float  exposure;                      /* 1 */
     double lambdas[3];                    /* 680, 550, 440 nm */
@@ -384,6 +384,13 @@ typedef struct vpt_atmosphere_model_options {
 void vpt_atmosphere_model_options_default(vpt_atmosphere_model_options *opt);
 int  vpt_atmosphere_model(const vpt_atmosphere_model_options *opt, const char *spectra_file, vpt_atmosphere_parameters *atm);
 int  vpt_atmosphere_precompute(vpt_ctx *ctx, vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
+/* atmosphere::init's precomputation for any luminance mode (source/atmosphere/atmosphere.cpp:1227-1275): vpt_atmosphere_model +
+ * the table passes.  use_luminance 0 / 1: one pass, i.e. vpt_atmosphere_model followed by vpt_atmosphere_precompute.
+ * use_luminance 2 (PRECOMPUTED): five passes over 15 wavelengths with per-pass model scalars, luminance-from-radiance matrices and
+ * blending as the reference runs them (its argument-passing quirks included, csrc/vpt_atmosphere.hip), then the transmittance
+ * table for opt->lambdas.  `atm` is an OUTPUT: scalars, the nine device buffers (allocated here) and the four texture handles. */
+int  vpt_atmosphere_precompute_model(vpt_ctx *ctx, const vpt_atmosphere_model_options *opt, const char *spectra_file,
+                                     vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
 int  vpt_atmosphere_read_lut(vpt_ctx *ctx, const vpt_atmosphere_parameters *atm, int which, float *host_out, size_t n_floats);
 
 /* ---- environment importance tables (prerequisite of estimate_sky on the procedural sky) -------

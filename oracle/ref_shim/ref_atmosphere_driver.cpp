@@ -34,6 +34,30 @@ void convert_profile(DensityProfile& d, const vpt_density_profile& s) {
     }
 }
 
+// model scalars of a pass (everything but the nine buffers)
+void set_scalars(AtmosphereParameters& atm, const vpt_atmosphere_parameters* vatm) {
+    atm.sky_spectral_radiance_to_luminance = cv(vatm->sky_spectral_radiance_to_luminance);
+    atm.sun_spectral_radiance_to_luminance = cv(vatm->sun_spectral_radiance_to_luminance);
+    atm.solar_irradiance = cv(vatm->solar_irradiance);
+    atm.angle = vatm->angle;
+    atm.bottom_radius = vatm->bottom_radius;
+    atm.top_radius = vatm->top_radius;
+    atm.use_luminance = vatm->use_luminance;
+    convert_profile(atm.rayleigh_density, vatm->rayleigh_density);
+    atm.rayleigh_scattering = cv(vatm->rayleigh_scattering);
+    convert_profile(atm.mie_density, vatm->mie_density);
+    atm.mie_scattering = cv(vatm->mie_scattering);
+    atm.mie_extinction = cv(vatm->mie_extinction);
+    atm.mie_phase_function_g = vatm->mie_phase_function_g;
+    convert_profile(atm.absorption_density, vatm->absorption_density);
+    atm.absorption_extinction = cv(vatm->absorption_extinction);
+    atm.ground_albedo = cv(vatm->ground_albedo);
+    atm.sun_angular_radius = vatm->sun_angular_radius;
+    atm.mu_s_min = vatm->mu_s_min;
+    atm.exposure = vatm->exposure;
+    atm.white_point = cv(vatm->white_point);
+}
+
 // one "thread" per texel, blockDim = 1: every kernel only writes its own texel and reads tables written by
 // earlier launches, so any execution order inside a launch gives the same result
 void launch(int nx, int ny, int nz, int threads, const std::function<void()>& kernel) {
@@ -65,9 +89,23 @@ void launch(int nx, int ny, int nz, int threads, const std::function<void()>& ke
 // scattering / single_mie SCATTERING_TEXTURE_WIDTH x HEIGHT x DEPTH.  A NULL output is skipped.
 // max_z > 0 restricts the three scattering-sized launches of orders >= 2 to the first max_z depth slices (a cheaper,
 // partial run for small machines: the slices that are computed are exact only for order 2, whose inputs are complete).
+// npasses > 0: the PRECOMPUTED luminance mode of atmosphere::init (atmosphere.cpp:1237-1268): pass i runs atmosphere::precompute with
+// the model scalars passes[i] (update_model(lambdas_i)), the luminance-from-radiance matrix lfrm[9 i .. 9 i + 8] and blend = i > 0;
+// then compute_transmittance with the scalars `vatm`.  npasses == 0: the one ordinary pass (identity matrix, no blend).
+extern "C" int ref_atmosphere_precompute_passes(const vpt_atmosphere_parameters* vatm, const vpt_atmosphere_parameters* passes, const double* lfrms,
+                                                int npasses, int num_scattering_orders, int nthreads,
+                                                float* transmittance, float* irradiance, float* scattering, float* single_mie,
+                                                float* delta_scattering_density, int max_z, float guard_fill);
 extern "C" int ref_atmosphere_precompute(const vpt_atmosphere_parameters* vatm, int num_scattering_orders, int nthreads,
                                          float* transmittance, float* irradiance, float* scattering, float* single_mie,
                                          float* delta_scattering_density, int max_z, float guard_fill) {
+    return ref_atmosphere_precompute_passes(vatm, nullptr, nullptr, 0, num_scattering_orders, nthreads, transmittance, irradiance, scattering,
+                                            single_mie, delta_scattering_density, max_z, guard_fill);
+}
+extern "C" int ref_atmosphere_precompute_passes(const vpt_atmosphere_parameters* vatm, const vpt_atmosphere_parameters* passes, const double* lfrms,
+                                                int npasses, int num_scattering_orders, int nthreads,
+                                                float* transmittance, float* irradiance, float* scattering, float* single_mie,
+                                                float* delta_scattering_density, int max_z, float guard_fill) {
     if (!vatm) return -1;
     if (num_scattering_orders < 1) num_scattering_orders = 4;
     const int threads = nthreads > 1 ? nthreads : 1;
@@ -77,26 +115,7 @@ extern "C" int ref_atmosphere_precompute(const vpt_atmosphere_parameters* vatm, 
 
     AtmosphereParameters atm;
     std::memset(&atm, 0, sizeof(atm));
-    atm.sky_spectral_radiance_to_luminance = cv(vatm->sky_spectral_radiance_to_luminance);
-    atm.sun_spectral_radiance_to_luminance = cv(vatm->sun_spectral_radiance_to_luminance);
-    atm.solar_irradiance = cv(vatm->solar_irradiance);
-    atm.angle = vatm->angle;
-    atm.bottom_radius = vatm->bottom_radius;
-    atm.top_radius = vatm->top_radius;
-    atm.use_luminance = vatm->use_luminance;
-    convert_profile(atm.rayleigh_density, vatm->rayleigh_density);
-    atm.rayleigh_scattering = cv(vatm->rayleigh_scattering);
-    convert_profile(atm.mie_density, vatm->mie_density);
-    atm.mie_scattering = cv(vatm->mie_scattering);
-    atm.mie_extinction = cv(vatm->mie_extinction);
-    atm.mie_phase_function_g = vatm->mie_phase_function_g;
-    convert_profile(atm.absorption_density, vatm->absorption_density);
-    atm.absorption_extinction = cv(vatm->absorption_extinction);
-    atm.ground_albedo = cv(vatm->ground_albedo);
-    atm.sun_angular_radius = vatm->sun_angular_radius;
-    atm.mu_s_min = vatm->mu_s_min;
-    atm.exposure = vatm->exposure;
-    atm.white_point = cv(vatm->white_point);
+    set_scalars(atm, vatm);
 
     // The reference's nearest-texel table reads (atmosphere_kernels.cu:157-169, 375-395, 604-616) are not bounds-checked
     // and step past the end of a table for coordinates equal to 1.  Every table therefore sits between guard regions
@@ -127,11 +146,16 @@ extern "C" int ref_atmosphere_precompute(const vpt_atmosphere_parameters* vatm, 
     atm.delta_multiple_scattering_buffer = ptr[8];
 
     static double identity[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};   // kDefaultLuminanceFromRadiance
-    mat3 lfrm;
-    lfrm = lfrm.toMatrix(identity);
-    const int BLEND = 0;                                                          // init(): precompute(nullptr, nullptr, false, 4)
-
     const int SZ = (max_z > 0 && max_z < SCATTERING_TEXTURE_DEPTH) ? max_z : SCATTERING_TEXTURE_DEPTH;
+    const int runs = npasses > 0 ? npasses : 1;
+    for (int pass = 0; pass < runs; ++pass) {
+    double m9[9];
+    std::memcpy(m9, npasses > 0 ? lfrms + 9 * pass : identity, sizeof(m9));
+    mat3 lfrm;
+    lfrm = lfrm.toMatrix(m9);
+    const int BLEND = pass > 0 ? 1 : 0;                                           // init(): precompute(lambdas, luminance_from_radiance, i > 0, 4)
+    if (npasses > 0) set_scalars(atm, passes + pass);                             // update_model(lambdas) of the pass
+
     launch(TRANSMITTANCE_TEXTURE_WIDTH, TRANSMITTANCE_TEXTURE_HEIGHT, 1, threads, [&]() { calculate_transmittance(atm); });
     launch(IRRADIANCE_TEXTURE_WIDTH, IRRADIANCE_TEXTURE_HEIGHT, 1, threads, [&]() { calculate_direct_irradiance(atm, BLEND); });
     {
@@ -148,6 +172,12 @@ extern "C" int ref_atmosphere_precompute(const vpt_atmosphere_parameters* vatm, 
         std::memcpy(&blend_as_int, &blend_vec, sizeof(int));
         launch(IRRADIANCE_TEXTURE_WIDTH, IRRADIANCE_TEXTURE_HEIGHT, 1, threads, [&]() { calculate_indirect_irradiance(atm, blend_as_int, lfrm, order); });
         launch(SCATTERING_TEXTURE_WIDTH, SCATTERING_TEXTURE_HEIGHT, SZ, threads, [&]() { calculate_multiple_scattering(atm, blend_as_int, lfrm, order); });
+    }
+    }   // passes
+    if (npasses > 0) {
+        // atmosphere::compute_transmittance (:1118-1175): the transmittance table once more, for the final wavelengths
+        set_scalars(atm, vatm);
+        launch(TRANSMITTANCE_TEXTURE_WIDTH, TRANSMITTANCE_TEXTURE_HEIGHT, 1, threads, [&]() { calculate_transmittance(atm); });
     }
 
     if (transmittance) std::memcpy(transmittance, b_t, nt * sizeof(float4));

@@ -10,7 +10,7 @@
 // allocations in the reference, :1316-1339) are given empty bodies here; the three defaults the constructor sets come from
 // the command line.  It pins vpt_atmosphere_model (csrc/vpt_atmosphere.hip): tests/test_atmosphere_model.py.
 //
-//   ref_atmosphere_model <const_solar 0|1> <ozone 0|1> <white_balance 0|1> <use_luminance 0|1> <exposure> <lr> <lg> <lb> <out.bin>
+//   ref_atmosphere_model <const_solar 0|1> <ozone 0|1> <white_balance 0|1> <use_luminance 0|1|2> <exposure> <lr> <lg> <lb> <out.bin>
 //   out.bin: the scalar members of AtmosphereParameters as 32-bit floats / ints, in the order written below
 #include "cuda_runtime.h"
 #define private public
@@ -32,8 +32,9 @@ struct Probe : atmosphere {
 #include "atmosphere_init_spectra.inc"         // atmosphere.cpp:1198-1224
     }
     void factors_and_update(float3 lambdas) {
-        // atmosphere::precompute :903-912, with m_use_luminance != PRECOMPUTED
-        compute_spectral_radiance_to_luminance_factors(m_wave_lengths, m_solar_irradiance, -3, sky_k_r, sky_k_g, sky_k_b);
+        // atmosphere::precompute :900-912
+        if (m_use_luminance == PRECOMPUTED) sky_k_r = sky_k_g = sky_k_b = MAX_LUMINOUS_EFFICACY;
+        else compute_spectral_radiance_to_luminance_factors(m_wave_lengths, m_solar_irradiance, -3, sky_k_r, sky_k_g, sky_k_b);
         compute_spectral_radiance_to_luminance_factors(m_wave_lengths, m_solar_irradiance, 0, sun_k_r, sun_k_g, sun_k_b);
         update_model(lambdas);
     }
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
     P->m_use_constant_solar_spectrum = atoi(argv[1]) != 0;
     P->m_use_ozone = atoi(argv[2]) != 0;
     P->m_do_white_balance = atoi(argv[3]) != 0;
-    P->m_use_luminance = atoi(argv[4]) == 1 ? APPROXIMATE : NONE;
+    P->m_use_luminance = atoi(argv[4]) == 2 ? PRECOMPUTED : (atoi(argv[4]) == 1 ? APPROXIMATE : NONE);
     P->m_exposure = (float)atof(argv[5]);
     P->build_spectra();
     P->factors_and_update(make_float3((float)atof(argv[6]), (float)atof(argv[7]), (float)atof(argv[8])));

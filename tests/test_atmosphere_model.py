@@ -22,6 +22,8 @@ CASES = {
     "off_node_wavelengths": (0, 1, 0, 0, 2.5, (612.3, 549.1, 465.7)),
     "approximate_luminance": (0, 1, 1, 1, 10.0, (650.0, 510.0, 475.0)),
     "edge_wavelengths": (1, 1, 1, 0, 1.0, (830.0, 360.0, 355.0)),
+    "precomputed_luminance": (1, 1, 1, 2, 1.0, (680.0, 550.0, 440.0)),
+    "precomputed_luminance_pass_2": (0, 1, 1, 2, 1.0, (563.666666, 595.0, 626.333333)),      # a wavelength triple of the five-pass precompute
 }
 
 
@@ -93,8 +95,8 @@ def test_model_matches_reference_live(pkg):
 
 def test_default_options_reproduce_the_builtin_default_model(pkg):
     assert bytes(pkg.atmosphere.model()) == bytes(pkg.atmosphere.default_model())
-    with pytest.raises(pkg.VptError):
-        pkg.atmosphere.model(use_luminance=2)                      # PRECOMPUTED: the 15-wavelength precompute is not built
+    lum = pkg.atmosphere.model(use_luminance=2)                   # PRECOMPUTED: the sky factor is MAX_LUMINOUS_EFFICACY alone
+    assert lum.use_luminance == 2 and lum.sky_spectral_radiance_to_luminance.x == 683.0 == lum.sky_spectral_radiance_to_luminance.z
     with pytest.raises(pkg.VptError):
         pkg.atmosphere.model(spectra_file="/nonexistent/spectra.bin")
 

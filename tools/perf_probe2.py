@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c3"); ap.add_argument("--spp", type=int, default=8); ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--set", action="append", default=[])
+ap.add_argument("--count-spp", type=int, default=4, help="iterations of the COUNTED render the schedule figures come from (64 = one full record chunk)")
+ap.add_argument("--grid-scale", type=float, default=0.5, help="c4: linear scale of the 1024x704x1216 grid")
 a = ap.parse_args()
 import torch
 import __graft_entry__ as ge
@@ -14,7 +16,7 @@ S = pkg.scene
 if a.config == "c3": sd = S.fireball_scene(1920, 1080, n=256)
 elif a.config == "c5": sd = S.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0)
 elif a.config == "c4":
-    sd = S.cloud_scene(1920, 1080, env=(2048, 1024), integrator=1, device_grid=S.cloud_grid_torch((608, 352, 512), device="cuda"))
+    sd = S.cloud_scene(1920, 1080, env=(2048, 1024), integrator=1, device_grid=S.cloud_grid_torch(tuple(int(round(x * a.grid_scale)) for x in (1216, 704, 1024)), device="cuda"))
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
 else:
     sd = S.dragon_scene(1920, 1080, a.config)
@@ -44,7 +46,8 @@ if sum(op[8:12]):
     print("  of the walk step, the empty-node skip loop: %.1f%% of all cycles" % (100.0 * op[5] / tot))
     print("  transitions split: entry+FIRST_DONE %.1f%%, TRACK_DONE..EMIT %.1f%%, OUTER_SECOND/TOP %.1f%%, FINISH %.1f%%, Tr prologue %.1f%% (of all cycles)" % tuple(100.0 * x / tot for x in op[0:5]))
 hb.ctx.set_counting(True)
-hb.render(min(a.spp, 4), iteration=0); hb.sync()
+hb.render(a.count_spp, iteration=0); hb.sync()
+print("(schedule figures: a counted render of %d iterations)" % a.count_spp)
 out = (C.c_ulonglong * 12)()
 pkg.load_library().vpt_test_get_schedule(hb.ctx.h, out)
 o = list(out); st = hb.ctx.stats()

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -120,6 +121,8 @@ int main(int argc, char** argv) {
     return 0;
 }
 
+static std::atomic<int> g_setup_arrived{0}, g_setup_failed{0};      // --ranks: agreement before the collective communicator init
+
 static int render_rank(const Options& opt, int rank, const unsigned char* comm_id) {
     vpt_ctx* ctx = nullptr;
     const std::string &scene = opt.scene, &assets = opt.assets, &env = opt.env, &lights_file = opt.lights_file, &out = opt.out;
@@ -127,7 +130,18 @@ static int render_rank(const Options& opt, int rank, const unsigned char* comm_i
     const float fov = opt.fov, aperture = opt.aperture;
     vpt_kernel_params kp = opt.kp;
 
-    CHECK(vpt_create(device, &ctx));
+    const int created = vpt_create(device, &ctx);
+    if (ranks > 1) {
+        // the communicator init is collective: every rank first says whether it has a context, and nobody enters
+        // ncclCommInitRank unless all have (a rank that failed earlier would leave the others blocked in it for good)
+        if (created != VPT_OK) g_setup_failed.fetch_add(1);
+        g_setup_arrived.fetch_add(1);
+        while (g_setup_arrived.load() < ranks) std::this_thread::yield();
+        if (g_setup_failed.load() != 0) {
+            if (created == VPT_OK) { fprintf(stderr, "vpt_cli: rank %d: another rank has no context, not joining the communicator\n", rank); vpt_destroy(ctx); return 1; }
+        }
+    }
+    CHECK(created);
     if (ranks > 1) CHECK(vpt_comm_init_rank(ctx, ranks, rank, comm_id));
 
     // ---- volumes: one file or an instance file (main.cpp:1283-1303, 980-1102) --------------------------

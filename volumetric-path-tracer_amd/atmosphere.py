@@ -41,6 +41,37 @@ def model(spectra_file=None, **options):
     return p
 
 
+def model_options(**options):
+    from . import abi
+    o = abi.AtmosphereModelOptions()
+    load_library().vpt_atmosphere_model_options_default(C.byref(o))
+    for k, v in options.items():
+        if k == "lambdas":
+            o.lambdas = (C.c_double * 3)(*[float(x) for x in v])
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def _read_luts(ctx, p):
+    luts = {}
+    for name, shape in LUT_SHAPES.items():
+        a = np.empty(shape, np.float32)
+        ctx._chk(ctx.lib.vpt_atmosphere_read_lut(ctx.h, C.byref(p), _WHICH[name], a.ctypes.data_as(C.c_void_p), a.size), "vpt_atmosphere_read_lut")
+        luts[name] = a
+    return luts
+
+
+def precompute_model(ctx, orders=4, spectra_file=None, **options):
+    """vpt_atmosphere_precompute_model: model + table passes for any luminance mode (use_luminance=2: the PRECOMPUTED mode's five
+    passes over 15 wavelengths); returns (params, dict of numpy LUTs)."""
+    p = AtmosphereParameters()
+    o = model_options(**options)
+    ctx._chk(ctx.lib.vpt_atmosphere_precompute_model(ctx.h, C.byref(o), spectra_file.encode() if spectra_file else None, C.byref(p), int(orders), None),
+             "vpt_atmosphere_precompute_model")
+    return p, _read_luts(ctx, p)
+
+
 def precompute(ctx, params=None, orders=4):
     """Runs the precompute on ctx's GPU; returns (params with device buffers + textures, dict of numpy LUTs)."""
     p = params or default_model()
@@ -59,7 +90,10 @@ def attach_default_atmosphere(sd, device=0, **model_options):
     key = (int(device), tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in model_options.items())))
     if key not in _cache:
         ctx = Context(device)
-        p, luts = precompute(ctx, model(**model_options) if model_options else None)
+        if model_options.get("use_luminance") == 2:
+            p, luts = precompute_model(ctx, **model_options)
+        else:
+            p, luts = precompute(ctx, model(**model_options) if model_options else None)
         scal = AtmosphereParameters.from_buffer_copy(p)
         for f in ("delta_irradience_buffer", "delta_rayleigh_scattering_buffer", "delta_mie_scattering_buffer", "delta_scattering_density_buffer",
                   "delta_multiple_scattering_buffer", "transmittance_buffer", "irradiance_buffer", "scattering_buffer", "optional_mie_single_scattering_buffer"):

@@ -267,7 +267,14 @@ VPT_D f3 GetScatteringOrder(const AtmoD& a, float r, float mu, float mu_s, float
     return GetScatteringBuf(a, a.scattering, r, mu, mu_s, nu, ground);
 }
 
-__global__ void k_single_scattering(AtmoD a) {                                        // :172-243, 719-752 (blend = 0)
+// luminance_from_radiance (matrix_math.h mat3: toMatrix fills rows, operator* is row . vector): identity except in the
+// PRECOMPUTED luminance mode's passes (atmosphere.cpp:1247-1255)
+struct Lfrm { float m[9]; };
+VPT_D f3 lfrm_mul(const Lfrm& L, f3 v) {
+    return mk3(L.m[0] * v.x + L.m[1] * v.y + L.m[2] * v.z, L.m[3] * v.x + L.m[4] * v.y + L.m[5] * v.z, L.m[6] * v.x + L.m[7] * v.y + L.m[8] * v.z);
+}
+// blend_s / blend_m: blend_vec.z / .w of atmosphere.cpp:988 -- add what the two tables held before (passes after the first)
+__global__ void k_single_scattering(AtmoD a, Lfrm L, int blend_s, int blend_m) {      // :172-243, 719-752
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z * blockDim.z + threadIdx.z;
     if (x >= SW || y >= SH || z >= SD) return;
     const int idx = x + SW * (y + SH * z);
@@ -290,8 +297,13 @@ __global__ void k_single_scattering(AtmoD a) {                                  
     f3 mie = mie_sum * dx * a.solar_irradiance * a.mie_scattering;
     a.delta_rayleigh[idx] = make_float4(ray.x, ray.y, ray.z, 1.0f);
     a.delta_mie[idx] = make_float4(mie.x, mie.y, mie.z, 1.0f);
-    a.scattering[idx] = make_float4(ray.x, ray.y, ray.z, mie.x);          // luminance_from_radiance = identity
-    a.single_mie[idx] = make_float4(mie.x, mie.y, mie.z, 1.0f);
+    const float4 ts = a.scattering[idx], tm = a.single_mie[idx];           // :733-735 (read whatever the flags say, as the reference does)
+    const f3 lr = lfrm_mul(L, ray), lm = lfrm_mul(L, mie);
+    float4 sc = make_float4(lr.x, lr.y, lr.z, lm.x), sm = make_float4(mie.x, mie.y, mie.z, 1.0f);
+    if (blend_s) sc = make_float4(sc.x + ts.x, sc.y + ts.y, sc.z + ts.z, sc.w + ts.w);
+    if (blend_m) sm = make_float4(sm.x + tm.x, sm.y + tm.y, sm.z + tm.z, sm.w + tm.w);
+    a.scattering[idx] = sc;
+    a.single_mie[idx] = sm;
 }
 
 __global__ void k_scattering_density(AtmoD a, int order) {                            // :412-480, 702-717
@@ -338,7 +350,7 @@ __global__ void k_scattering_density(AtmoD a, int order) {                      
     a.delta_density[idx] = make_float4(acc.x, acc.y, acc.z, 1.0f);
 }
 
-__global__ void k_indirect_irradiance(AtmoD a, int order) {                           // :572-586, 654-674 (blend = 0, D3)
+__global__ void k_indirect_irradiance(AtmoD a, int order, Lfrm L) {                   // :572-586, 654-674 (blend = 0, D3)
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= IW || y >= IH) return;
     const int idx = y * IW + x;
@@ -358,11 +370,12 @@ __global__ void k_indirect_irradiance(AtmoD a, int order) {                     
             result += GetScatteringOrder(a, r, w.z, mu_s, nu, false, order - 1) * w.z * dw;
         }
     }
-    a.irradiance[idx] = make_float4(result.x, result.y, result.z, 0.0f);
+    const f3 lres = lfrm_mul(L, result);                                   // :668: the table holds the converted value, and so does the "delta"
+    a.irradiance[idx] = make_float4(lres.x, lres.y, lres.z, 0.0f);
     a.delta_irradiance[idx] = a.irradiance[idx];
 }
 
-__global__ void k_multiple_scattering(AtmoD a) {                                      // :482-517, 676-700 (blend = 0, D3)
+__global__ void k_multiple_scattering(AtmoD a, Lfrm L) {                              // :482-517, 676-700 (blend = 0, D3)
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z * blockDim.z + threadIdx.z;
     if (x >= SW || y >= SH || z >= SD) return;
     const int idx = x + SW * (y + SH * z);
@@ -382,7 +395,7 @@ __global__ void k_multiple_scattering(AtmoD a) {                                
         sum += v * w;
     }
     a.delta_multiple[idx] = make_float4(sum.x, sum.y, sum.z, 1.0f);
-    f3 s = sum / RayleighPhase(nu);
+    f3 s = lfrm_mul(L, sum) / RayleighPhase(nu);
     a.scattering[idx] = make_float4(s.x, s.y, s.z, 0.0f);
 }
 
@@ -498,6 +511,15 @@ void luminance_factors(const Spectra& S, const std::vector<double>& wl, const st
 }
 }  // namespace
 
+static bool default_spectra_path(std::string& path) {     // data/atmosphere_spectra.bin next to this library
+    Dl_info info;
+    if (!dladdr((const void*)&vpt_atmosphere_model_options_default, &info) || !info.dli_fname) return false;
+    path = info.dli_fname;
+    const size_t slash = path.find_last_of('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/data/atmosphere_spectra.bin";
+    return true;
+}
+
 void vpt_atmosphere_model_options_default(vpt_atmosphere_model_options* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
@@ -513,17 +535,10 @@ void vpt_atmosphere_model_options_default(vpt_atmosphere_model_options* o) {
 
 int vpt_atmosphere_model(const vpt_atmosphere_model_options* o, const char* spectra_file, vpt_atmosphere_parameters* p) {
     if (!o || !p) return VPT_E_INVALID;
-    if (o->use_luminance == 2) return VPT_E_UNSUPPORTED;      // PRECOMPUTED: 15-wavelength precompute with blending, not built
     if (o->use_luminance < 0 || o->use_luminance > 2 || !(o->length_unit_in_meters > 0.0)) return VPT_E_INVALID;
     std::string path;
     if (spectra_file && spectra_file[0]) path = spectra_file;
-    else {
-        Dl_info info;                              // default: data/atmosphere_spectra.bin next to this library
-        if (!dladdr((const void*)&vpt_atmosphere_model, &info) || !info.dli_fname) return VPT_E_IO;
-        path = info.dli_fname;
-        const size_t slash = path.find_last_of('/');
-        path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/data/atmosphere_spectra.bin";
-    }
+    else if (!default_spectra_path(path)) return VPT_E_IO;
     Spectra S;
     if (!load_spectra(path.c_str(), S)) return VPT_E_IO;
     // ---- init's spectra (:1193-1224)
@@ -546,9 +561,11 @@ int vpt_atmosphere_model(const vpt_atmosphere_model_options* o, const char* spec
     const double unit = o->length_unit_in_meters;
     const double bottom = 6360000.0f, top = 6420000.0f;        // float literals in the reference (:1218-1219)
     std::memset(p, 0, sizeof(*p));
-    // ---- luminance factors (:903-910): use_luminance != PRECOMPUTED here
+    // ---- luminance factors (:900-908): PRECOMPUTED converts radiance to luminance inside the tables, the sky factor is then
+    // MAX_LUMINOUS_EFFICACY alone
     double sky_k[3], sun_k[3];
-    luminance_factors(S, wl, solar, -3.0, sky_k);
+    if (o->use_luminance == 2) sky_k[0] = sky_k[1] = sky_k[2] = 683.0;
+    else luminance_factors(S, wl, solar, -3.0, sky_k);
     luminance_factors(S, wl, solar, 0.0, sun_k);
     // ---- update_model (:698-784)
     p->sky_spectral_radiance_to_luminance = {(float)sky_k[0], (float)sky_k[1], (float)sky_k[2]};
@@ -618,11 +635,11 @@ static int alloc4(float4** p, size_t n) {
     return hipMalloc(p, n * sizeof(float4)) == hipSuccess ? 0 : -1;
 }
 
-int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int num_scattering_orders, void* stream_v) {
-    if (!ctx || !p) return VPT_E_INVALID;
-    if (num_scattering_orders < 1) num_scattering_orders = 4;
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
-    vpt_invalidate_sky_tables(ctx);      // the per-frame sky tables are keyed on the buffers' addresses, which a re-run keeps
+// One pass of atmosphere::precompute (:888-1116) over the buffers of `p` with the model scalars of `m` (the same struct for the
+// ordinary single pass; PRECOMPUTED luminance runs five with their own wavelengths, matrices and blend flag);
+// transmittance_only: atmosphere::compute_transmittance (:1118-1175)
+static int precompute_pass(vpt_ctx* ctx, vpt_atmosphere_parameters* p, const vpt_atmosphere_parameters* m, int num_scattering_orders,
+                           const double* lfrm9, int blend, bool transmittance_only, hipStream_t stream) {
     const size_t n2t = (size_t)TW * TH, n2i = (size_t)IW * IH, n3 = (size_t)SW * SH * SD;
     float4** bufs2t[] = {(float4**)&p->transmittance_buffer};
     float4** bufs2i[] = {(float4**)&p->delta_irradience_buffer, (float4**)&p->irradiance_buffer};
@@ -633,13 +650,13 @@ int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int nu
     for (auto b : bufs2i) if (alloc4(b, n2i)) return VPT_E_NOMEM;
     for (auto b : bufs3) if (alloc4(b, n3)) return VPT_E_NOMEM;
     AtmoD a;
-    a.bottom = p->bottom_radius; a.top = p->top_radius;
-    a.sun_angular_radius = p->sun_angular_radius; a.mu_s_min = p->mu_s_min; a.mie_g = p->mie_phase_function_g;
+    a.bottom = m->bottom_radius; a.top = m->top_radius;
+    a.sun_angular_radius = m->sun_angular_radius; a.mu_s_min = m->mu_s_min; a.mie_g = m->mie_phase_function_g;
     auto v = [](vpt_float3 q) { return mk3(q.x, q.y, q.z); };
-    a.solar_irradiance = v(p->solar_irradiance); a.rayleigh_scattering = v(p->rayleigh_scattering);
-    a.mie_scattering = v(p->mie_scattering); a.mie_extinction = v(p->mie_extinction);
-    a.absorption_extinction = v(p->absorption_extinction); a.ground_albedo = v(p->ground_albedo);
-    a.rayleigh_density = p->rayleigh_density; a.mie_density = p->mie_density; a.absorption_density = p->absorption_density;
+    a.solar_irradiance = v(m->solar_irradiance); a.rayleigh_scattering = v(m->rayleigh_scattering);
+    a.mie_scattering = v(m->mie_scattering); a.mie_extinction = v(m->mie_extinction);
+    a.absorption_extinction = v(m->absorption_extinction); a.ground_albedo = v(m->ground_albedo);
+    a.rayleigh_density = m->rayleigh_density; a.mie_density = m->mie_density; a.absorption_density = m->absorption_density;
     a.delta_irradiance = (float4*)p->delta_irradience_buffer; a.delta_rayleigh = (float4*)p->delta_rayleigh_scattering_buffer;
     a.delta_mie = (float4*)p->delta_mie_scattering_buffer; a.delta_density = (float4*)p->delta_scattering_density_buffer;
     a.delta_multiple = (float4*)p->delta_multiple_scattering_buffer; a.transmittance = (float4*)p->transmittance_buffer;
@@ -649,15 +666,24 @@ int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int nu
     const dim3 b2(16, 16, 1), b3(32, 4, 2);
     const dim3 gt((TW + 15) / 16, (TH + 15) / 16, 1), gi((IW + 15) / 16, (IH + 15) / 16, 1);
     const dim3 gs((SW + 31) / 32, (SH + 3) / 4, (SD + 1) / 2);
+    Lfrm L;
+    for (int i = 0; i < 9; ++i) L.m[i] = lfrm9 ? (float)lfrm9[i] : (i % 4 == 0 ? 1.0f : 0.0f);       // kDefaultLuminanceFromRadiance: identity
     hipLaunchKernelGGL(k_transmittance, gt, b2, 0, stream, a);
-    hipLaunchKernelGGL(k_direct_irradiance, gi, b2, 0, stream, a, 0);
-    hipLaunchKernelGGL(k_single_scattering, gs, b3, 0, stream, a);
-    for (int order = 2; order <= num_scattering_orders; ++order) {
-        hipLaunchKernelGGL(k_scattering_density, gs, b3, 0, stream, a, order);
-        hipLaunchKernelGGL(k_indirect_irradiance, gi, b2, 0, stream, a, order);
-        hipLaunchKernelGGL(k_multiple_scattering, gs, b3, 0, stream, a);
+    if (!transmittance_only) {
+        hipLaunchKernelGGL(k_direct_irradiance, gi, b2, 0, stream, a, blend);
+        hipLaunchKernelGGL(k_single_scattering, gs, b3, 0, stream, a, L, blend, blend);
+        for (int order = 2; order <= num_scattering_orders; ++order) {
+            // (the two kernels below never blend: the host hands them a float4 whose first lane is 0.0f where they declare an int, D3)
+            hipLaunchKernelGGL(k_scattering_density, gs, b3, 0, stream, a, order);
+            hipLaunchKernelGGL(k_indirect_irradiance, gi, b2, 0, stream, a, order, L);
+            hipLaunchKernelGGL(k_multiple_scattering, gs, b3, 0, stream, a, L);
+        }
     }
     if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return VPT_E_HIP;
+    return VPT_OK;
+}
+
+static int precompute_textures(vpt_ctx* ctx, vpt_atmosphere_parameters* p) {
     // copy_*_texture (atmosphere.cpp:503-675): float4, normalised, linear; 2-D wrap/clamp, 3-D clamp
     vpt_texture_desc d2 = {TW, TH, 1, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_WRAP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
     vpt_texture_desc d3 = {SW, SH, SD, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_CLAMP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
@@ -668,6 +694,67 @@ int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int nu
     if ((rc = vpt_texture_create_device(ctx, &d3, (const float*)p->scattering_buffer, &p->scattering_texture))) return rc;
     if ((rc = vpt_texture_create_device(ctx, &d3, (const float*)p->optional_mie_single_scattering_buffer, &p->single_mie_scattering_texture))) return rc;
     return VPT_OK;
+}
+
+int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int num_scattering_orders, void* stream_v) {
+    if (!ctx || !p) return VPT_E_INVALID;
+    if (p->use_luminance == 2) return VPT_E_INVALID;         // PRECOMPUTED needs the model's spectra per pass: vpt_atmosphere_precompute_model
+    if (num_scattering_orders < 1) num_scattering_orders = 4;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
+    vpt_invalidate_sky_tables(ctx);      // the per-frame sky tables are keyed on the buffers' addresses, which a re-run keeps
+    int rc = precompute_pass(ctx, p, p, num_scattering_orders, nullptr, 0, false, stream);
+    if (rc != VPT_OK) return rc;
+    return precompute_textures(ctx, p);
+}
+
+// atmosphere::init's precomputation for ANY luminance mode (atmosphere.cpp:1227-1275).  NONE / APPROXIMATE: the model for
+// opt->lambdas and one pass -- vpt_atmosphere_model + vpt_atmosphere_precompute.  PRECOMPUTED: five passes over three wavelengths
+// each (15 between 360 and 830 nm), every pass with its own model scalars (update_model(lambdas), :910), its own
+// luminance-from-radiance matrix (CIE colour matching functions x XYZ->sRGB x dlambda, :1247-1255) and blend = (pass > 0); then the
+// transmittance table once more for opt->lambdas (:1264-1268), whose scalars `atm` ends with.  What the passes leave in the
+// tables is the reference's, port bugs included (D3: calculate_indirect_irradiance / calculate_multiple_scattering never blend,
+// so the irradiance and scattering tables hold the LAST wavelength triple's highest order; calculate_direct_irradiance doubles
+// the table instead of adding to it; only the single-Mie table accumulates, unweighted) -- pinned on the reference's own kernels
+// run through the same sequence (tests/test_gpu_atmosphere_vs_ref.py).
+int vpt_atmosphere_precompute_model(vpt_ctx* ctx, const vpt_atmosphere_model_options* opt, const char* spectra_file,
+                                    vpt_atmosphere_parameters* atm, int num_scattering_orders, void* stream_v) {
+    if (!ctx || !opt || !atm) return VPT_E_INVALID;
+    if (num_scattering_orders < 1) num_scattering_orders = 4;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
+    vpt_atmosphere_parameters fin;
+    int rc = vpt_atmosphere_model(opt, spectra_file, &fin);
+    if (rc != VPT_OK) return rc;
+    if (opt->use_luminance != 2) {
+        *atm = fin;
+        return vpt_atmosphere_precompute(ctx, atm, num_scattering_orders, stream_v);
+    }
+    vpt_invalidate_sky_tables(ctx);
+    std::string path;
+    if (spectra_file && spectra_file[0]) path = spectra_file;
+    else if (!default_spectra_path(path)) return VPT_E_IO;
+    Spectra S;
+    if (!load_spectra(path.c_str(), S)) return VPT_E_IO;
+    const double lmin = S.lmin, lmax = S.lmin + S.step * (S.n - 1);                 // kLambdaMin, kLambdaMax
+    const int num_iterations = (15 + 2) / 3;                                         // num_precomputed_wavelengths() = 15
+    const double dlambda = (lmax - lmin) / (3.0 * num_iterations);
+    *atm = fin;                                                                      // (buffers: allocated by the first pass)
+    for (int i = 0; i < num_iterations; ++i) {
+        vpt_atmosphere_model_options o = *opt;
+        double lfrm[9];
+        for (int j = 0; j < 3; ++j) o.lambdas[j] = lmin + (3 * i + j + 0.5) * dlambda;
+        for (int c = 0; c < 3; ++c)
+            for (int j = 0; j < 3; ++j) {
+                // atmosphere::coeff :137-146
+                const double x = cie_value(S, o.lambdas[j], 1), y = cie_value(S, o.lambdas[j], 2), z = cie_value(S, o.lambdas[j], 3);
+                const double* m = S.xyz2srgb.data();
+                lfrm[3 * c + j] = (m[3 * c] * x + m[3 * c + 1] * y + m[3 * c + 2] * z) * dlambda;
+            }
+        vpt_atmosphere_parameters pass;
+        if ((rc = vpt_atmosphere_model(&o, spectra_file, &pass)) != VPT_OK) return rc;
+        if ((rc = precompute_pass(ctx, atm, &pass, num_scattering_orders, lfrm, i > 0 ? 1 : 0, false, stream)) != VPT_OK) return rc;
+    }
+    if ((rc = precompute_pass(ctx, atm, &fin, num_scattering_orders, nullptr, 0, true, stream)) != VPT_OK) return rc;
+    return precompute_textures(ctx, atm);
 }
 
 int vpt_atmosphere_read_lut(vpt_ctx* ctx, const vpt_atmosphere_parameters* p, int which, float* host_out, size_t n_floats) {

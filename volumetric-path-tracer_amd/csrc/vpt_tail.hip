@@ -20,6 +20,35 @@ namespace vpt {
 // binary32 quotient.  __fdiv_rn is just `a / b` in HIP and follows the approximate-divide flag.
 VPT_D float div1_rn(float a, float b) { return (float)((double)a / (double)b); }
 VPT_D f3 div_rn(f3 a, float b) { return mk3(div1_rn(a.x, b), div1_rn(a.y, b), div1_rn(a.z, b)); }
+// The running means divide by the iteration count: ONE divisor n (an integer in [2, 2^24]) for the four quotients of a sample.
+// For such an n and a numerator of ordinary magnitude the correctly rounded binary32 quotient needs no binary64 and no
+// operand scaling: the reciprocal refined once, then the quotient corrected twice with exact FMA remainders -- the sequence
+// the compiler itself emits for an IEEE `a / b` between its v_div_scale / v_div_fixup brackets, which do nothing in this range
+// (2^-60 <= |a| <= 2^60: every remainder is a normal number).  Zeros return themselves (+-0 / n = +-0); everything else --
+// infinities, NaNs, tiny and huge numerators -- takes the binary64 route above.  Bit-identical to it on every operand
+// (tests/test_gpu_parity.py::test_mean_divide_is_the_ieee_quotient: 2^24 random pairs + the edges).
+struct MeanDiv {
+    float n, r;            // r: 1 / n after one Newton step
+};
+VPT_D MeanDiv mean_div_prepare(float n) {
+    MeanDiv d;
+    d.n = n;
+    const float r0 = __builtin_amdgcn_rcpf(n);
+    const float e = __builtin_fmaf(-n, r0, 1.0f);
+    d.r = __builtin_fmaf(e, r0, r0);
+    return d;
+}
+VPT_D float mean_div1(float a, const MeanDiv& d) {
+    if (a == 0.0f) return a;
+    const float m = fabsf(a);
+    if (!(m >= 8.6736174e-19f && m <= 1.1529215e18f)) return div1_rn(a, d.n);           // outside [2^-60, 2^60], or NaN
+    const float q0 = a * d.r;
+    const float r0 = __builtin_fmaf(-d.n, q0, a);
+    const float q1 = __builtin_fmaf(r0, d.r, q0);
+    const float r1 = __builtin_fmaf(-d.n, q1, a);
+    return __builtin_fmaf(r1, d.r, q1);
+}
+VPT_D f3 mean_div(f3 a, const MeanDiv& d) { return mk3(mean_div1(a.x, d), mean_div1(a.y, d), mean_div1(a.z, d)); }
 VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
     f3 a = v * (v + 0.0245786f) - 0.000090537f;
     f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
@@ -150,11 +179,12 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
             dep = depth;
         } else if (iteration < R.max_interactions) {
             const float n = (float)(local_it + 1);
-            acc = acc + div_rn(value - acc, n);
+            const MeanDiv dn = mean_div_prepare(n);
+            acc = acc + mean_div(value - acc, dn);
             // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
             if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
             else cst = cst + div_rn(mk3(0.0f) - cst, n);
-            dep = dep + div1_rn(depth - dep, n);
+            dep = dep + mean_div1(depth - dep, dn);
         }
         tr_last = tr;
     }
@@ -391,6 +421,18 @@ __global__ void sky_samples_kernel(const ResolveParams R, const float* __restric
 }
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream) {
     hipLaunchKernelGGL(sky_samples_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, origins, dirs, out, n, use_table);
+    return hipGetLastError();
+}
+
+// test hook (vpt_test_mean_divide): the running-mean quotient next to the binary64 route, element-wise
+__global__ void mean_divide_kernel(const float* __restrict__ a, const float* __restrict__ n, float* __restrict__ fast, float* __restrict__ ref, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fast[i] = mean_div1(a[i], mean_div_prepare(n[i]));
+    ref[i] = div1_rn(a[i], n[i]);
+}
+hipError_t launch_mean_divide(const float* a, const float* n, float* fast, float* ref, uint32_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(mean_divide_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, a, n, fast, ref, count);
     return hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
     "vpt_comm_unique_id", "vpt_comm_init_rank", "vpt_comm_destroy", "vpt_allreduce_accum", "vpt_resolve_display",
-    "vpt_atmosphere_default_model", "vpt_atmosphere_model_options_default", "vpt_atmosphere_model", "vpt_atmosphere_precompute", "vpt_atmosphere_read_lut",
+    "vpt_atmosphere_default_model", "vpt_atmosphere_model_options_default", "vpt_atmosphere_model", "vpt_atmosphere_precompute", "vpt_atmosphere_precompute_model", "vpt_atmosphere_read_lut",
     "vpt_env_cdf_build", "vpt_env_cdf_create",
     "vpt_camera_update", "vpt_camera_frame", "vpt_camera_default", "vpt_gpu_vdb_bounds", "vpt_instance_xform", "vpt_kernel_params_default",
 ]
@@ -95,6 +95,7 @@ def load_library(path=None):
     lib.vpt_atmosphere_model_options_default.restype = None
     lib.vpt_atmosphere_model.argtypes = [C.POINTER(abi.AtmosphereModelOptions), C.c_char_p, C.POINTER(AtmosphereParameters)]
     lib.vpt_atmosphere_precompute.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp]
+    lib.vpt_atmosphere_precompute_model.argtypes = [vp, C.POINTER(abi.AtmosphereModelOptions), C.c_char_p, C.POINTER(AtmosphereParameters), C.c_int, vp]
     lib.vpt_atmosphere_read_lut.argtypes = [vp, C.POINTER(AtmosphereParameters), C.c_int, vp, C.c_size_t]
     lib.vpt_env_cdf_build.argtypes = [C.POINTER(KernelParams), C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     lib.vpt_env_cdf_create.argtypes = [vp, C.POINTER(KernelParams)]
