@@ -48,9 +48,6 @@ int vpt_test_get_dir_table_check(vpt_ctx *ctx, float out[8]);
  * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
  * hits through the view-point ground tables (when the last render had them within tolerance), else in full */
 int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float *dirs, int use_table, float *out);
-/* the running means' divide (csrc/vpt_tail.hip: mean_div1, the FMA-corrected quotient by an iteration count) next to the
- * binary64 route it replaces, element-wise over host arrays: fast[i] and ref[i] for a[i] / n[i] */
-int vpt_test_mean_divide(vpt_ctx *ctx, int count, const float *a, const float *n, float *fast, float *ref);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
  * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */
 int vpt_io_test_blosc_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t nbytes_out);

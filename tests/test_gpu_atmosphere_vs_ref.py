@@ -202,7 +202,11 @@ def test_precomputed_luminance_tables_match_reference_kernels_live(pkg, hip_lumi
 
 @pytest.mark.gpu
 def test_render_with_precomputed_luminance_sky(pkg):
-    """a frame under the PRECOMPUTED-luminance sky: HIP vs oracle on the same tables (the render path only sees use_luminance != 0)"""
+    """a frame under the PRECOMPUTED-luminance sky: HIP vs oracle on the same tables (the render path only sees use_luminance != 0).
+    What the reference's five passes leave in the scattering table is the LAST wavelength triple's highest order pushed through an
+    XYZ->sRGB matrix with negative entries: radiances come out negative, the tone curve's pow() of a negative number is NaN, and
+    volume_rt_kernel's NaN guard (:2263) substitutes the running mean -- the mode renders (mostly) black in the reference too.  The
+    test is that HIP and oracle agree on that, pixel for pixel, not that the picture is pretty."""
     import oracle_binding
     sd = pkg.scene.dragon_scene(160, 90, "c2")
     pkg.atmosphere.attach_default_atmosphere(sd, device=0, use_luminance=2)
@@ -212,6 +216,14 @@ def test_render_with_precomputed_luminance_sky(pkg):
     ob = oracle_binding.OracleBinding(sd)
     ob.render(4)
     got = hb.accum.cpu().numpy()
-    assert np.isfinite(got).all() and got.mean() > 1e-3
-    assert rel_l2(got, ob.accum) <= 1e-3
+    assert np.isfinite(got).all() and np.isfinite(ob.accum).all()
+    np.testing.assert_array_equal(got == 0.0, ob.accum == 0.0)                       # the same pixels fall to the NaN guard
+    if ob.accum.any():
+        assert rel_l2(got, ob.accum) <= 1e-3
     np.testing.assert_array_equal(hb.depth.cpu().numpy(), ob.depth)
+    # the APPROXIMATE mode on the same scene is a picture (and the tables differ from it)
+    sa = pkg.scene.dragon_scene(160, 90, "c2")
+    pkg.atmosphere.attach_default_atmosphere(sa, device=0, use_luminance=1)
+    ha = pkg.scene.HipBinding(sa, device=0)
+    ha.render(4); ha.sync()
+    assert ha.accum.cpu().numpy().mean() > 1e-3

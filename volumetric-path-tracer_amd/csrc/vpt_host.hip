@@ -36,7 +36,6 @@ size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
-hipError_t launch_mean_divide(const float* a, const float* n, float* fast, float* ref, uint32_t count, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -820,22 +819,6 @@ int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned 
         *cell = (unsigned int)w;
     }
     return VPT_OK;
-}
-
-int vpt_test_mean_divide(vpt_ctx* ctx, int count, const float* a, const float* n, float* fast, float* ref) {
-    if (!ctx || count <= 0 || !a || !n || !fast || !ref) return VPT_E_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    float* d = nullptr;
-    const size_t bytes = sizeof(float) * (size_t)count;
-    HIPCHK(ctx, hipMalloc(&d, 4 * bytes));
-    HIPCHK(ctx, hipMemcpy(d, a, bytes, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(d + count, n, bytes, hipMemcpyHostToDevice));
-    hipError_t e = launch_mean_divide(d, d + count, d + 2 * (size_t)count, d + 3 * (size_t)count, (uint32_t)count, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(fast, d + 2 * (size_t)count, bytes, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ref, d + 3 * (size_t)count, bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    return e == hipSuccess ? VPT_OK : VPT_E_HIP;
 }
 
 int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {

@@ -20,35 +20,6 @@ namespace vpt {
 // binary32 quotient.  __fdiv_rn is just `a / b` in HIP and follows the approximate-divide flag.
 VPT_D float div1_rn(float a, float b) { return (float)((double)a / (double)b); }
 VPT_D f3 div_rn(f3 a, float b) { return mk3(div1_rn(a.x, b), div1_rn(a.y, b), div1_rn(a.z, b)); }
-// The running means divide by the iteration count: ONE divisor n (an integer in [2, 2^24]) for the four quotients of a sample.
-// For such an n and a numerator of ordinary magnitude the correctly rounded binary32 quotient needs no binary64 and no
-// operand scaling: the reciprocal refined once, then the quotient corrected twice with exact FMA remainders -- the sequence
-// the compiler itself emits for an IEEE `a / b` between its v_div_scale / v_div_fixup brackets, which do nothing in this range
-// (2^-60 <= |a| <= 2^60: every remainder is a normal number).  Zeros return themselves (+-0 / n = +-0); everything else --
-// infinities, NaNs, tiny and huge numerators -- takes the binary64 route above.  Bit-identical to it on every operand
-// (tests/test_gpu_parity.py::test_mean_divide_is_the_ieee_quotient: 2^24 random pairs + the edges).
-struct MeanDiv {
-    float n, r;            // r: 1 / n after one Newton step
-};
-VPT_D MeanDiv mean_div_prepare(float n) {
-    MeanDiv d;
-    d.n = n;
-    const float r0 = __builtin_amdgcn_rcpf(n);
-    const float e = __builtin_fmaf(-n, r0, 1.0f);
-    d.r = __builtin_fmaf(e, r0, r0);
-    return d;
-}
-VPT_D float mean_div1(float a, const MeanDiv& d) {
-    if (a == 0.0f) return a;
-    const float m = fabsf(a);
-    if (!(m >= 8.6736174e-19f && m <= 1.1529215e18f)) return div1_rn(a, d.n);           // outside [2^-60, 2^60], or NaN
-    const float q0 = a * d.r;
-    const float r0 = __builtin_fmaf(-d.n, q0, a);
-    const float q1 = __builtin_fmaf(r0, d.r, q0);
-    const float r1 = __builtin_fmaf(-d.n, q1, a);
-    return __builtin_fmaf(r1, d.r, q1);
-}
-VPT_D f3 mean_div(f3 a, const MeanDiv& d) { return mk3(mean_div1(a.x, d), mean_div1(a.y, d), mean_div1(a.z, d)); }
 VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
     f3 a = v * (v + 0.0245786f) - 0.000090537f;
     f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
@@ -179,12 +150,11 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
             dep = depth;
         } else if (iteration < R.max_interactions) {
             const float n = (float)(local_it + 1);
-            const MeanDiv dn = mean_div_prepare(n);
-            acc = acc + mean_div(value - acc, dn);
+            acc = acc + div_rn(value - acc, n);
             // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
             if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
             else cst = cst + div_rn(mk3(0.0f) - cst, n);
-            dep = dep + mean_div1(depth - dep, dn);
+            dep = dep + div1_rn(depth - dep, n);
         }
         tr_last = tr;
     }
@@ -321,7 +291,7 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     const uint32_t cells = (uint32_t)((S::DT_NX - 1) * (S::DT_NN - 1));
     const uint32_t variant = t / cells, c = t % cells;
     const int k = view->k;
-    if (variant > 2u * (uint32_t)k) return;
+    bool valid = variant <= 2u * (uint32_t)k;              // (no early return: the wave-level sums below need every lane)
     S sky = {R};
     load_sky_view<LENS>(R, sky);
     const uint32_t ix = c / (uint32_t)(S::DT_NN - 1), in = c % (uint32_t)(S::DT_NN - 1);
@@ -332,7 +302,7 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     const f3 up0 = normalize(cam - ec);
     // the origin: `variant - k` binary32 steps of r above / below the camera origin (which variant that lands on is the tail's own
     // decision, below)
-    const float dr = __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)k) - view->r;
+    const float dr = valid ? __uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)k) - view->r : 0.0f;
     f3 pos = cam + up0 * dr;
     if (LENS) {
         // ... and, like the samples behind an open lens, somewhere within a lens radius of it horizontally (a fixed pseudo-random
@@ -347,11 +317,12 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     int cv = 0;
     if (LENS) {
         cv = sky.CamVariant(r, dot(p, sun) * frcp(r));
-        if (cv < 0) return;
-    } else if (variant != 0u) {
-        return;
+        valid = valid && cv >= 0;
+        cv = max(cv, 0);
+    } else {
+        valid = valid && variant == 0u;
     }
-    if (view->tab[cv].w == 0.0f || x > view->tab[cv].z) return;                                // no table / beyond the part that is used
+    valid = valid && view->tab[cv].w != 0.0f && x <= view->tab[cv].z;                          // a table, and within the part that is used
     const f3 up = p * frcp(r);
     const float mu_s = dot(up, sun);
     const float b = sky.bottom();
@@ -359,18 +330,35 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     const float mu = clampf(fdiv(-(h2 + d * d), 2.0f * r * d), -1.0f, 1.0f);
     // a unit vector with view . up = mu and view . sun = nu (two solutions mirrored in the sun's vertical plane: take one)
     const float sv = fsqrt(fmax_(1.0f - mu * mu, 0.0f)), ss = fsqrt(fmax_(1.0f - mu_s * mu_s, 0.0f));
-    if (!(sv * ss > 1e-6f)) return;
+    valid = valid && sv * ss > 1e-6f;
     const float cphi = fdiv(nu - mu * mu_s, sv * ss);
-    if (!(fabsf(cphi) <= 1.0f)) return;                                                        // no view ray has this (mu, nu)
-    const f3 e1 = (sun - up * mu_s) * frcp(ss), e2 = cross(up, e1);
-    const f3 dir = normalize(up * mu + (e1 * cphi + e2 * fsqrt(fmax_(1.0f - cphi * cphi, 0.0f))) * sv);
-    const f3 full = sky.sample(pos, dir, sun, false), tab = sky.sample(pos, dir, sun, true);
-    const float dev = fmax_(fmax_(fabsf(tab.x - full.x), fabsf(tab.y - full.y)), fabsf(tab.z - full.z)) / fmax_(fmax_(fmax_(full.x, full.y), full.z), 1e-30f);
-    const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;
-    unsigned long long* e = err + 8 + 4 * cv;
-    if (bits != 0u) atomicMax(e, ((unsigned long long)bits << 32) | c);
-    atomicAdd(e + 1, 1ull);
-    if (!(dev <= 1e-3f)) atomicAdd(e + 2, 1ull);
+    valid = valid && fabsf(cphi) <= 1.0f;                                                      // else: no view ray has this (mu, nu)
+    float dev = 0.0f;
+    if (valid) {
+        const f3 e1 = (sun - up * mu_s) * frcp(ss), e2 = cross(up, e1);
+        const f3 dir = normalize(up * mu + (e1 * cphi + e2 * fsqrt(fmax_(1.0f - cphi * cphi, 0.0f))) * sv);
+        const f3 full = sky.sample(pos, dir, sun, false), tab = sky.sample(pos, dir, sun, true);
+        dev = fmax_(fmax_(fabsf(tab.x - full.x), fabsf(tab.y - full.y)), fabsf(tab.z - full.z)) / fmax_(fmax_(fmax_(full.x, full.y), full.z), 1e-30f);
+    }
+    const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;                      // NaN compares false everywhere: let it through as a huge error
+    // per variant, one set of atomics per WAVE (a quarter of a million threads on three words otherwise)
+    const int lane = __lane_id();
+    for (int v = 0; v <= 2 * k; ++v) {
+        const unsigned long long m = __ballot(valid && cv == v);
+        if (m == 0ull) continue;
+        const unsigned long long above = __ballot(valid && cv == v && !(dev <= 1e-3f));
+        unsigned long long key = (valid && cv == v) ? (((unsigned long long)bits << 32) | c) : 0ull;
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), s) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, s);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) {
+            unsigned long long* e = err + 8 + 4 * v;
+            if ((key >> 32) != 0ull) atomicMax(e, key);
+            atomicAdd(e + 1, (unsigned long long)__popcll(m));
+            if (above != 0ull) atomicAdd(e + 2, (unsigned long long)__popcll(above));
+        }
+    }
 }
 // The verdicts the tail reads.  Per variant: against real rays through the full path no ray is off by more than 2 % and at most
 // 2 % of them by more than 1e-3 (the image tolerance is 1e-3 rel. L2) -- a variant that fails loses its table (SkyView::tab[v].w = 0:
@@ -421,18 +409,6 @@ __global__ void sky_samples_kernel(const ResolveParams R, const float* __restric
 }
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream) {
     hipLaunchKernelGGL(sky_samples_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, origins, dirs, out, n, use_table);
-    return hipGetLastError();
-}
-
-// test hook (vpt_test_mean_divide): the running-mean quotient next to the binary64 route, element-wise
-__global__ void mean_divide_kernel(const float* __restrict__ a, const float* __restrict__ n, float* __restrict__ fast, float* __restrict__ ref, uint32_t count) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    fast[i] = mean_div1(a[i], mean_div_prepare(n[i]));
-    ref[i] = div1_rn(a[i], n[i]);
-}
-hipError_t launch_mean_divide(const float* a, const float* n, float* fast, float* ref, uint32_t count, hipStream_t stream) {
-    hipLaunchKernelGGL(mean_divide_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, a, n, fast, ref, count);
     return hipGetLastError();
 }
 
