@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VPT_ABI_VERSION 1
+#define VPT_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------- */
 #define VPT_OK              0
@@ -315,9 +315,8 @@ typedef struct vpt_render_stats {
     unsigned long long skip_steps;        /* empty-node pushes                         */
     unsigned long long queued_rays;       /* rays the last batch handed to the tracer  */
     float              trace_ms;          /* HIP-event time of trace_kernel            */
-    float              resolve_ms;        /* 0: the resolve is fused into the tail kernel */
     float              raygen_ms;         /* HIP-event time of raygen_kernel           */
-    float              tail_ms;           /* HIP-event time of tail_resolve_kernel      */
+    float              tail_ms;           /* HIP-event time of tail_resolve_kernel (environment tail + resolve, fused) */
     /* trilinear fetches the tracer actually issued (counting renders): the look-up point lies inside the instance's
      * domain and the value is used -- density / colour (float4 texels) / emission.  The N_* above are the reference-defined
      * counts (every instance of the leaf at every step, :1003-1014, and the colour at every step, :1662). */

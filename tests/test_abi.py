@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(pkg.ABI_SYMBOLS), (declared ^ set(pkg.ABI_SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vpt_abi_version() == 1
+    assert lib.vpt_abi_version() == 2
     # ... and everything the other two headers declare (vpt_io.h: host-side formats, vpt_testhooks.h: probes)
     for h, listed in (("vpt_io.h", set(pkg.io.IO_SYMBOLS)), ("vpt_testhooks.h", None)):
         text = open(os.path.join(ROOT, "include", h)).read()

@@ -28,7 +28,7 @@ for combo in itertools.product(*vals) if vals else [()]:
     best = None
     for _ in range(a.reps):
         hb.render(a.spp, iteration=0); hb.sync(); st = hb.ctx.stats()
-        tot = st.raygen_ms + st.trace_ms + st.tail_ms + st.resolve_ms
+        tot = st.raygen_ms + st.trace_ms + st.tail_ms
         if best is None or tot < best[0]: best = (tot, st.raygen_ms, st.trace_ms, st.tail_ms)
     n = sd.width * sd.height * a.spp
     print(a.config, " ".join("%s=%s" % kv for kv in zip(keys, combo)), "raygen %.3f trace %.3f tail %.3f ms -> %.1f Msamples/s" % (best[1], best[2], best[3], n / best[0] / 1e3), flush=True)

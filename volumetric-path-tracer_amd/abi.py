@@ -139,7 +139,7 @@ class TextureDesc(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_ulonglong), ("density_lookups", C.c_ulonglong), ("color_lookups", C.c_ulonglong),
                 ("emission_lookups", C.c_ulonglong), ("tracking_steps", C.c_ulonglong), ("skip_steps", C.c_ulonglong), ("queued_rays", C.c_ulonglong),
-                ("trace_ms", C.c_float), ("resolve_ms", C.c_float), ("raygen_ms", C.c_float), ("tail_ms", C.c_float),
+                ("trace_ms", C.c_float), ("raygen_ms", C.c_float), ("tail_ms", C.c_float),
                 ("density_fetches", C.c_ulonglong), ("color_fetches", C.c_ulonglong), ("emission_fetches", C.c_ulonglong)]
 
 

@@ -760,8 +760,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[s.e0], ctx->ev_pool[s.e1]));
         if (s.kind == 0) out->raygen_ms += ms;
         else if (s.kind == 1) out->trace_ms += ms;
-        else if (s.kind == 2) out->tail_ms += ms;
-        else out->resolve_ms += ms;
+        else out->tail_ms += ms;
     }
     out->samples = ctx->last_samples;
     {
