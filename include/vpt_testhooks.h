@@ -48,6 +48,9 @@ int vpt_test_get_dir_table_check(vpt_ctx *ctx, float out[8]);
  * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
  * hits through the view-point ground tables (when the last render had them within tolerance), else in full */
 int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float *dirs, int use_table, float *out);
+/* per-pixel sky patches of the last render (csrc/vpt_tail.hip: sky_patch_kernel): pixels of the frame, and how many of them passed
+ * the patch's check (the others evaluate every untraced sample in full); both 0 when the render used no patches */
+int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
  * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */
 int vpt_io_test_blosc_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t nbytes_out);

@@ -221,6 +221,16 @@ struct ResolveParams {
     const float4* heads;
     const float4* head_org;          // origin of a head's ray when the lens is open (thin-lens offset), else NULL: cam_origin
     float cam_origin[3];
+    // Per-pixel SKY PATCH (vpt_tail.hip: sky_patch_kernel; closed lens + direct integrator + procedural sky): the value of an untraced
+    // sample is a function of its primary direction alone, i.e. of the pixel and the sample's jitter (jx, jy) in [0,1)^2 -- smooth
+    // across one pixel except where the horizon or the sun's disc cuts through it.  The patch holds that value at the pixel's four
+    // corners (3 float4 per pixel: v00.rgb v10.rgb v01.rgb v11.rgb); a pixel whose exact centre value the bilinear patch misses by
+    // more than 1e-3 (relative), or that lies within a pixel of the sun's disc, is marked (first word NaN) and evaluates every sample
+    // in full.  Untraced samples of the other pixels -- 70 % of config 2's samples -- cost one jitter look-up and nine FMAs instead of
+    // ~250 instructions of sample_atmosphere.  VALUE-ONLY, like the ground table: a cache of a pure function with a measured bound.
+    const float4* sky_patch;         // [n_pixels][3], or NULL
+    const float2* blue_noise;        // [iter_count][65536]: the chunk's jitter tables (what raygen read), for the patch
+    float cam_llc[3], cam_h[3], cam_v[3];   // camera frame (lower_left_corner, horizontal, vertical), for the patch corners
     float* accum;          // float3[n_pixels]
     float* cost;           // float3[n_pixels] or NULL
     float* depth;          // float[n_pixels] or NULL

@@ -36,6 +36,7 @@ size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -130,6 +131,12 @@ struct vpt_ctx {
     float cam_tab_key[47] = {0};
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
     bool cam_tab_built = false;
+    // per-pixel sky patches of the untraced samples (ResolveParams::sky_patch): rebuilt when the sky tables or the camera frame change
+    float4* d_sky_patch = nullptr;
+    size_t sky_patch_pixels = 0;           // capacity, in pixels
+    float sky_patch_key[16] = {0};         // camera frame, image size, sky_mult, sky_color
+    bool sky_patch_built = false;
+    bool no_sky_patch = false;             // VPT_NO_SKY_PATCH: every untraced sample evaluated in full (tests)
     hipEvent_t tab_event = nullptr;        // recorded behind the table kernels; a render on ANOTHER stream waits for it
     hipStream_t tab_stream = nullptr;      // the stream the tables were built on
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
@@ -329,6 +336,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_heads = std::getenv("VPT_NO_HEADS") != nullptr;
     ctx->no_cam_table = std::getenv("VPT_NO_CAM_TABLE") != nullptr;
     ctx->no_dir_table = std::getenv("VPT_NO_DIR_TABLE") != nullptr;
+    ctx->no_sky_patch = std::getenv("VPT_NO_SKY_PATCH") != nullptr;
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -368,6 +376,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_head_org);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_pool_hist);
+    (void)hipFree(ctx->d_sky_patch);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);
@@ -390,6 +399,7 @@ int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
     if (!ctx) return VPT_E_INVALID;
     ctx->cam_tab_built = false;
     ctx->dir_tab_built = false;
+    ctx->sky_patch_built = false;
     return VPT_OK;
 }
 
@@ -817,6 +827,22 @@ int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned 
         std::memcpy(err, &hi, sizeof(float));
         *cell = (unsigned int)w;
     }
+    return VPT_OK;
+}
+
+int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, unsigned long long* with_patch) {
+    if (!ctx || !pixels || !with_patch) return VPT_E_INVALID;
+    *pixels = *with_patch = 0;
+    if (!ctx->sky_patch_built || !ctx->have_last_resolve || !ctx->last_resolve.sky_patch) return VPT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const size_t n = ctx->last_resolve.n_pixels;
+    std::vector<float> first(n);
+    HIPCHK(ctx, hipMemcpy2D(first.data(), sizeof(float), ctx->d_sky_patch, 3 * sizeof(float4), sizeof(float), n, hipMemcpyDeviceToHost));
+    unsigned long long ok = 0;
+    for (size_t i = 0; i < n; ++i) ok += first[i] == first[i] ? 1ull : 0ull;
+    *pixels = n;
+    *with_patch = ok;
     return VPT_OK;
 }
 
@@ -1306,6 +1332,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
             ctx->cam_tab_built = true;
             ctx->dir_tab_built = false;
+            ctx->sky_patch_built = false;
         }
         R.cam_tab_valid = 1;
         // view-point ground tables (vpt_sky.h): the direct integrator's procedural sky; which variants get one (view point between
@@ -1326,6 +1353,30 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             }
             R.dir_tab = ctx->d_dir_tab;
             R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
+        }
+        // per-pixel sky patches (ResolveParams::sky_patch): untraced samples behind a closed lens, direct integrator, procedural sky, heads
+        if (!ctx->no_sky_patch && compact && cam->lens_radius == 0.0f && kp->integrator == 0 && kp->environment_type == 0) {
+            const float pk[16] = {cam->lower_left_corner.x, cam->lower_left_corner.y, cam->lower_left_corner.z, cam->horizontal.x, cam->horizontal.y, cam->horizontal.z,
+                                  cam->vertical.x, cam->vertical.y, cam->vertical.z, (float)W, (float)H, kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z,
+                                  (ctx->no_dir_table ? 0.0f : 1.0f) + ctx->dir_tab_tol};
+            for (int i = 0; i < 3; ++i) { R.cam_llc[i] = pk[i]; R.cam_h[i] = pk[3 + i]; R.cam_v[i] = pk[6 + i]; }
+            if (ctx->sky_patch_pixels < (size_t)n_pixels) {
+                if (ctx->tab_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+                HIPCHK(ctx, hipStreamSynchronize(stream));
+                (void)hipFree(ctx->d_sky_patch); ctx->d_sky_patch = nullptr; ctx->sky_patch_pixels = 0;
+                HIPCHK(ctx, hipMalloc(&ctx->d_sky_patch, (size_t)n_pixels * 3u * sizeof(float4)));
+                ctx->sky_patch_pixels = n_pixels;
+                ctx->sky_patch_built = false;
+            }
+            if (!ctx->sky_patch_built || std::memcmp(pk, ctx->sky_patch_key, sizeof(pk)) != 0) {
+                if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+                tables_written = true;
+                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, stream));
+                std::memcpy(ctx->sky_patch_key, pk, sizeof(pk));
+                ctx->sky_patch_built = true;
+            }
+            R.sky_patch = ctx->d_sky_patch;
+            R.blue_noise = ctx->d_bn_table;
         }
         // stream order: the tables are built on the stream of the render that needed them; a later render on another stream
         // reuses them only behind the event recorded after that build

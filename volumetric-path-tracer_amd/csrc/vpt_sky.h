@@ -445,7 +445,9 @@ struct Sky {
         return true;
     }
     // sample_atmosphere :839-895.  use_dir_tab: ground hits seen from the table's view point come from the ground table
-    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction, bool use_dir_tab = false) const {
+    // kind (optional): which evaluation the direction took -- 0 sky, 1 ground through the table, 2 ground in full (the one whose
+    // binary32 ground point makes it noisy from ray to ray: the per-pixel sky patches keep away from it)
+    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction, bool use_dir_tab = false, int* kind = nullptr) const {
         const f3 earth_center = mk3(.0f, -bottom(), .0f);
         const f3 p = ray_pos - earth_center;
         const float p_dot_v = dot(p, ray_dir);
@@ -469,7 +471,9 @@ struct Sky {
         }
         if (dist > 0.0f && use_dir_tab && cv >= 0 && GroundFromTable(p, r_view, mu_s_view, ray_pos + ray_dir * dist - earth_center, sun_direction, cv, radiance)) {
             // radiance from the view-point ground table
+            if (kind) *kind = 1;
         } else if (dist > 0.0f) {
+            if (kind) *kind = 2;
             const f3 pt = ray_pos + ray_dir * dist - earth_center;
             const float r = length(pt);
             const float inv_r = frcp(r);
@@ -485,6 +489,7 @@ struct Sky {
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits
         } else {
+            if (kind) *kind = 0;
             f3 tr_sky;
             const bool in_disc = dot(ray_dir, sun_direction) > f(AF_COS_SUN);
             radiance = SkyRadiance(p, ray_dir, sun_direction, tr_sky, cv, in_disc);

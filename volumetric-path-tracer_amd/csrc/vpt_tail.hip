@@ -66,9 +66,74 @@ VPT_D void load_sky_view(const ResolveParams& R, Sky<ResolveParams>& sky) {
 
 // HEADS: samples that start no walk arrive as 16-byte heads (+ origins when the lens is open) instead of 64-byte records
 // (ResolveParams).  Two instantiations: each keeps its own register budget (the kernel spills at 4 waves per SIMD).
+// per-pixel sky patch (ResolveParams::sky_patch): one thread per pixel evaluates the untraced-sample value at the pixel's four
+// corners and at its centre, keeps the corners when the bilinear patch reproduces the centre to 1e-3
+__global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, float4* __restrict__ out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R.n_pixels) return;
+    const uint32_t y = idx / R.width, x = idx - y * R.width;
+    Sky<ResolveParams> sky = {R};
+    load_sky_view<false>(R, sky);
+    const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
+    const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const f3 org = mk3(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2]);
+    const f3 llc = mk3(R.cam_llc[0], R.cam_llc[1], R.cam_llc[2]), ch = mk3(R.cam_h[0], R.cam_h[1], R.cam_h[2]), cv = mk3(R.cam_v[0], R.cam_v[1], R.cam_v[2]);
+    const f3 scale = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]) * R.sky_mult;
+    const float inv_w = frcp((float)R.width), inv_h = frcp((float)R.height);
+    auto ray = [&](float jx, float jy) {                     // camera::get_ray with a closed lens (camera.h:131-136)
+        const float u = ((float)x + jx) * inv_w, v = ((float)y + jy) * inv_h;
+        return normalize(llc + ch * u + cv * v - org);
+    };
+    const f3 d00 = ray(0.0f, 0.0f), d11 = ray(1.0f, 1.0f), dc = ray(0.5f, 0.5f);
+    int k00, k10, k01, k11, kc;
+    const f3 v00 = sky.sample(org, d00, sun_dir, use_dir_tab, &k00) * scale, v10 = sky.sample(org, ray(1.0f, 0.0f), sun_dir, use_dir_tab, &k10) * scale;
+    const f3 v01 = sky.sample(org, ray(0.0f, 1.0f), sun_dir, use_dir_tab, &k01) * scale, v11 = sky.sample(org, d11, sun_dir, use_dir_tab, &k11) * scale;
+    const f3 vc = sky.sample(org, dc, sun_dir, use_dir_tab, &kc) * scale;
+    const f3 pred = (v00 + v10 + v01 + v11) * 0.25f;
+    const float dev = fmax_(fmax_(fabsf(pred.x - vc.x), fabsf(pred.y - vc.y)), fabsf(pred.z - vc.z));
+    const float ref = fmax_(fmax_(fabsf(vc.x), fabsf(vc.y)), fabsf(vc.z));
+    // 1e-3 of the centre value: sample_atmosphere itself is only that smooth -- the reference's binary32 `r^2 mu^2 - r^2 + bottom^2`
+    // (vpt_sky.h: ScatteringUvwz) is a staircase in mu with steps of ~1e-4 of the radiance between neighbouring directions, while
+    // what the check is for, the horizon or the sun's disc cutting through the pixel, moves the centre by 1e-2 and more
+    bool ok = dev <= 1e-3f * ref || (dev == 0.0f && ref == 0.0f);               // (NaNs fail the comparison)
+    // the sun's disc can be smaller than a pixel and miss all five probes: keep a pixel's diagonal away from it
+    const f3 dd = d00 - d11;
+    const float diag = fsqrt(dot(dd, dd));
+    const float ang = __builtin_amdgcn_sqrtf(fmax_(2.0f - 2.0f * dot(dc, sun_dir), 0.0f));   // chord ~ angle between pixel centre and sun
+    const float disc = fsqrt(fmax_(2.0f - 2.0f * sky.f(AF_COS_SUN), 0.0f));
+    if (ang <= disc + diag) ok = false;
+    // a ground hit evaluated in full (grazing rays, or no ground table) rounds its ground point to binary32 at earth-radius
+    // magnitude and jumps by up to 1-2 % from ray to ray (vpt_sky.h): per sample that is noise which averages out, frozen into a
+    // patch corner it would be a bias -- such pixels keep the per-sample evaluation
+    if (k00 == 2 || k10 == 2 || k01 == 2 || k11 == 2 || kc == 2) ok = false;
+    float4* o = out + 3u * (size_t)idx;
+    o[0] = make_float4(ok ? v00.x : __uint_as_float(0x7fc00000u), v00.y, v00.z, v10.x);
+    o[1] = make_float4(v10.y, v10.z, v01.x, v01.y);
+    o[2] = make_float4(v01.z, v11.x, v11.y, v11.z);
+}
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_patch_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R, out);
+    return hipGetLastError();
+}
+
 template <bool HEADS, bool LENS>
 __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // the pixel's sky patch, parked in LDS ([word][thread]); usable: the pixel has one and it passed its check
+    __shared__ float s_patch[12 * 256];
+    bool patch = false;
+    uint32_t bn_idx = 0;
+    if (HEADS && !LENS && R.sky_patch != nullptr && idx < R.n_pixels) {
+        const float4* pp = R.sky_patch + 3u * (size_t)idx;
+        const float4 a = pp[0], b = pp[1], c = pp[2];
+        patch = a.x == a.x;
+        float* s = s_patch + threadIdx.x;
+        s[0] = a.x; s[256] = a.y; s[512] = a.z; s[768] = a.w;
+        s[1024] = b.x; s[1280] = b.y; s[1536] = b.z; s[1792] = b.w;
+        s[2048] = c.x; s[2304] = c.y; s[2560] = c.z; s[2816] = c.w;
+        const uint32_t py = idx / R.width, px = idx - py * R.width;
+        bn_idx = (py & 255u) * 256u + (px & 255u);
+    }
     if (idx >= R.n_pixels) return;
     f3 acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
     f3 cst = R.cost ? mk3(R.cost[3 * idx], R.cost[3 * idx + 1], R.cost[3 * idx + 2]) : mk3(0.0f);
@@ -95,7 +160,20 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         if (HEADS) {
             const float4 h = h_next;
             if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
-            if (h.w != -1.0f) {
+            if (!LENS && patch && h.w >= 0.0f) {
+                // an untraced sample of a pixel with a sky patch: its value is the patch at the sample's jitter (L = 0, beta = 1)
+                const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];
+                const float* s = s_patch + threadIdx.x;
+                const f3 v00 = mk3(s[0], s[256], s[512]), v10 = mk3(s[768], s[1024], s[1280]);
+                const f3 v01 = mk3(s[1536], s[1792], s[2048]), v11 = mk3(s[2304], s[2560], s[2816]);
+                const f3 lo = flerp3(v00, v10, j.x), hi = flerp3(v01, v11, j.x);
+                const f3 val = flerp3(lo, hi, j.y);
+                q0 = make_float4(val.x, val.y, val.z, 0.0f);
+                q1 = make_float4(1.0f, 1.0f, 1.0f, h.w);
+                q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(0u));      // flags 0: nothing left to add
+                q3 = make_float4(h.x, h.y, h.z, 0.0f);
+                from_record = false;
+            } else if (h.w != -1.0f) {
                 // no 64-byte record: a primary ray that started no walk (or a sample that is not rendered)
                 const bool rendered = h.w >= 0.0f;
                 const float l = rendered ? 0.0f : 1.0f, b = rendered ? 1.0f : 0.0f;
