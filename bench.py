@@ -307,6 +307,11 @@ def main():
                         "vs_full_path_along_real_rays": {"rays_centre_variant": int(chk[2]), "max_relative_difference": float(chk[1]), "accepted_below": 2e-2,
                                                          "fraction_above_1e-3": (float(chk[3]) / float(chk[2])) if chk[2] else None, "accepted_fraction": 0.02,
                                                          "all_variants_max": float(chk[6]), "all_variants_largest_fraction_above_1e-3": float(chk[7])}}
+                pa, pb = C.c_ulonglong(0), C.c_ulonglong(0)
+                lib.vpt_test_get_sky_patch_coverage.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+                if lib.vpt_test_get_sky_patch_coverage(hb.ctx.h, C.byref(pa), C.byref(pb)) == 0:
+                    # per-pixel sky patches: pixels whose untraced samples take their sky value from a checked bilinear patch
+                    out["config"]["sky_patch"] = {"pixels": int(pa.value), "with_patch": int(pb.value), "centre_check_relative": 1e-3}
             except Exception as e:                                    # reporting only
                 out["config"]["sky_ground_table"] = {"error": str(e)}
             if not with_extras and not multi and not args.no_parity:
