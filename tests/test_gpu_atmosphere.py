@@ -396,3 +396,41 @@ def test_sky_patch_matches_full_evaluation(pkg, sky, monkeypatch, view):
         ob = oracle_binding.OracleBinding(sd)
         ob.render(n)
         assert rel_l2(x, ob.accum) <= 5e-4 and rel_l2(y, ob.accum) <= 5e-4, (rel_l2(x, ob.accum), rel_l2(y, ob.accum))
+
+
+@pytest.mark.parametrize("view", ["default", "horizon in view", "sphere in view", "inside the box", "render off"])
+def test_never_traced_pixels_change_nothing(pkg, sky, monkeypatch, view):
+    """Pixels whose whole jitter footprint misses the volumes' root box and the reference sphere -- screen-space bounds grown by three
+    pixels, the `B == 0` line of sphere::intersect kept out (csrc/vpt_host.hip: project_box, vpt_tail.hip: sky_patch_kernel) -- and that
+    have a sky patch are skipped by raygen altogether; the tail takes their samples from the patch.  Against VPT_NO_PIXEL_CULL=1:
+    every buffer and every count bit-identical, and some pixels really were skipped (except from inside the box)."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    w, h = 320, 180
+    sd = pkg.scene.dragon_scene(w, h, "c2")
+    lib = pkg.load_library()
+    if view == "horizon in view":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(40.0, 3.0, 5.0), Float3(0.0, 3.0, 0.0), Float3(0, 1, 0), 70.0, w / h, 0.0)
+    if view == "sphere in view":
+        o = sd.camera.origin
+        sd.sphere.center = Float3(o.x * 0.55, o.y * 0.55 + 1.0, o.z * 0.55 - 2.0)
+        sd.sphere.radius = 1.5
+    if view == "inside the box":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(0.3, 0.2, 0.1), Float3(5.0, 1.0, 2.0), Float3(0, 1, 0), 60.0, w / h, 0.0)
+    if view == "render off":
+        sd.kp.max_interactions = 2                       # iterations 2.. are not rendered (volume_rt_kernel :2254)
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(True)
+        hb.render(4); hb.sync()
+        return hb, hb.ctx.stats()
+    a, sa = run()
+    monkeypatch.setenv("VPT_NO_PIXEL_CULL", "1")
+    b, sb = run()
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy(), err_msg=buf)
+    for k in ("samples", "density_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+        assert getattr(sa, k) == getattr(sb, k), k
+    assert sa.samples == w * h * 4

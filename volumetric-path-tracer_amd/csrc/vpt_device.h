@@ -145,6 +145,8 @@ struct TraceParams {
     const float2* blue_noise;        // [iter_count][65536] (x,y) jitter of each iteration
     Counters* counters;              // may be NULL
     Counters* prof;                  // section cycle counters of -DVPT_PROFILE_SECTIONS builds (else unused)
+    const unsigned char* never_traced;   // [n_pixels] or NULL: 1 = no primary ray of this pixel can start a walk and its samples' values come
+                                     // from the pixel's sky patch (ResolveParams::never_traced): raygen emits nothing for it
     float* pool_hist;                // pool tracer (vpt_trace_pool.hip): density histories of the fused first walk, [workgroup][entry][ray]
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera
@@ -231,6 +233,19 @@ struct ResolveParams {
     const float4* sky_patch;         // [n_pixels][3], or NULL
     const float2* blue_noise;        // [iter_count][65536]: the chunk's jitter tables (what raygen read), for the patch
     float cam_llc[3], cam_h[3], cam_v[3];   // camera frame (lower_left_corner, horizontal, vertical), for the patch corners
+    // NEVER-TRACED pixels (written by sky_patch_kernel next to the patches): a pixel whose whole jitter footprint lies outside the
+    // screen-space bounds of the volumes' root box (cull_rect, in pixels, already grown by the margin), whose rays all pass the
+    // reference sphere at more than its radius INFLATED by what the binary32 discriminant of sphere::intersect can lose
+    // (B^2 - 4AC cancels to ~36 eps D^2 at distance D: false hits out to sqrt(r^2 + 9 eps D^2), several pixels at 1080p), away from
+    // the line on which that function's `B == 0` case reports a hit at distance 0 whatever the sphere's place (geometry.h:118-121:
+    // cull_line, a x + b y + c in pixels), and that has a patch: raygen skips it altogether (no ray, no head), the tail takes every
+    // sample's value from the patch.  cull_enabled = 0: a box corner at or behind the camera plane, the origin on a slab plane, ...
+    int cull_enabled;
+    float cull_rect[4];              // root box: x0, y0, x1, y1
+    float cull_line[3];
+    float cull_sph[4];               // reference sphere: centre, radius
+    int render;                      // kernel_params.render (a pixel without heads has to know whether its samples are rendered)
+    const unsigned char* never_traced;      // [n_pixels] or NULL (read by the tail); unsigned char* for sky_patch_kernel to write
     float* accum;          // float3[n_pixels]
     float* cost;           // float3[n_pixels] or NULL
     float* depth;          // float[n_pixels] or NULL

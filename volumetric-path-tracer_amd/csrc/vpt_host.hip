@@ -36,7 +36,7 @@ size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
-hipError_t launch_sky_patch(const ResolveParams& R, float4* out, hipStream_t stream);
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -133,10 +133,12 @@ struct vpt_ctx {
     bool cam_tab_built = false;
     // per-pixel sky patches of the untraced samples (ResolveParams::sky_patch): rebuilt when the sky tables or the camera frame change
     float4* d_sky_patch = nullptr;
+    unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
     size_t sky_patch_pixels = 0;           // capacity, in pixels
-    float sky_patch_key[16] = {0};         // camera frame, image size, sky_mult, sky_color
+    float sky_patch_key[40] = {0};         // camera frame, image size, sky_mult, sky_color, the cull bounds
     bool sky_patch_built = false;
     bool no_sky_patch = false;             // VPT_NO_SKY_PATCH: every untraced sample evaluated in full (tests)
+    bool no_pixel_cull = false;            // VPT_NO_PIXEL_CULL: raygen emits every pixel's samples (tests)
     hipEvent_t tab_event = nullptr;        // recorded behind the table kernels; a render on ANOTHER stream waits for it
     hipStream_t tab_stream = nullptr;      // the stream the tables were built on
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
@@ -337,6 +339,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_cam_table = std::getenv("VPT_NO_CAM_TABLE") != nullptr;
     ctx->no_dir_table = std::getenv("VPT_NO_DIR_TABLE") != nullptr;
     ctx->no_sky_patch = std::getenv("VPT_NO_SKY_PATCH") != nullptr;
+    ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -377,6 +380,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_pool_hist);
     (void)hipFree(ctx->d_sky_patch);
+    (void)hipFree(ctx->d_never_traced);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);
@@ -494,6 +498,34 @@ __global__ void quads_kernel(const float* __restrict__ src, float4* __restrict__
     const int j0 = max(jc - 1, 0), j1 = min(jc, dy - 1), k0 = max(kc - 1, 0), k1 = min(kc, dz - 1);
     dst[o] = make_float4(src[((size_t)k0 * dy + j0) * dx + x], src[((size_t)k0 * dy + j1) * dx + x],
                          src[((size_t)k1 * dy + j0) * dx + x], src[((size_t)k1 * dy + j1) * dx + x]);
+}
+
+// Screen-space bounds, in pixels, of the world box [lo, hi] as camera::get_ray (camera.h:131-136, closed lens) sees it: a world point
+// X is hit by the ray of image-plane coordinates (u, v) with X - o = s (llc - o + u h + v vert), s > 0.  false: a corner at or
+// behind the camera plane (no bound can be given).
+static bool project_box(const vpt_camera* cam, const double lo[3], const double hi[3], double W, double H, double rect[4]) {
+    const double o[3] = {cam->origin.x, cam->origin.y, cam->origin.z};
+    const double A[3] = {cam->lower_left_corner.x - o[0], cam->lower_left_corner.y - o[1], cam->lower_left_corner.z - o[2]};
+    const double hv[3] = {cam->horizontal.x, cam->horizontal.y, cam->horizontal.z}, vv[3] = {cam->vertical.x, cam->vertical.y, cam->vertical.z};
+    const double n[3] = {hv[1] * vv[2] - hv[2] * vv[1], hv[2] * vv[0] - hv[0] * vv[2], hv[0] * vv[1] - hv[1] * vv[0]};
+    auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    const double an = dot3(A, n), hh = dot3(hv, hv), vvv = dot3(vv, vv), hvv = dot3(hv, vv);
+    const double det = hh * vvv - hvv * hvv;
+    if (!(std::fabs(an) > 0.0) || !(det > 0.0)) return false;
+    rect[0] = rect[1] = 1e300; rect[2] = rect[3] = -1e300;
+    for (int c = 0; c < 8; ++c) {
+        const double X[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+        const double d[3] = {X[0] - o[0], X[1] - o[1], X[2] - o[2]};
+        const double s = dot3(d, n) / an;
+        if (!(s > 1e-6)) return false;
+        const double q[3] = {d[0] / s - A[0], d[1] / s - A[1], d[2] / s - A[2]};
+        const double qh = dot3(q, hv), qv = dot3(q, vv);
+        const double u = (qh * vvv - qv * hvv) / det, v = (qv * hh - qh * hvv) / det;
+        if (!std::isfinite(u) || !std::isfinite(v)) return false;
+        rect[0] = std::min(rect[0], u * W); rect[2] = std::max(rect[2], u * W);
+        rect[1] = std::min(rect[1], v * H); rect[3] = std::max(rect[3], v * H);
+    }
+    return true;
 }
 
 // ---- scene ------------------------------------------------------------------------------------
@@ -1356,27 +1388,60 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         }
         // per-pixel sky patches (ResolveParams::sky_patch): untraced samples behind a closed lens, direct integrator, procedural sky, heads
         if (!ctx->no_sky_patch && compact && cam->lens_radius == 0.0f && kp->integrator == 0 && kp->environment_type == 0) {
-            const float pk[16] = {cam->lower_left_corner.x, cam->lower_left_corner.y, cam->lower_left_corner.z, cam->horizontal.x, cam->horizontal.y, cam->horizontal.z,
-                                  cam->vertical.x, cam->vertical.y, cam->vertical.z, (float)W, (float)H, kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z,
-                                  (ctx->no_dir_table ? 0.0f : 1.0f) + ctx->dir_tab_tol};
+            float pk[40] = {cam->lower_left_corner.x, cam->lower_left_corner.y, cam->lower_left_corner.z, cam->horizontal.x, cam->horizontal.y, cam->horizontal.z,
+                            cam->vertical.x, cam->vertical.y, cam->vertical.z, (float)W, (float)H, kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z,
+                            (ctx->no_dir_table ? 0.0f : 1.0f) + ctx->dir_tab_tol};
             for (int i = 0; i < 3; ++i) { R.cam_llc[i] = pk[i]; R.cam_h[i] = pk[3 + i]; R.cam_v[i] = pk[6 + i]; }
+            // never-traced pixels: screen-space bounds of the root box grown by 3 pixels (the rounding of a slab test moves a hit by ~eps / pixel
+            // angle: a tenth of a pixel at most), the sphere by its inflated radius per pixel (sky_patch_kernel), and the line
+            // dir . (origin - centre) = 0 of sphere::intersect's B == 0 case.  No culling when a box corner is at or behind the camera plane,
+            // or the origin sits exactly on a slab plane (0 x inf in the slab test).
+            R.render = kp->render ? 1 : 0;
+            R.cull_enabled = 0;
+            if (!ctx->no_pixel_cull) {
+                const double blo[3] = {P.root_pmin[0], P.root_pmin[1], P.root_pmin[2]}, bhi[3] = {P.root_pmax[0], P.root_pmax[1], P.root_pmax[2]};
+                double rb[4];
+                const double o[3] = {cam->origin.x, cam->origin.y, cam->origin.z};
+                bool on_plane = false;
+                for (int i = 0; i < 3; ++i) on_plane = on_plane || o[i] == blo[i] || o[i] == bhi[i];
+                if (!on_plane && project_box(cam, blo, bhi, (double)W, (double)H, rb)) {
+                    const double m = 3.0;
+                    for (int i = 0; i < 2; ++i) { R.cull_rect[i] = (float)(rb[i] - m); R.cull_rect[2 + i] = (float)(rb[2 + i] + m); }
+                    const double orig[3] = {o[0] - ref_sphere->center.x, o[1] - ref_sphere->center.y, o[2] - ref_sphere->center.z};
+                    const double A[3] = {cam->lower_left_corner.x - o[0], cam->lower_left_corner.y - o[1], cam->lower_left_corner.z - o[2]};
+                    R.cull_line[0] = (float)((cam->horizontal.x * orig[0] + cam->horizontal.y * orig[1] + cam->horizontal.z * orig[2]) / (double)W);
+                    R.cull_line[1] = (float)((cam->vertical.x * orig[0] + cam->vertical.y * orig[1] + cam->vertical.z * orig[2]) / (double)H);
+                    R.cull_line[2] = (float)(A[0] * orig[0] + A[1] * orig[1] + A[2] * orig[2]);
+                    R.cull_sph[0] = ref_sphere->center.x; R.cull_sph[1] = ref_sphere->center.y; R.cull_sph[2] = ref_sphere->center.z;
+                    R.cull_sph[3] = ref_sphere->radius;
+                    R.cull_enabled = 1;
+                }
+            }
+            pk[16] = (float)R.cull_enabled; pk[17] = (float)R.render;
+            std::memcpy(pk + 18, R.cull_rect, sizeof(float) * 4);
+            std::memcpy(pk + 22, R.cull_line, sizeof(float) * 3);
+            std::memcpy(pk + 25, R.cull_sph, sizeof(float) * 4);
             if (ctx->sky_patch_pixels < (size_t)n_pixels) {
                 if (ctx->tab_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
                 HIPCHK(ctx, hipStreamSynchronize(stream));
                 (void)hipFree(ctx->d_sky_patch); ctx->d_sky_patch = nullptr; ctx->sky_patch_pixels = 0;
+                (void)hipFree(ctx->d_never_traced); ctx->d_never_traced = nullptr;
                 HIPCHK(ctx, hipMalloc(&ctx->d_sky_patch, (size_t)n_pixels * 3u * sizeof(float4)));
+                HIPCHK(ctx, hipMalloc(&ctx->d_never_traced, (size_t)n_pixels));
                 ctx->sky_patch_pixels = n_pixels;
                 ctx->sky_patch_built = false;
             }
             if (!ctx->sky_patch_built || std::memcmp(pk, ctx->sky_patch_key, sizeof(pk)) != 0) {
                 if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
                 tables_written = true;
-                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, stream));
+                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, stream));
                 std::memcpy(ctx->sky_patch_key, pk, sizeof(pk));
                 ctx->sky_patch_built = true;
             }
             R.sky_patch = ctx->d_sky_patch;
             R.blue_noise = ctx->d_bn_table;
+            R.never_traced = ctx->d_never_traced;
+            P.never_traced = ctx->d_never_traced;
         }
         // stream order: the tables are built on the stream of the render that needed them; a later render on another stream
         // reuses them only behind the event recorded after that build

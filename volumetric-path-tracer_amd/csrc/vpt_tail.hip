@@ -68,7 +68,7 @@ VPT_D void load_sky_view(const ResolveParams& R, Sky<ResolveParams>& sky) {
 // (ResolveParams).  Two instantiations: each keeps its own register budget (the kernel spills at 4 waves per SIMD).
 // per-pixel sky patch (ResolveParams::sky_patch): one thread per pixel evaluates the untraced-sample value at the pixel's four
 // corners and at its centre, keeps the corners when the bilinear patch reproduces the centre to 1e-3
-__global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, float4* __restrict__ out, unsigned char* __restrict__ never) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
     const uint32_t y = idx / R.width, x = idx - y * R.width;
@@ -110,9 +110,35 @@ __global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, f
     o[0] = make_float4(ok ? v00.x : __uint_as_float(0x7fc00000u), v00.y, v00.z, v10.x);
     o[1] = make_float4(v10.y, v10.z, v01.x, v01.y);
     o[2] = make_float4(v01.z, v11.x, v11.y, v11.z);
+    // never-traced pixels (ResolveParams::cull_*): the pixel's square [x, x+1] x [y, y+1] against the grown bounds
+    if (never) {
+        bool nt = ok && R.cull_enabled != 0;
+        const float fx = (float)x, fy = (float)y;
+        if (fx + 1.0f >= R.cull_rect[0] && fx <= R.cull_rect[2] && fy + 1.0f >= R.cull_rect[1] && fy <= R.cull_rect[3]) nt = false;
+        {
+            // the sphere: perpendicular distance of its centre from the pixel's centre ray against the inflated radius + the pixel's reach
+            const f3 oc = mk3(R.cull_sph[0], R.cull_sph[1], R.cull_sph[2]) - org;
+            const float D2 = dot(oc, oc), tca = dot(oc, dc);
+            const float eps = 1.1920929e-7f;
+            const float r2 = R.cull_sph[3] * R.cull_sph[3] + 64.0f * eps * D2;
+            if (tca > 0.0f || D2 <= r2) {                        // (a sphere behind a ray that starts outside it is never hit: both roots negative)
+                const float reach = fsqrt(r2) + fsqrt(D2) * diag * 1.5f;
+                if (D2 - tca * tca - 16.0f * eps * D2 <= reach * reach) nt = false;
+            }
+        }
+        const float la = R.cull_line[0], lb = R.cull_line[1], lc = R.cull_line[2];
+        const float ln = la * la + lb * lb;
+        if (ln > 0.0f) {
+            const float dist = fabsf(la * (fx + 0.5f) + lb * (fy + 0.5f) + lc) * __builtin_amdgcn_rsqf(ln);
+            if (!(dist > 4.0f)) nt = false;                                            // half a diagonal + 3 pixels
+        } else if (lc == 0.0f) {
+            nt = false;
+        }
+        never[idx] = nt ? 1 : 0;
+    }
 }
-hipError_t launch_sky_patch(const ResolveParams& R, float4* out, hipStream_t stream) {
-    hipLaunchKernelGGL(sky_patch_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R, out);
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_patch_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R, out, never);
     return hipGetLastError();
 }
 
@@ -122,11 +148,13 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     // the pixel's sky patch, parked in LDS ([word][thread]); usable: the pixel has one and it passed its check
     __shared__ float s_patch[12 * 256];
     bool patch = false;
+    bool never = false;              // no heads exist for this pixel (ResolveParams::never_traced): every sample is untraced, depth 0
     uint32_t bn_idx = 0;
     if (HEADS && !LENS && R.sky_patch != nullptr && idx < R.n_pixels) {
         const float4* pp = R.sky_patch + 3u * (size_t)idx;
         const float4 a = pp[0], b = pp[1], c = pp[2];
         patch = a.x == a.x;
+        never = R.never_traced != nullptr && R.never_traced[idx] != 0;
         float* s = s_patch + threadIdx.x;
         s[0] = a.x; s[256] = a.y; s[512] = a.z; s[768] = a.w;
         s[1024] = b.x; s[1280] = b.y; s[1536] = b.z; s[1792] = b.w;
@@ -150,7 +178,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
     // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
-    float4 h_next = HEADS ? R.heads[idx] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    float4 h_next = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    if (HEADS && !never) h_next = R.heads[idx];
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
         const uint32_t local_it = local_it0 + k;
@@ -158,8 +187,13 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         float4 q0, q1, q2, q3;
         bool from_record = true;
         if (HEADS) {
-            const float4 h = h_next;
-            if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
+            float4 h = h_next;
+            if (never) {
+                // (raygen wrote nothing for this pixel: what its head would say)
+                h.w = (iteration < R.max_interactions && R.render) ? 0.0f : -2.0f;
+            } else if (k + 1u < R.iter_count) {
+                h_next = R.heads[slot + R.n_pixels];
+            }
             if (!LENS && patch && h.w >= 0.0f) {
                 // an untraced sample of a pixel with a sky patch: its value is the patch at the sample's jitter (L = 0, beta = 1)
                 const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];

@@ -77,7 +77,13 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
         const int y = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
         bool enqueue = false;
         uint32_t s = 0;
-        if (x < (int)P.width && y < (int)P.height) {
+        bool live = x < (int)P.width && y < (int)P.height;
+        if (live && P.never_traced && P.never_traced[(uint32_t)y * P.width + (uint32_t)x]) {
+            // no ray of this pixel can start a walk and the tail has its samples' values (ResolveParams::never_traced): nothing to emit
+            live = false;
+            n_final++;
+        }
+        if (live) {
             const uint32_t pixel = (uint32_t)y * P.width + (uint32_t)x;
             s = kiter * P.n_pixels + pixel;
             const float2 bn = P.blue_noise[(size_t)kiter * 65536 + (y % 256) * 256 + (x % 256)];
