@@ -177,9 +177,53 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
 
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
+    // what volume_rt_kernel does with a sample value (:2263-2287): NaN guard, viz_dof tint, running means
+    auto accumulate = [&](f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it) {
+        // :2263-2264
+        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
+        if (isnan(tr) || isinf(tr)) tr = 1.0f;
+        // :2266-2274
+        if (R.viz_dof) {
+            float aof = clampf(__fdiv_rn(1.0f, R.lens_radius), .0f, 3.402823466e+38F);
+            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
+            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
+            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
+        }
+        // :2278-2287 (cost is always BLACK, :2249)
+        if (local_it == 0) {
+            acc = value;
+            cst = mk3(0.0f);
+            dep = depth;
+        } else if (iteration < R.max_interactions) {
+            const float n = (float)(local_it + 1);
+            acc = acc + div_rn(value - acc, n);
+            // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
+            if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+            else cst = cst + div_rn(mk3(0.0f) - cst, n);
+            dep = dep + div1_rn(depth - dep, n);
+        }
+        tr_last = tr;
+    };
+    if (never) {
+        // a pixel raygen emitted nothing for (ResolveParams::never_traced): every sample is untraced with depth 0, its value the patch at the
+        // sample's jitter -- or WHITE when the sample is not rendered (:2248, :2254).  No head, no record, no sky code: waves over the background
+        // run this loop only.
+        const float* s = s_patch + threadIdx.x;
+        const f3 v00 = mk3(s[0], s[256], s[512]), v10 = mk3(s[768], s[1024], s[1280]);
+        const f3 v01 = mk3(s[1536], s[1792], s[2048]), v11 = mk3(s[2304], s[2560], s[2816]);
+        for (uint32_t k = 0; k < R.iter_count; ++k) {
+            const uint32_t iteration = R.iter_begin + k * R.iter_stride;
+            f3 value = mk3(1.0f);
+            if (iteration < R.max_interactions && R.render) {
+                const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];
+                value = flerp3(flerp3(v00, v10, j.x), flerp3(v01, v11, j.x), j.y);
+            }
+            accumulate(value, 0.0f, 0.0f, iteration, local_it0 + k);
+        }
+    } else {
     // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
     float4 h_next = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    if (HEADS && !never) h_next = R.heads[idx];
+    if (HEADS) h_next = R.heads[idx];
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
         const uint32_t local_it = local_it0 + k;
@@ -187,13 +231,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         float4 q0, q1, q2, q3;
         bool from_record = true;
         if (HEADS) {
-            float4 h = h_next;
-            if (never) {
-                // (raygen wrote nothing for this pixel: what its head would say)
-                h.w = (iteration < R.max_interactions && R.render) ? 0.0f : -2.0f;
-            } else if (k + 1u < R.iter_count) {
-                h_next = R.heads[slot + R.n_pixels];
-            }
+            const float4 h = h_next;
+            if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
             if (!LENS && patch && h.w >= 0.0f) {
                 // an untraced sample of a pixel with a sky patch: its value is the patch at the sample's jitter (L = 0, beta = 1)
                 const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];
@@ -245,30 +284,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }
         }
-        // :2263-2264
-        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
-        if (isnan(tr) || isinf(tr)) tr = 1.0f;
-        // :2266-2274
-        if (R.viz_dof) {
-            float aof = clampf(__fdiv_rn(1.0f, R.lens_radius), .0f, 3.402823466e+38F);
-            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
-            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
-            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
-        }
-        // :2278-2287 (cost is always BLACK, :2249)
-        if (local_it == 0) {
-            acc = value;
-            cst = mk3(0.0f);
-            dep = depth;
-        } else if (iteration < R.max_interactions) {
-            const float n = (float)(local_it + 1);
-            acc = acc + div_rn(value - acc, n);
-            // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
-            if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
-            else cst = cst + div_rn(mk3(0.0f) - cst, n);
-            dep = dep + div1_rn(depth - dep, n);
-        }
-        tr_last = tr;
+        accumulate(value, tr, depth, iteration, local_it);
+    }
     }
     R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;
     if (R.cost) { R.cost[3 * idx] = cst.x; R.cost[3 * idx + 1] = cst.y; R.cost[3 * idx + 2] = cst.z; }
