@@ -73,12 +73,25 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     const int lane = __lane_id();
     const bool rendered = iteration < P.max_interactions && P.render;
     uint32_t n_final = 0;
+    // the never-traced flags of this thread's pixels (one per pass), requested together up front: one memory latency per thread
+    // instead of a dependent load at the head of every pass
+    uint32_t never_bits = 0;
+#ifndef VPT_AB_NO_NEVER
+    if (P.never_traced && x < (int)P.width) {
+#pragma unroll
+        for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
+            const int yy = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
+            const uint32_t f = yy < (int)P.height ? (uint32_t)P.never_traced[(uint32_t)yy * P.width + (uint32_t)x] : 0u;
+            never_bits |= (f & 1u) << pass;
+        }
+    }
+#endif
     for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
         const int y = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
         bool enqueue = false;
         uint32_t s = 0;
         bool live = x < (int)P.width && y < (int)P.height;
-        if (live && P.never_traced && P.never_traced[(uint32_t)y * P.width + (uint32_t)x]) {
+        if (live && ((never_bits >> pass) & 1u)) {
             // no ray of this pixel can start a walk and the tail has its samples' values (ResolveParams::never_traced): nothing to emit
             live = false;
             n_final++;
