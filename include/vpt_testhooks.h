@@ -48,6 +48,10 @@ int vpt_test_get_dir_table_check(vpt_ctx *ctx, float out[8]);
  * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
  * hits through the view-point ground tables (when the last render had them within tolerance), else in full */
 int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float *dirs, int use_table, float *out);
+/* screen-space bounds, in pixels (x0, y0, x1, y1, not grown by any margin), of the world box [lo, hi] as the closed-lens camera::get_ray
+ * sees it -- what the never-traced pixel mask of the renderer is built from (csrc/vpt_host.hip: project_box).  Host only.
+ * VPT_E_UNSUPPORTED: a corner lies at or behind the camera plane (no bound; the renderer then skips nothing). */
+int vpt_test_project_box(const vpt_camera *cam, const float lo[3], const float hi[3], int width, int height, float rect[4]);
 /* per-pixel sky patches of the last render (csrc/vpt_tail.hip: sky_patch_kernel): pixels of the frame, and how many of them passed
  * the patch's check (the others evaluate every untraced sample in full); both 0 when the render used no patches */
 int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);

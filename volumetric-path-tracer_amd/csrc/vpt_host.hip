@@ -862,6 +862,15 @@ int vpt_test_get_dir_table_error(vpt_ctx* ctx, int* built, float* err, unsigned 
     return VPT_OK;
 }
 
+int vpt_test_project_box(const vpt_camera* cam, const float lo[3], const float hi[3], int width, int height, float rect[4]) {
+    if (!cam || !lo || !hi || !rect || width <= 0 || height <= 0) return VPT_E_INVALID;
+    const double l[3] = {lo[0], lo[1], lo[2]}, h[3] = {hi[0], hi[1], hi[2]};
+    double r[4];
+    if (!project_box(cam, l, h, (double)width, (double)height, r)) return VPT_E_UNSUPPORTED;       // a corner at or behind the camera plane
+    for (int i = 0; i < 4; ++i) rect[i] = (float)r[i];
+    return VPT_OK;
+}
+
 int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, unsigned long long* with_patch) {
     if (!ctx || !pixels || !with_patch) return VPT_E_INVALID;
     *pixels = *with_patch = 0;
