@@ -52,6 +52,9 @@ int vpt_test_sky_samples(vpt_ctx *ctx, int n, const float *origins, const float 
  * sees it -- what the never-traced pixel mask of the renderer is built from (csrc/vpt_host.hip: project_box).  Host only.
  * VPT_E_UNSUPPORTED: a corner lies at or behind the camera plane (no bound; the renderer then skips nothing). */
 int vpt_test_project_box(const vpt_camera *cam, const float lo[3], const float hi[3], int width, int height, float rect[4]);
+/* the sphere half of that mask (csrc/vpt_cull.h: sphere_may_hit): 1 when a primary ray within `diag` (chord) of the unit direction
+ * dir_centre could make sphere::intersect report a hit -- its binary32 discriminant included --, 0 when none can.  Host only. */
+int vpt_test_sphere_may_hit(const float org[3], const float dir_centre[3], float diag, const float sphere[4]);
 /* per-pixel sky patches of the last render (csrc/vpt_tail.hip: sky_patch_kernel): pixels of the frame, and how many of them passed
  * the patch's check (the others evaluate every untraced sample in full); both 0 when the render used no patches */
 int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);

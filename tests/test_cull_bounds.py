@@ -84,3 +84,57 @@ def test_projection_refuses_boxes_that_reach_behind_the_camera(pkg):
     assert lib.vpt_test_project_box(C.byref(cam), (C.c_float * 3)(-1, -1, 3), (C.c_float * 3)(1, 1, 5), 320, 180, C.byref(rect)) != 0    # all behind
     assert lib.vpt_test_project_box(C.byref(cam), (C.c_float * 3)(-1, -1, -9), (C.c_float * 3)(1, 1, -7), 320, 180, C.byref(rect)) == 0
     assert rect[0] < 160 < rect[2] and rect[1] < 90 < rect[3]
+
+
+def _sphere_intersect_f32(o, d, c, r):
+    """sphere::intersect + find_discr (geometry/geometry.h:46-70, 114-137) on binary32 arrays, operation by operation -> hit mask"""
+    f = np.float32
+    ox, oy, oz = (o[:, 0] - c[0]).astype(f), (o[:, 1] - c[1]).astype(f), (o[:, 2] - c[2]).astype(f)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    A = ((dx * dx).astype(f) + (dy * dy).astype(f)).astype(f) + (dz * dz).astype(f)
+    B = f(2) * (((dx * ox).astype(f) + (dy * oy).astype(f)).astype(f) + (dz * oz).astype(f))
+    C = (((ox * ox).astype(f) + (oy * oy).astype(f)).astype(f) + (oz * oz).astype(f)) - f(r) * f(r)
+    with np.errstate(all="ignore"):
+        discr = (B * B).astype(f) - ((f(4) * A).astype(f) * C).astype(f)
+        sq = np.sqrt(discr).astype(f)
+        q = np.where(B < 0, f(-0.5) * (B - sq), f(-0.5) * (B + sq)).astype(f)
+        x1 = (q / A).astype(f); x2 = (C / q).astype(f)
+        tmin = np.minimum(x1, x2); tmax = np.maximum(x1, x2)
+    hit = (discr >= 0) & ((tmin >= 0) | (tmax >= 0)) & (B != 0)
+    return hit
+
+
+def test_inflated_sphere_bounds_every_reported_hit(pkg):
+    """sphere::intersect decides with a binary32 discriminant that cancels catastrophically when the sphere is far away: it reports hits for
+    rays that pass the centre at many radii (a unit sphere 19 km away: out to ~10 units).  The never-traced mask's sphere test
+    (csrc/vpt_cull.h: sphere_may_hit) must say "may hit" for every ray the reference's arithmetic reports as a hit."""
+    lib = pkg.load_library()
+    lib.vpt_test_sphere_may_hit.argtypes = [C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, C.POINTER(C.c_float * 4)]
+    rng = np.random.default_rng(17)
+    reported = beyond_radius = 0
+    for D, r in ((19000.0, 1.0), (1000.0, 1.0), (300.0, 0.5), (50.0, 2.0), (6.0, 1.5), (2.0e5, 3.0)):
+        c = np.array([0.0, 1000.0, 0.0], np.float32)
+        dirn = rng.standard_normal(3); dirn /= np.linalg.norm(dirn)
+        o = (c + dirn * D).astype(np.float32)
+        n = 200000
+        # rays aimed at points within a few inflated radii of the centre
+        spread = 6.0 * np.sqrt(r * r + 64 * 1.19e-7 * D * D)
+        target = c + rng.uniform(-spread, spread, (n, 3))
+        d = (target - o); d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+        hit = _sphere_intersect_f32(np.tile(o, (n, 1)), d, c, r)
+        p = np.linalg.norm(np.cross((c - o).astype(np.float64), d.astype(np.float64)), axis=1)      # true distance of the centre from each ray
+        reported += int(hit.sum())
+        beyond_radius += int((hit & (p > 1.5 * r)).sum())
+        sph = (C.c_float * 4)(c[0], c[1], c[2], r)
+        for i in np.flatnonzero(hit)[:4000]:
+            assert lib.vpt_test_sphere_may_hit((C.c_float * 3)(*o), (C.c_float * 3)(*d[i]), 0.0, sph) == 1, (D, r, p[i])
+        # ... and the test does cull: rays passing at 20 inflated radii, or pointing away, cannot hit
+        far = np.flatnonzero(p > 3.0 * spread)
+        for i in far[:200]:
+            assert not hit[i]
+        away = (-d[0]).astype(np.float32)
+        assert lib.vpt_test_sphere_may_hit((C.c_float * 3)(*o), (C.c_float * 3)(*away), 0.0, sph) == 0
+        wide = (c + np.array([40.0 * spread, 0, 0]) - o); wide = (wide / np.linalg.norm(wide)).astype(np.float32)
+        if 40.0 * spread < 0.5 * D:
+            assert lib.vpt_test_sphere_may_hit((C.c_float * 3)(*o), (C.c_float * 3)(*wide), 0.0, sph) == 0
+    assert reported > 1000 and beyond_radius > 20        # the cancellation is real: hits well outside the geometric sphere were seen

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libvpt_hip.so")
-HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", "vpt_trace_common.h", "vpt_walk.h", "vpt_trace_direct.h", "vpt_tex.h", "vpt_sky.h", os.path.join("..", "..", "include", "vpt_abi.h"),
+HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", "vpt_trace_common.h", "vpt_walk.h", "vpt_trace_direct.h", "vpt_tex.h", "vpt_sky.h", "vpt_cull.h", os.path.join("..", "..", "include", "vpt_abi.h"),
            os.path.join("..", "..", "include", "vpt_testhooks.h"),
            os.path.join("..", "..", "include", "vpt_io.h")]
 

@@ -22,6 +22,7 @@
 #include "../../include/vpt_abi.h"
 #include "../../include/vpt_testhooks.h"
 #include "vpt_device.h"
+#include "vpt_cull.h"
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
@@ -869,6 +870,11 @@ int vpt_test_project_box(const vpt_camera* cam, const float lo[3], const float h
     if (!project_box(cam, l, h, (double)width, (double)height, r)) return VPT_E_UNSUPPORTED;       // a corner at or behind the camera plane
     for (int i = 0; i < 4; ++i) rect[i] = (float)r[i];
     return VPT_OK;
+}
+
+int vpt_test_sphere_may_hit(const float org[3], const float dir_centre[3], float diag, const float sphere[4]) {
+    if (!org || !dir_centre || !sphere) return VPT_E_INVALID;
+    return sphere_may_hit(mk3(org[0], org[1], org[2]), mk3(dir_centre[0], dir_centre[1], dir_centre[2]), diag, sphere) ? 1 : 0;
 }
 
 int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, unsigned long long* with_patch) {

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "vpt_sky.h"
+#include "vpt_cull.h"
 
 namespace vpt {
 
@@ -115,17 +116,7 @@ __global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, f
         bool nt = ok && R.cull_enabled != 0;
         const float fx = (float)x, fy = (float)y;
         if (fx + 1.0f >= R.cull_rect[0] && fx <= R.cull_rect[2] && fy + 1.0f >= R.cull_rect[1] && fy <= R.cull_rect[3]) nt = false;
-        {
-            // the sphere: perpendicular distance of its centre from the pixel's centre ray against the inflated radius + the pixel's reach
-            const f3 oc = mk3(R.cull_sph[0], R.cull_sph[1], R.cull_sph[2]) - org;
-            const float D2 = dot(oc, oc), tca = dot(oc, dc);
-            const float eps = 1.1920929e-7f;
-            const float r2 = R.cull_sph[3] * R.cull_sph[3] + 64.0f * eps * D2;
-            if (tca > 0.0f || D2 <= r2) {                        // (a sphere behind a ray that starts outside it is never hit: both roots negative)
-                const float reach = fsqrt(r2) + fsqrt(D2) * diag * 1.5f;
-                if (D2 - tca * tca - 16.0f * eps * D2 <= reach * reach) nt = false;
-            }
-        }
+        if (sphere_may_hit(org, dc, diag, R.cull_sph)) nt = false;
         const float la = R.cull_line[0], lb = R.cull_line[1], lc = R.cull_line[2];
         const float ln = la * la + lb * lb;
         if (ln > 0.0f) {
