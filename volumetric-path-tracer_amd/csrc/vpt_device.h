@@ -25,6 +25,11 @@ enum { GRID_DENSE = 0, GRID_BRICKS = 1, GRID_QUADS = 2 };
 
 // view point of the environment tail's per-frame tables (vpt_sky.h), device-resident
 enum { SKY_VIEW_MAX_K = 4 };
+#ifndef VPT_SKY_DOME_NU
+#define VPT_SKY_DOME_NU 2048     // (4096 x 2048 and 1024 x 512 measured: the same tail time; 2048 x 1024 = 33 MB, 0.18-degree cells)
+#define VPT_SKY_DOME_NV 1024
+#endif
+enum { SKY_DOME_NU = VPT_SKY_DOME_NU, SKY_DOME_NV = VPT_SKY_DOME_NV };          // sky dome nodes (ResolveParams::sky_dome): float4 each
 enum { SKY_DIR_ERR_WORDS = 8 + 4 * (2 * SKY_VIEW_MAX_K + 1) };   // u64 words of the ground table's build-time check (vpt_tail.hip: launch_sky_dir_table)
 struct SkyView {
     float r, mu_s;         // of the camera origin, with the tail's own arithmetic
@@ -231,6 +236,14 @@ struct ResolveParams {
     // in full.  Untraced samples of the other pixels -- 70 % of config 2's samples -- cost one jitter look-up and nine FMAs instead of
     // ~250 instructions of sample_atmosphere.  VALUE-ONLY, like the ground table: a cache of a pure function with a measured bound.
     const float4* sky_patch;         // [n_pixels][3], or NULL
+    // SKY DOME (vpt_tail.hip: sky_dome_kernel; same conditions as the patches): a TRACED sample's environment term is
+    // beta x sample_atmosphere(env_pos, dir) x sky_mult x sky_color with env_pos = the camera origin unless the path bounced off the
+    // sphere, i.e. a function of the exit direction alone -- tabulated once per view over the whole sphere of directions
+    // (SKY_DOME_NU x SKY_DOME_NV = 2048 x 1024 nodes: rows uniform in dir.y, columns in the L1 azimuth x / (|x| + |z|), no trigonometry either way),
+    // with one flag per CELL: its bilinear interpolant reproduces the exact value at the cell's centre to 1e-3, no probe of the cell is
+    // a ground hit evaluated in full, the sun's disc is more than a cell away.  A sample whose direction falls into a flagged cell
+    // costs four float4 reads and nine FMAs instead of sample_atmosphere; the others are evaluated as before.  VALUE-ONLY.
+    const float4* sky_dome;          // [SKY_DOME_NV][SKY_DOME_NU] {value.rgb, cell flag}, or NULL
     const float2* blue_noise;        // [iter_count][65536]: the chunk's jitter tables (what raygen read), for the patch
     float cam_llc[3], cam_h[3], cam_v[3];   // camera frame (lower_left_corner, horizontal, vertical), for the patch corners
     // NEVER-TRACED pixels (written by sky_patch_kernel next to the patches): a pixel whose whole jitter footprint lies outside the

@@ -38,6 +38,7 @@ size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
 hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream);
+hipError_t launch_sky_dome(const ResolveParams& R, float4* out, hipStream_t stream);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -133,10 +134,14 @@ struct vpt_ctx {
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
     bool cam_tab_built = false;
     // per-pixel sky patches of the untraced samples (ResolveParams::sky_patch): rebuilt when the sky tables or the camera frame change
+    float4* d_sky_dome = nullptr;              // sky dome (ResolveParams::sky_dome), rebuilt with the patches
+    bool no_sky_dome = false;                  // VPT_NO_SKY_DOME (tests)
     float4* d_sky_patch = nullptr;
     unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
     size_t sky_patch_pixels = 0;           // capacity, in pixels
     float sky_patch_key[40] = {0};         // camera frame, image size, sky_mult, sky_color, the cull bounds
+    float sky_patch_seen[40] = {0};        // the same of the previous render call, built or not
+    bool sky_patch_seen_valid = false;
     bool sky_patch_built = false;
     bool no_sky_patch = false;             // VPT_NO_SKY_PATCH: every untraced sample evaluated in full (tests)
     bool no_pixel_cull = false;            // VPT_NO_PIXEL_CULL: raygen emits every pixel's samples (tests)
@@ -341,6 +346,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_dir_table = std::getenv("VPT_NO_DIR_TABLE") != nullptr;
     ctx->no_sky_patch = std::getenv("VPT_NO_SKY_PATCH") != nullptr;
     ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
+    ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -381,6 +387,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_pool_hist);
     (void)hipFree(ctx->d_sky_patch);
+    (void)hipFree(ctx->d_sky_dome);
     (void)hipFree(ctx->d_never_traced);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
@@ -1451,18 +1458,33 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 ctx->sky_patch_pixels = n_pixels;
                 ctx->sky_patch_built = false;
             }
-            if (!ctx->sky_patch_built || std::memcmp(pk, ctx->sky_patch_key, sizeof(pk)) != 0) {
+            // The patches, the mask and the dome cost ~0.3 ms to build: they are built for a batch (>= 2 iterations), or once a view repeats (the
+            // progressive render of a still camera, main.cpp:1822-1829 frame after frame) -- a camera that moves every frame with one iteration
+            // per frame never pays for them.
+            const bool built_for_this = ctx->sky_patch_built && std::memcmp(pk, ctx->sky_patch_key, sizeof(pk)) == 0;
+            const bool view_repeats = ctx->sky_patch_seen_valid && std::memcmp(pk, ctx->sky_patch_seen, sizeof(pk)) == 0;
+            std::memcpy(ctx->sky_patch_seen, pk, sizeof(pk));
+            ctx->sky_patch_seen_valid = true;
+            const bool use_caches = built_for_this || iter_count >= 2u || view_repeats;
+            if (use_caches && !built_for_this) {
                 if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
                 tables_written = true;
                 HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, stream));
+                if (!ctx->no_sky_dome) {
+                    if (!ctx->d_sky_dome) HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sizeof(float4) * (size_t)SKY_DOME_NU * (size_t)SKY_DOME_NV));
+                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_dome, stream));
+                }
                 std::memcpy(ctx->sky_patch_key, pk, sizeof(pk));
                 ctx->sky_patch_built = true;
             }
-            R.sky_patch = ctx->d_sky_patch;
-            R.blue_noise = ctx->d_bn_table;
-            if (R.cull_enabled) {
-                R.never_traced = ctx->d_never_traced;
-                P.never_traced = ctx->d_never_traced;
+            if (use_caches) {
+                R.sky_patch = ctx->d_sky_patch;
+                R.sky_dome = ctx->no_sky_dome ? nullptr : ctx->d_sky_dome;
+                R.blue_noise = ctx->d_bn_table;
+                if (R.cull_enabled) {
+                    R.never_traced = ctx->d_never_traced;
+                    P.never_traced = ctx->d_never_traced;
+                }
             }
         }
         // stream order: the tables are built on the stream of the render that needed them; a later render on another stream

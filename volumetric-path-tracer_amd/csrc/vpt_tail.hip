@@ -133,6 +133,84 @@ hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* 
     return hipGetLastError();
 }
 
+// ---- sky dome (ResolveParams::sky_dome) ------------------------------------------------------------------------------------------
+// direction <-> dome coordinates: v = dir.y in [-1, 1] (rows), u in [0, 4) the L1 azimuth in the xz plane: t = x / (|x| + |z|),
+// u = 1 - t for z >= 0 (x runs +1 -> -1), u = 3 + t for z < 0 (x runs -1 -> +1); periodic, piecewise smooth with its kinks (the axes) on nodes
+VPT_D void dome_coords(f3 d, float& fu, float& fv) {
+    const float s = fabsf(d.x) + fabsf(d.z);
+    const float tt = s > 0.0f ? d.x * frcp(s) : 1.0f;
+    const float u = d.z >= 0.0f ? 1.0f - tt : 3.0f + tt;
+    fu = u * (float)(SKY_DOME_NU / 4);
+    fv = fmin_(fmax_(ffma(d.y, 0.5f, 0.5f), 0.0f), 1.0f) * (float)(SKY_DOME_NV - 1);
+}
+VPT_D f3 dome_direction(float fu, float fv) {
+    const float v = clampf(ffma(fv, 2.0f / (float)(SKY_DOME_NV - 1), -1.0f), -1.0f, 1.0f);
+    float u = fu * (4.0f / (float)SKY_DOME_NU);
+    u = u >= 4.0f ? u - 4.0f : u;
+    const bool front = u <= 2.0f;
+    const float tt = front ? 1.0f - u : u - 3.0f;
+    const float x = tt, z = (1.0f - fabsf(tt)) * (front ? 1.0f : -1.0f);
+    const float rxz = fsqrt(fmax_(1.0f - v * v, 0.0f)) * frcp(fsqrt(x * x + z * z));
+    return mk3(x * rxz, v, z * rxz);
+}
+// one thread per cell (i, j): its four corner nodes and its centre, evaluated from the camera origin; writes node (i, j) and the cell's flag
+__global__ __launch_bounds__(256) void sky_dome_kernel(const ResolveParams R, float4* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV) return;
+    const uint32_t j = t / (uint32_t)SKY_DOME_NU, i = t - j * (uint32_t)SKY_DOME_NU;
+    Sky<ResolveParams> sky = {R};
+    load_sky_view<false>(R, sky);
+    const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
+    const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const f3 org = mk3(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2]);
+    const f3 scale = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]) * R.sky_mult;
+    const float fi = (float)i, fj = (float)j;
+    const f3 d00 = dome_direction(fi, fj);
+    int k00 = 0, k10 = 0, k01 = 0, k11 = 0, kc = 0;
+    const f3 v00 = sky.sample(org, d00, sun_dir, use_dir_tab, &k00) * scale;
+    bool ok = false;
+    if (j + 1u < (uint32_t)SKY_DOME_NV) {
+        const f3 d11 = dome_direction(fi + 1.0f, fj + 1.0f), dc = dome_direction(fi + 0.5f, fj + 0.5f);
+        const f3 v10 = sky.sample(org, dome_direction(fi + 1.0f, fj), sun_dir, use_dir_tab, &k10) * scale;
+        const f3 v01 = sky.sample(org, dome_direction(fi, fj + 1.0f), sun_dir, use_dir_tab, &k01) * scale;
+        const f3 v11 = sky.sample(org, d11, sun_dir, use_dir_tab, &k11) * scale;
+        const f3 vc = sky.sample(org, dc, sun_dir, use_dir_tab, &kc) * scale;
+        const f3 pred = (v00 + v10 + v01 + v11) * 0.25f;
+        const float dev = fmax_(fmax_(fabsf(pred.x - vc.x), fabsf(pred.y - vc.y)), fabsf(pred.z - vc.z));
+        const float ref = fmax_(fmax_(fabsf(vc.x), fabsf(vc.y)), fabsf(vc.z));
+        ok = dev <= 1e-3f * ref || (dev == 0.0f && ref == 0.0f);
+        const f3 dd = d00 - d11;
+        const float diag = fsqrt(dot(dd, dd));
+        const float ang = fsqrt(fmax_(2.0f - 2.0f * dot(dc, sun_dir), 0.0f));
+        const float disc = fsqrt(fmax_(2.0f - 2.0f * sky.f(AF_COS_SUN), 0.0f));
+        if (ang <= disc + diag) ok = false;
+        if (k00 == 2 || k10 == 2 || k01 == 2 || k11 == 2 || kc == 2) ok = false;
+    }
+    out[t] = make_float4(v00.x, v00.y, v00.z, ok ? 1.0f : 0.0f);
+}
+hipError_t launch_sky_dome(const ResolveParams& R, float4* out, hipStream_t stream) {
+    const uint32_t n = (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV;
+    hipLaunchKernelGGL(sky_dome_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, out);
+    return hipGetLastError();
+}
+// the dome's value along d (ResolveParams::sky_dome); false: the cell is flagged, evaluate in full
+VPT_D bool dome_lookup(const float4* __restrict__ dome, f3 d, f3& value) {
+    float fu, fv;
+    dome_coords(d, fu, fv);
+    const float flu = floorf(fu), flv = fminf(floorf(fv), (float)(SKY_DOME_NV - 2));
+    const float au = fu - flu, av = fv - flv;
+    uint32_t i0 = (uint32_t)flu;
+    i0 = i0 >= (uint32_t)SKY_DOME_NU ? i0 - (uint32_t)SKY_DOME_NU : i0;
+    const uint32_t i1 = i0 + 1u == (uint32_t)SKY_DOME_NU ? 0u : i0 + 1u;
+    const uint32_t r0 = (uint32_t)flv * (uint32_t)SKY_DOME_NU, r1 = r0 + (uint32_t)SKY_DOME_NU;
+    const float4 a = dome[r0 + i0];
+    if (a.w == 0.0f) return false;
+    const float4 b = dome[r0 + i1], c = dome[r1 + i0], e = dome[r1 + i1];
+    const f3 lo = flerp3(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), au), hi = flerp3(mk3(c.x, c.y, c.z), mk3(e.x, e.y, e.z), au);
+    value = flerp3(lo, hi, av);
+    return true;
+}
+
 template <bool HEADS, bool LENS>
 __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,7 +348,15 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 // procedural sky, no sky_mult / sky_color, whatever environment_type says
                 value += beta * sky.sample(env_pos, dir, sun_dir);
             } else if (R.environment_type == 0) {                                   // :1838-1842
-                if (R.has_atmosphere) value += sky.sample(env_pos, dir, sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
+                if (R.has_atmosphere) {
+                    // a sample that looks from the camera origin (no sphere bounce) along a direction whose dome cell passed its check: the dome
+                    f3 dv;
+                    if (!LENS && R.sky_dome != nullptr && env_pos.x == R.cam_origin[0] && env_pos.y == R.cam_origin[1] && env_pos.z == R.cam_origin[2] &&
+                        dome_lookup(R.sky_dome, dir, dv))
+                        value += dv * beta;
+                    else
+                        value += sky.sample(env_pos, dir, sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
+                }
             } else {                                                                 // :1843-1850
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }
