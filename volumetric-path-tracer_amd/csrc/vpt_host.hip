@@ -38,7 +38,8 @@ size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
 hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream);
-hipError_t launch_sky_dome(const ResolveParams& R, float4* out, hipStream_t stream);
+hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* out, int k, hipStream_t stream);
+size_t sky_dome_bytes(int k);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
 hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
@@ -134,7 +135,10 @@ struct vpt_ctx {
     const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
     bool cam_tab_built = false;
     // per-pixel sky patches of the untraced samples (ResolveParams::sky_patch): rebuilt when the sky tables or the camera frame change
-    float4* d_sky_dome = nullptr;              // sky dome (ResolveParams::sky_dome), rebuilt with the patches
+    float4* d_sky_dome = nullptr;              // sky dome(s) (ResolveParams::sky_dome), rebuilt with the patches (closed lens) / the tables (open lens)
+    int sky_dome_k = -1;                       // variants the allocation holds: 2 k + 1
+    bool lens_dome_built = false;              // open lens: domes valid for the current camera-point tables
+    float lens_dome_key[4] = {0};              // sky_mult, sky_color
     bool no_sky_dome = false;                  // VPT_NO_SKY_DOME (tests)
     float4* d_sky_patch = nullptr;
     unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
@@ -1471,8 +1475,12 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 tables_written = true;
                 HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, stream));
                 if (!ctx->no_sky_dome) {
-                    if (!ctx->d_sky_dome) HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sizeof(float4) * (size_t)SKY_DOME_NU * (size_t)SKY_DOME_NV));
-                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_dome, stream));
+                    if (ctx->sky_dome_k < 0) {
+                        HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sky_dome_bytes(0)));
+                        ctx->sky_dome_k = 0;
+                    }
+                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_view, ctx->d_sky_dome, 0, stream));
+                    ctx->lens_dome_built = false;
                 }
                 std::memcpy(ctx->sky_patch_key, pk, sizeof(pk));
                 ctx->sky_patch_built = true;
@@ -1485,6 +1493,30 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                     R.never_traced = ctx->d_never_traced;
                     P.never_traced = ctx->d_never_traced;
                 }
+            }
+        }
+        // open lens: one dome per table variant (vpt_tail.hip: sky_dome_kernel<true>), for batches; traced AND untraced samples use them
+        if (!ctx->no_sky_dome && compact && cam->lens_radius != 0.0f && kp->integrator == 0 && kp->environment_type == 0) {
+            const float dk[4] = {kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z};
+            const bool valid = ctx->lens_dome_built && ctx->sky_patch_built && ctx->sky_dome_k >= view_k && std::memcmp(dk, ctx->lens_dome_key, sizeof(dk)) == 0;
+            if (valid || iter_count >= 2u) {
+                if (!valid) {
+                    if (ctx->sky_dome_k < view_k) {
+                        if (ctx->tab_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+                        HIPCHK(ctx, hipStreamSynchronize(stream));
+                        (void)hipFree(ctx->d_sky_dome); ctx->d_sky_dome = nullptr; ctx->sky_dome_k = -1;
+                        HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sky_dome_bytes(view_k)));
+                        ctx->sky_dome_k = view_k;
+                    }
+                    if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
+                    tables_written = true;
+                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_view, ctx->d_sky_dome, view_k, stream));
+                    std::memcpy(ctx->lens_dome_key, dk, sizeof(dk));
+                    ctx->lens_dome_built = true;
+                    ctx->sky_patch_built = true;          // (the flag the table rebuilds clear: "caches valid for the current tables")
+                    std::memset(ctx->sky_patch_key, 0, sizeof(ctx->sky_patch_key));     // ... but no closed-lens patches exist
+                }
+                R.sky_dome = ctx->d_sky_dome;
             }
         }
         // stream order: the tables are built on the stream of the render that needed them; a later render on another stream

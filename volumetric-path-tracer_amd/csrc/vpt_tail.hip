@@ -154,15 +154,30 @@ VPT_D f3 dome_direction(float fu, float fv) {
     return mk3(x * rxz, v, z * rxz);
 }
 // one thread per cell (i, j): its four corner nodes and its centre, evaluated from the camera origin; writes node (i, j) and the cell's flag
-__global__ __launch_bounds__(256) void sky_dome_kernel(const ResolveParams R, float4* __restrict__ out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV) return;
+// LENS: one dome per table variant (SkyView: one per binary32 value of r across the lens disc) -- the sky sees a sample's origin only through
+// r and mu_s, so a dome built from the camera origin displaced by the variant's steps of r serves every lens origin of that r
+template <bool LENS>
+__global__ __launch_bounds__(256) void sky_dome_kernel(const ResolveParams R, const SkyView* view, float4* __restrict__ out) {
+    const uint32_t tg = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cells = (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV;
+    const uint32_t variant = tg / cells, t = tg - variant * cells;
+    const int kv = LENS ? view->k : 0;
+    if (variant > 2u * (uint32_t)kv) return;
     const uint32_t j = t / (uint32_t)SKY_DOME_NU, i = t - j * (uint32_t)SKY_DOME_NU;
     Sky<ResolveParams> sky = {R};
-    load_sky_view<false>(R, sky);
+    load_sky_view<LENS>(R, sky);
     const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
-    const f3 org = mk3(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2]);
+    f3 org = mk3(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2]);
+    bool variant_ok = true;
+    if (LENS) {
+        const f3 ec = mk3(0.0f, -sky.bottom(), 0.0f);
+        const f3 up0 = normalize(org - ec);
+        org = org + up0 * (__uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)kv) - view->r);
+        const f3 p = org - ec;
+        const float r = length(p);
+        variant_ok = sky.CamVariant(r, dot(p, sun_dir) * frcp(r)) == (int)variant;       // (the displaced origin did land on this variant's r)
+    }
     const f3 scale = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]) * R.sky_mult;
     const float fi = (float)i, fj = (float)j;
     const f3 d00 = dome_direction(fi, fj);
@@ -186,11 +201,13 @@ __global__ __launch_bounds__(256) void sky_dome_kernel(const ResolveParams R, fl
         if (ang <= disc + diag) ok = false;
         if (k00 == 2 || k10 == 2 || k01 == 2 || k11 == 2 || kc == 2) ok = false;
     }
-    out[t] = make_float4(v00.x, v00.y, v00.z, ok ? 1.0f : 0.0f);
+    out[tg] = make_float4(v00.x, v00.y, v00.z, ok && variant_ok ? 1.0f : 0.0f);
 }
-hipError_t launch_sky_dome(const ResolveParams& R, float4* out, hipStream_t stream) {
-    const uint32_t n = (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV;
-    hipLaunchKernelGGL(sky_dome_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, out);
+size_t sky_dome_bytes(int k) { return sizeof(float4) * (size_t)SKY_DOME_NU * (size_t)SKY_DOME_NV * (size_t)(2 * k + 1); }
+hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* out, int k, hipStream_t stream) {
+    const uint32_t n = (uint32_t)SKY_DOME_NU * (uint32_t)SKY_DOME_NV * (uint32_t)(2 * k + 1);
+    if (k > 0) hipLaunchKernelGGL(sky_dome_kernel<true>, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, view, out);
+    else hipLaunchKernelGGL(sky_dome_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, view, out);
     return hipGetLastError();
 }
 // the dome's value along d (ResolveParams::sky_dome); false: the cell is flagged, evaluate in full
@@ -351,8 +368,17 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 if (R.has_atmosphere) {
                     // a sample that looks from the camera origin (no sphere bounce) along a direction whose dome cell passed its check: the dome
                     f3 dv;
-                    if (!LENS && R.sky_dome != nullptr && env_pos.x == R.cam_origin[0] && env_pos.y == R.cam_origin[1] && env_pos.z == R.cam_origin[2] &&
-                        dome_lookup(R.sky_dome, dir, dv))
+                    int dcv = -1;                        // the dome that serves this sample's origin: the camera origin's, or the lens variant of its r
+                    if (R.sky_dome != nullptr) {
+                        if (!LENS) {
+                            dcv = (env_pos.x == R.cam_origin[0] && env_pos.y == R.cam_origin[1] && env_pos.z == R.cam_origin[2]) ? 0 : -1;
+                        } else {
+                            const f3 pe = env_pos - mk3(0.0f, -sky.bottom(), 0.0f);
+                            const float re = length(pe);
+                            dcv = sky.CamVariant(re, dot(pe, sun_dir) * frcp(re));
+                        }
+                    }
+                    if (dcv >= 0 && dome_lookup(R.sky_dome + (size_t)dcv * ((size_t)SKY_DOME_NU * SKY_DOME_NV), dir, dv))
                         value += dv * beta;
                     else
                         value += sky.sample(env_pos, dir, sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
