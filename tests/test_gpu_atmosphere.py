@@ -102,6 +102,7 @@ def test_camera_point_table_fast_path_matches_general_path(pkg, sky, monkeypatch
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
     monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")           # the ground table has its own test below
     monkeypatch.setenv("VPT_NO_SKY_PATCH", "1")           # ... and so have the per-pixel sky patches
+    monkeypatch.setenv("VPT_NO_SKY_DOME", "1")            # ... and the sky domes (closed and open lens)
     fast = pkg.scene.HipBinding(sd, device=0)
     fast.render(2); fast.sync()
     monkeypatch.setenv("VPT_NO_CAM_TABLE", "1")
