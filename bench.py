@@ -214,7 +214,14 @@ def main():
     def measure(cfg, spp, steps, warmup, W, H, with_extras):
         """one workload: returns the dict of the JSON line (rank 0) or None"""
         sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or args.scaling == "weak" else spp * world, args.grid_scale, dev, local_rank)
+        # scene set-up as a rank pays it at start (outside the timed region): texture uploads / adoption, the re-lay of big grids
+        # into corner quads (config 4: 3.5 GB -> 14 GB on the GPU), the host octree and its candidate lists, buffer allocation
+        torch.cuda.synchronize(dev)
+        t_setup = time.perf_counter()
         hb = pkg.scene.HipBinding(sd, device=local_rank)
+        hb.sync()
+        torch.cuda.synchronize(dev)
+        t_setup = time.perf_counter() - t_setup
         first_it, stride, bn_pre = pkg.dist.stripe(rank, world)
         bn0 = hb.blue_noise.clone()
         torch.cuda.synchronize(dev)
@@ -287,7 +294,8 @@ def main():
                            # host-staged torch.distributed fallback (VPT_BENCH_BACKEND=gloo: ranks sharing one GPU)
                            "collective": ({"backend": "rccl (vpt_allreduce_accum)", "comm_ranks": int(hb.ctx.comm_nranks)} if use_comm else
                                           {"backend": backend + " (torch.distributed, host-staged)", "comm_ranks": world}) if multi else None,
-                           "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)"},
+                           "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)",
+                           "scene_setup_s": round(t_setup, 3)},
                 "roofline": roofline,
             }
             # per-frame sky tables of the environment tail: were ground tables in use, and their self-measured error
