@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     // the never-traced flags of this thread's pixels (one per pass), requested together up front: one memory latency per thread
     // instead of a dependent load at the head of every pass
     uint32_t never_bits = 0;
-#ifndef VPT_AB_NO_NEVER
     if (P.never_traced && x < (int)P.width) {
 #pragma unroll
         for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
@@ -85,7 +84,6 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             never_bits |= (f & 1u) << pass;
         }
     }
-#endif
     for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
         const int y = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
         bool enqueue = false;
