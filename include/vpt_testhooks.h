@@ -55,6 +55,10 @@ int vpt_test_project_box(const vpt_camera *cam, const float lo[3], const float h
 /* the sphere half of that mask (csrc/vpt_cull.h: sphere_may_hit): 1 when a primary ray within `diag` (chord) of the unit direction
  * dir_centre could make sphere::intersect report a hit -- its binary32 discriminant included --, 0 when none can.  Host only. */
 int vpt_test_sphere_may_hit(const float org[3], const float dir_centre[3], float diag, const float sphere[4]);
+/* the host's check of one grid extent d (csrc/vpt_fastdiv.h): 1 when y + (q - d y) r, y = q r, has the bits of q / d for every
+ * significand q of a binade (the look-ups then form the quotient that way, csrc/vpt_trace_common.h: to_unit), 0 when some q differs,
+ * d is outside [1, 2^16] or the host has no FMA.  r: the reciprocal to test -- RN(1 / d) in the product.  Host only. */
+int vpt_test_fast_div_ok(float d, float r);
 /* per-pixel sky patches of the last render (csrc/vpt_tail.hip: sky_patch_kernel): pixels of the frame, and how many of them passed
  * the patch's check (the others evaluate every untraced sample in full); both 0 when the render used no patches */
 int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);

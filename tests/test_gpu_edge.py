@@ -252,3 +252,35 @@ def test_pool_tracer_is_bit_identical_to_lane_tracer(pkg, monkeypatch, scene):
     c = pkg.scene.HipBinding(sd, device=0)
     c.render(5); c.sync()
     np.testing.assert_array_equal(a.accum.cpu().numpy(), c.accum.cpu().numpy())
+
+
+@pytest.mark.parametrize("scene", ["dragon", "fireball", "instanced", "cloud_vol"])
+def test_quotient_by_checked_reciprocal_is_the_division(pkg, monkeypatch, scene):
+    """to_unit divides the index-space position by the grid extent (render_kernel.cu:996).  Where the host has checked the
+    extent over a whole binade (csrc/vpt_fastdiv.h) the look-ups multiply by its rounded reciprocal and correct with one exact
+    residual instead; VPT_NO_FAST_DIV keeps the division.  Same bits: every buffer and every count must be identical."""
+    def make():
+        if scene == "dragon":
+            return pkg.scene.dragon_scene(160, 90, "sun")
+        if scene == "fireball":
+            return pkg.scene.fireball_scene(96, 64, n=37)                 # emission grid: a second extent per look-up
+        if scene == "instanced":
+            return pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)    # instance loop, colour grids
+        sd = pkg.scene.cloud_scene(96, 64, shape=(76, 44, 64), env=(128, 64))        # vol_integrator, HDRI
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+        return sd
+    sd = make()
+    a = pkg.scene.HipBinding(sd, device=0)
+    a.ctx.set_counting(True)
+    a.render(5); a.sync()
+    sa = a.ctx.stats()
+    monkeypatch.setenv("VPT_NO_FAST_DIV", "1")
+    b = pkg.scene.HipBinding(sd, device=0)
+    b.ctx.set_counting(True)
+    b.render(5); b.sync()
+    sb = b.ctx.stats()
+    assert a.accum.abs().max() > 0
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())
+    for k in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+        assert getattr(sa, k) == getattr(sb, k), k

@@ -56,6 +56,8 @@ struct DVolume {
     int bdim[2];           // GRID_BRICKS: bricks along x and y
     int elayout;           // of the emission grid: GRID_DENSE or GRID_QUADS
     int addr24;            // every texel-index product of this volume's grids fits the 24-bit multiplier (see imul)
+    float rdim[3];         // RN(1 / fdim)
+    int fast_div;          // q / fdim may be formed as y + (q - fdim y) rdim, y = q rdim: the host checked all three extents (vpt_fastdiv.h)
 };
 
 struct DTexture {          // CUDA sampler state restated

@@ -23,6 +23,7 @@
 #include "../../include/vpt_testhooks.h"
 #include "vpt_device.h"
 #include "vpt_cull.h"
+#include "vpt_fastdiv.h"
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
@@ -128,6 +129,7 @@ struct vpt_ctx {
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
     bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
     bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
+    bool no_fast_div = false;              // VPT_NO_FAST_DIV: every look-up divides by the grid extent (tests: both forms give the same bits)
     bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
     float dir_tab_tol = 5e-4f;             // VPT_DIR_TABLE_TOL: largest relative mid-cell error the ground table may show
     // camera-point scattering table: rebuilt only when its inputs change (per-frame calls reuse it)
@@ -351,6 +353,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_patch = std::getenv("VPT_NO_SKY_PATCH") != nullptr;
     ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
+    ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -512,6 +515,18 @@ __global__ void quads_kernel(const float* __restrict__ src, float4* __restrict__
                          src[((size_t)k1 * dy + j0) * dx + x], src[((size_t)k1 * dy + j1) * dx + x]);
 }
 
+// vpt_fastdiv.h's verdict for one divisor, remembered for the process (~3 ms each: a scene has three, instances share theirs)
+static bool divisor_checked(float d, float r) {
+    static std::mutex mu;
+    static std::vector<std::pair<float, bool>> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& s : seen)
+        if (s.first == d) return s.second;
+    const bool ok = vpt::fast_div_ok(d, r);
+    seen.emplace_back(d, ok);
+    return ok;
+}
+
 // Screen-space bounds, in pixels, of the world box [lo, hi] as camera::get_ray (camera.h:131-136, closed lens) sees it: a world point
 // X is hit by the ray of image-plane coordinates (u, v) with X - o = s (llc - o + u h + v vert), s > 0.  false: a corner at or
 // behind the camera plane (no bound can be given).
@@ -651,6 +666,11 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         st3(d.bmin, vi.bmin);
         d.fdim[0] = (float)vi.dim.x; d.fdim[1] = (float)vi.dim.y; d.fdim[2] = (float)vi.dim.z;
         d.dim[0] = vi.dim.x; d.dim[1] = vi.dim.y; d.dim[2] = vi.dim.z;
+        d.fast_div = ctx->no_fast_div ? 0 : 1;
+        for (int a = 0; a < 3; ++a) {
+            d.rdim[a] = 1.0f / d.fdim[a];
+            if (d.fast_div && !divisor_checked(d.fdim[a], d.rdim[a])) d.fast_div = 0;
+        }
         bounds[i] = vdb_bounds(volumes[i]);
     }
     if (!ctx->bricked.empty()) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // re-tiled grids ready for any stream
@@ -887,6 +907,8 @@ int vpt_test_sphere_may_hit(const float org[3], const float dir_centre[3], float
     if (!org || !dir_centre || !sphere) return VPT_E_INVALID;
     return sphere_may_hit(mk3(org[0], org[1], org[2]), mk3(dir_centre[0], dir_centre[1], dir_centre[2]), diag, sphere) ? 1 : 0;
 }
+
+int vpt_test_fast_div_ok(float d, float r) { return vpt::fast_div_ok(d, r) ? 1 : 0; }
 
 int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, unsigned long long* with_patch) {
     if (!ctx || !pixels || !with_patch) return VPT_E_INVALID;

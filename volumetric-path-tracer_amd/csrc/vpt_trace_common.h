@@ -178,9 +178,22 @@ VPT_D bool to_unit(const float* m, const DVolume& v, f3 p, f3& u) {
     q.x = q.x - v.bmin[0];
     q.y = q.y - v.bmin[1];
     q.z = q.z - v.bmin[2];
-    u.x = q.x / v.fdim[0];
-    u.y = q.y / v.fdim[1];
-    u.z = q.z / v.fdim[2];
+    // u = q / fdim, correctly rounded (:996).  The extents are constants of the volume: where the host has checked them (vpt_fastdiv.h)
+    // a multiplication by the rounded reciprocal and one exact-residual correction give the same bits as the division, as long as no
+    // intermediate is subnormal or overflows -- |q| in [2^-40, 2^40] (extents <= 2^16).  A position within 1e-12 voxels of a bmin
+    // plane, a non-finite coordinate or an unchecked extent takes the division itself; the wave decides together.
+    const float qlo = fmin_(fmin_(fabsf(q.x), fabsf(q.y)), fabsf(q.z)), qhi = fmax_(fmax_(fabsf(q.x), fabsf(q.y)), fabsf(q.z));
+    const bool fast = v.fast_div != 0 && qlo >= 0x1p-40f && qhi <= 0x1p+40f;
+    if (__all(fast)) {
+        const float yx = q.x * v.rdim[0], yy = q.y * v.rdim[1], yz = q.z * v.rdim[2];
+        u.x = __builtin_fmaf(__builtin_fmaf(-v.fdim[0], yx, q.x), v.rdim[0], yx);
+        u.y = __builtin_fmaf(__builtin_fmaf(-v.fdim[1], yy, q.y), v.rdim[1], yy);
+        u.z = __builtin_fmaf(__builtin_fmaf(-v.fdim[2], yz, q.z), v.rdim[2], yz);
+    } else {
+        u.x = q.x / v.fdim[0];
+        u.y = q.y / v.fdim[1];
+        u.z = q.z / v.fdim[2];
+    }
     return !(u.x < .0f || u.y < .0f || u.z < .0f || u.x > 1.0f || u.y > 1.0f || u.z > 1.0f);
 }
 
