@@ -284,3 +284,22 @@ def test_quotient_by_checked_reciprocal_is_the_division(pkg, monkeypatch, scene)
         np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())
     for k in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays"):
         assert getattr(sa, k) == getattr(sb, k), k
+
+
+@pytest.mark.parametrize("size", [(160, 90), (97, 61)])
+def test_image_plane_quotients_by_checked_reciprocal(pkg, monkeypatch, size):
+    """volume_rt_kernel's u = (x + jitter) / width, v = (y + jitter) / height (render_kernel.cu:2243-2244) are formed like the look-up's
+    quotient (csrc/vpt_trace.hip raygen; extents checked by the host, a zero numerator divides): same rays, bit for bit -- closed and open lens."""
+    for config, aperture in (("sun", 0.0), ("sun", 0.4)):
+        sd = pkg.scene.dragon_scene(size[0], size[1], config)
+        if aperture:
+            sd.camera.lens_radius = aperture / 2
+        monkeypatch.delenv("VPT_NO_FAST_DIV", raising=False)
+        a = pkg.scene.HipBinding(sd, device=0)
+        a.render(4); a.sync()
+        monkeypatch.setenv("VPT_NO_FAST_DIV", "1")
+        b = pkg.scene.HipBinding(sd, device=0)
+        b.render(4); b.sync()
+        assert a.accum.abs().max() > 0
+        for buf in ("accum", "depth", "raw", "display", "blue_noise"):
+            np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())

@@ -1238,6 +1238,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     std::memset(&P, 0, sizeof(P));
     P.width = W; P.height = H; P.n_pixels = n_pixels;
     P.inv_n_pixels = 1.0f / (float)n_pixels;
+    P.rcp_w = 1.0f / (float)W; P.rcp_h = 1.0f / (float)H;
+    P.fast_uv = !ctx->no_fast_div && divisor_checked((float)W, P.rcp_w) && divisor_checked((float)H, P.rcp_h) ? 1 : 0;
     P.iter_stride = iter_stride;
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;

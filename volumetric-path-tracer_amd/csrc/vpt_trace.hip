@@ -98,8 +98,18 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             const uint32_t pixel = (uint32_t)y * P.width + (uint32_t)x;
             s = kiter * P.n_pixels + pixel;
             const float2 bn = P.blue_noise[(size_t)kiter * 65536 + (y % 256) * 256 + (x % 256)];
-            const float u = (float)(x + bn.x) / (float)P.width;
-            const float v = (float)(y + bn.y) / (float)P.height;
+            // volume_rt_kernel divides the jittered pixel position by the image extent (render_kernel.cu:2243-2244): per-launch constants, so the
+            // quotient is formed as in to_unit (vpt_trace_common.h) where the host has checked both extents; a zero numerator divides
+            const float qu = (float)(x + bn.x), qv = (float)(y + bn.y);
+            float u, v;
+            if (__all(P.fast_uv != 0 && fmin_(qu, qv) >= 0x1p-40f)) {
+                const float yu = qu * P.rcp_w, yv = qv * P.rcp_h;
+                u = __builtin_fmaf(__builtin_fmaf(-(float)P.width, yu, qu), P.rcp_w, yu);
+                v = __builtin_fmaf(__builtin_fmaf(-(float)P.height, yv, qv), P.rcp_h, yv);
+            } else {
+                u = qu / (float)P.width;
+                v = qv / (float)P.height;
+            }
             // camera::get_ray, camera.h:131-136.  With a closed lens (lens_radius == 0) the lens sample is multiplied by zero:
             // offset = u * (0 * pd.x) + v * (0 * pd.y) = +-0, so the ray does not depend on the stream at all -- it is built
             // and tested first, and only a ray that goes on to the tracer (41 % of config 2) pays for the Philox block(s)
