@@ -333,8 +333,8 @@ int  vpt_get_stats(vpt_ctx *ctx, vpt_render_stats *out);
  * (vpt_render_batch with iter_stride = G after vpt_blue_noise_advance(r)); its accum buffer then holds the running
  * mean of ITS n_local iterations.  vpt_allreduce_accum turns every rank's buffer into the job's mean,
  *     accum <- sum_r n_r * accum_r / sum_r n_r,
- * with ONE RCCL all-reduce over xGMI (the image and the iteration count travel in one grouped call), enqueued on
- * `stream` (NULL = the context's stream) between a scale and a divide kernel -- no host synchronisation; a render
+ * with ONE RCCL all-reduce over xGMI of W*H*3 + 1 floats (the rank's weighted image with its iteration count in the last float of a
+ * context-owned payload buffer), enqueued on `stream` (NULL = the context's stream) between a scale and a divide kernel -- no host synchronisation; a render
  * issued afterwards on the same stream is ordered behind it.  RCCL (librccl.so) is loaded on the first vpt_comm_* call.
  * The reduce is TERMINAL for a progressive render: afterwards `accum` holds the JOB's mean, not this rank's -- a further
  * vpt_render_batch into it would treat the job's mean as the rank's running mean, and a second reduce would count the other
@@ -366,7 +366,8 @@ int  vpt_atmosphere_default_model(vpt_atmosphere_parameters *atm);
 /* vpt_atmosphere_model: the same scalars for ANY setting of the reference's model switches -- what atmosphere::init
  * (spectra, atmosphere.cpp:1193-1224), precompute's luminance factors (:903-910) and update_model(lambdas) (:698-784) leave in
  * atmosphere_parameters: solar spectrum constant / ASTM, ozone on / off, white balance, luminance mode NONE (0) or
- * APPROXIMATE (1) (PRECOMPUTED (2), the 15-wavelength precompute, returns VPT_E_UNSUPPORTED), the three wavelengths the
+ * APPROXIMATE (1) (PRECOMPUTED (2) yields the scalars of its final pass here; its 15-wavelength table passes are
+ * vpt_atmosphere_precompute_model's), the three wavelengths the
  * tables are computed for, exposure, the 102-degree sun-zenith limit of half-precision tables, the length unit.  The published
  * data tables behind it (solar irradiance, ozone cross-sections, CIE 1931 CMFs) are read from `spectra_file`
  * (NULL: data/atmosphere_spectra.bin next to the library).  Follow with vpt_atmosphere_precompute. */

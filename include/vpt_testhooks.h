@@ -62,6 +62,10 @@ int vpt_test_fast_div_ok(float d, float r);
 /* per-pixel sky patches of the last render (csrc/vpt_tail.hip: sky_patch_kernel): pixels of the frame, and how many of them passed
  * the patch's check (the others evaluate every untraced sample in full); both 0 when the render used no patches */
 int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);
+/* which per-view caches of the environment tail the LAST render used (csrc/vpt_host.hip: built for a batch of >= 2 iterations or a repeated
+ * view): out[0] per-pixel sky patches, [1] never-traced pixel mask (raygen skips those pixels), [2] sky dome(s), [3] dome variants (1 behind
+ * a closed lens, 2 k + 1 behind an open one), [4] camera-point scattering table, [5] view-point ground table(s) bound; [6..7] reserved */
+int vpt_test_get_cache_state(vpt_ctx *ctx, int out[8]);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
  * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */
 int vpt_io_test_blosc_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t nbytes_out);

@@ -31,7 +31,19 @@ def _per_pixel(got, ref):
     return np.abs(a - b).max(1)[m] / lum[m]
 
 
-def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1e-2):
+def _cache_state(pkg, hb):
+    """which per-view caches of the environment tail the last render used (include/vpt_testhooks.h)"""
+    import ctypes as C
+    lib = pkg.load_library()
+    out = (C.c_int * 8)()
+    lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert lib.vpt_test_get_cache_state(hb.ctx.h, out) == 0
+    return dict(zip(("sky_patch", "never_traced", "sky_dome", "dome_variants", "cam_table", "dir_table"), list(out)[:6]))
+
+
+def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1e-2, caches=None):
+    """caches: names of the per-view caches (see _cache_state) the render MUST have used -- a batch of >= 2 iterations is what
+    bench.py times, and it goes through the sky patches, the never-traced pixel mask and the sky dome(s); one iteration does not."""
     import oracle_binding
     hb = pkg.scene.HipBinding(sd, device=0)
     ob = oracle_binding.OracleBinding(sd)
@@ -43,6 +55,10 @@ def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1
         hb.render(iterations)
     hb.sync()
     st = hb.ctx.stats()
+    if caches is not None:
+        state = _cache_state(pkg, hb)
+        for c in caches:
+            assert state[c], (c, state)
     ob.render(iterations)
     got = hb.accum.cpu().numpy()
     assert np.isfinite(got).all() and ob.accum.max() > 0
@@ -77,14 +93,17 @@ def test_config2_dragon_1080p(pkg):
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
     e, st = _compare(pkg, sd, 1)
     assert st.density_lookups > 0 and st.skip_steps > 0
-    # and the literal drop-in call: three frames through vpt_render
-    _compare(pkg, sd, 3, per_frame=True)
+    # what bench.py times: a BATCH, which builds and uses the per-view caches (patches for the untraced samples, the mask of
+    # never-traced pixels that raygen skips, the dome for the traced ones) -- whole frame against the oracle, depth / alpha / counts exact
+    _compare(pkg, sd, 2, caches=("sky_patch", "never_traced", "sky_dome", "cam_table", "dir_table"))
+    # and the literal drop-in call: three frames through vpt_render (the still view repeats: frames 2 and 3 use the caches too)
+    _compare(pkg, sd, 3, per_frame=True, caches=("sky_patch", "never_traced", "sky_dome"))
 
 
 def test_config3_fireball_1080p_sun_and_sky(pkg):
     sd = pkg.scene.fireball_scene(1920, 1080, n=256, sky=True)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    e, st = _compare(pkg, sd, 1)
+    e, st = _compare(pkg, sd, 2, caches=("sky_patch", "sky_dome", "cam_table", "dir_table"))       # (its box fills the frame: no pixel is skipped)
     assert st.emission_lookups > 0
 
 
@@ -163,5 +182,5 @@ def test_config4_cloud_benchmark_size_grid_1080p(pkg, monkeypatch):
 def test_config5_100_instances_4k_dof_sun_and_sky(pkg):
     sd = pkg.scene.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0, sky=True)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    e, st = _compare(pkg, sd, 1, p99=5e-3)                  # the open lens' ground-table variants: see _compare
+    e, st = _compare(pkg, sd, 2, p99=5e-3, caches=("sky_dome", "cam_table", "dir_table"))    # the open lens' ground-table variants: see _compare; one dome per variant
     assert st.color_lookups > 0 and st.density_lookups > 2 * st.tracking_steps       # several instances per leaf and step

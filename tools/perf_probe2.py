@@ -36,7 +36,7 @@ for combo in itertools.product(*vals) if vals else [()]:
 
 import ctypes as C
 hb = S.HipBinding(sd, device=0)
-hb.render(min(a.spp, 4), iteration=0); hb.sync()
+hb.render(a.spp, iteration=0); hb.sync()
 outp = (C.c_ulonglong * 12)()
 pkg.load_library().vpt_test_get_schedule(hb.ctx.h, outp)
 op = list(outp)
@@ -45,6 +45,12 @@ if sum(op[8:12]):
     print("section cycles (non-counting kernel): refill %.1f%%, philox top-up %.1f%%, walk step %.1f%%, transitions %.1f%%" % tuple(100.0 * x / tot for x in op[8:12]))
     print("  of the walk step, the empty-node skip loop: %.1f%% of all cycles" % (100.0 * op[5] / tot))
     print("  transitions split: entry+FIRST_DONE %.1f%%, TRACK_DONE..EMIT %.1f%%, OUTER_SECOND/TOP %.1f%%, FINISH %.1f%%, Tr prologue %.1f%% (of all cycles)" % tuple(100.0 * x / tot for x in op[0:5]))
+    co = (C.c_ulonglong * 8)()
+    pkg.load_library().vpt_test_get_coherence(hb.ctx.h, co)
+    co = list(co)
+    if sum(co[0:4]):
+        print("  refill split (of all cycles): idle test %.1f%%, claim (atomic + queue entries, waited for) %.1f%%, wait for the records %.1f%%, unpack %.1f%% | refills %d with %.1f lanes each, %d claims; cycles per refill: wait %.0f unpack %.0f, per claim %.0f"
+              % (100.0 * co[0] / tot, 100.0 * co[1] / tot, 100.0 * co[2] / tot, 100.0 * co[3] / tot, co[4], co[5] / max(1, co[4]), co[6], co[2] / max(1, co[4]), co[3] / max(1, co[4]), co[1] / max(1, co[6])))
 hb.ctx.set_counting(True)
 hb.render(a.count_spp, iteration=0); hb.sync()
 print("(schedule figures: a counted render of %d iterations)" % a.count_spp)

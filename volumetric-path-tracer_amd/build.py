@@ -17,9 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libvpt_hip.so")
-HEADERS = ["vpt_math.h", "vpt_device.h", "vpt_rng.h", "vpt_trace_common.h", "vpt_walk.h", "vpt_trace_direct.h", "vpt_tex.h", "vpt_sky.h", "vpt_cull.h", os.path.join("..", "..", "include", "vpt_abi.h"),
-           os.path.join("..", "..", "include", "vpt_testhooks.h"),
-           os.path.join("..", "..", "include", "vpt_io.h")]
+# every header a source may include: all of csrc/*.h and include/*.h (a stale object after a header edit is how an old fast_div verdict
+# or an old ABI struct would survive an incremental build)
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+          sorted(os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include")) if f.endswith(".h"))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
@@ -55,7 +56,7 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
         OBJ = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vpt_obj_" + variant)
         OUT = os.path.join(HERE, "libvpt_hip_%s.so" % variant)
     os.makedirs(OBJ, exist_ok=True)
-    common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    common_deps = list(HEADERS) + [os.path.abspath(__file__)]
     jobs = []
     objs = []
     for src, flags in SOURCES.items():

@@ -223,6 +223,9 @@ struct ResolveParams {
     float inv_n_pixels;              // 1 / n_pixels (fp32), see split_slot
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;
+    // RN64(1 / n) for the running-mean divisor n = (float)(iter_begin / iter_stride + k + 1) of the launch's k-th iteration (a launch holds at
+    // most 64), or 0 where n >= 2^27: the tail forms the quotients a / n as RN32(a * rcp_n[k]) (vpt_tail.hip: mul1_rn, with the proof)
+    double rcp_n[64];
     const Record* records;
     // 16-byte sample heads (only when every primary ray starts at the camera origin, i.e. lens_radius
     // == 0): {dir0.xyz, w}.  w >= 0: the primary ray started no walk ("miss", 59 % of config 2) -- it

@@ -121,7 +121,8 @@ struct vpt_ctx {
     // single-GPU host never maps it
     ncclComm_t comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
-    float* d_comm_count = nullptr;         // 1 float: this rank's iteration count, summed over ranks next to the image
+    float* d_comm_buf = nullptr;           // the collective's payload: this rank's weighted image + its iteration count in the last float
+    size_t comm_buf_floats = 0;
     // tuning / test switches, read from the environment ONCE, when the context is created (vpt_create)
     size_t relaid_min_bytes = (size_t)8 << 20;    // VPT_RELAID_MIN_BYTES: density / emission grids below this stay dense (they live in L2)
     int grid_layout = -1;                  // VPT_GRID_LAYOUT (tests): force "dense" / "bricks" / "quads" for grids >= relaid_min_bytes; -1: quads, bricks if those do not fit
@@ -375,7 +376,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)vpt_comm_destroy(ctx);
-    (void)hipFree(ctx->d_comm_count);
+    (void)hipFree(ctx->d_comm_buf);
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
     for (void* b : ctx->bricked) (void)hipFree(b);
@@ -926,6 +927,20 @@ int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, un
     return VPT_OK;
 }
 
+int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!ctx->have_last_resolve) return VPT_OK;
+    const ResolveParams& R = ctx->last_resolve;
+    out[0] = R.sky_patch != nullptr;
+    out[1] = R.never_traced != nullptr;
+    out[2] = R.sky_dome != nullptr;
+    out[3] = R.sky_dome != nullptr ? 2 * ctx->sky_dome_k + 1 : 0;
+    out[4] = R.cam_tab_valid;
+    out[5] = R.dir_tab != nullptr;
+    return VPT_OK;
+}
+
 int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {
     if (!ctx || !out) return VPT_E_INVALID;
     for (int i = 0; i < 8; ++i) out[i] = 0.0f;
@@ -992,8 +1007,6 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -1016,10 +1029,8 @@ bool rccl_load(vpt_ctx* ctx) {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
-    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
-    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         set_error(ctx, "vpt_comm: librccl.so lacks an expected symbol");
         dlclose(h);
         return false;
@@ -1036,17 +1047,18 @@ bool rccl_load(vpt_ctx* ctx) {
         }                                                                                                    \
     } while (0)
 
-// accum[i] *= n (weighted sum of this rank), count[0] = n
-__global__ void comm_scale_kernel(float* __restrict__ accum, size_t n_floats, float n, float* __restrict__ count) {
+// buf[i] = accum[i] * n (weighted sum of this rank), buf[n_floats] = n: ONE payload of W*H*3 + 1 floats
+__global__ void comm_scale_kernel(const float* __restrict__ accum, size_t n_floats, float n, float* __restrict__ buf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) count[0] = n;
-    if (i < n_floats) accum[i] *= n;
+    if (i == 0) buf[n_floats] = n;
+    if (i < n_floats) buf[i] = accum[i] * n;
 }
-// accum[i] /= count[0] (IEEE divide: this file is built strict)
-__global__ void comm_divide_kernel(float* __restrict__ accum, size_t n_floats, const float* __restrict__ count) {
+// accum[i] = buf[i] / buf[n_floats] (IEEE divide: this file is built strict)
+__global__ void comm_divide_kernel(float* __restrict__ accum, size_t n_floats, const float* __restrict__ buf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // (a job in which no rank rendered anything: the buffers hold zeros times zero -- leave them, do not divide by zero)
-    if (i < n_floats && count[0] > 0.0f) accum[i] = accum[i] / count[0];
+    // (a job in which no rank rendered anything: the payload holds zeros times zero -- leave the image, do not divide by zero)
+    const float count = buf[n_floats];
+    if (i < n_floats && count > 0.0f) accum[i] = buf[i] / count;
 }
 }  // namespace
 
@@ -1073,7 +1085,6 @@ int vpt_comm_init_rank(vpt_ctx* ctx, int nranks, int rank, const unsigned char* 
     RCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
     ctx->comm_nranks = nranks;
     ctx->comm_rank = rank;
-    if (!ctx->d_comm_count) HIPCHK(ctx, hipMalloc(&ctx->d_comm_count, 64));
     return VPT_OK;
 }
 
@@ -1107,15 +1118,19 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const unsigned blocks = (unsigned)((n_floats + 255ull) / 256ull);
-    // everything on ONE stream, in order: weighted sum of this rank -> one grouped all-reduce (image + iteration count)
-    // -> divide.  No host synchronisation: the next render on the same stream simply queues behind it.
-    hipLaunchKernelGGL(comm_scale_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, (float)n_local_iterations, ctx->d_comm_count);
+    if (ctx->comm_buf_floats < (size_t)n_floats + 1u) {
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+        (void)hipFree(ctx->d_comm_buf); ctx->d_comm_buf = nullptr; ctx->comm_buf_floats = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_comm_buf, ((size_t)n_floats + 1u) * sizeof(float)));
+        ctx->comm_buf_floats = (size_t)n_floats + 1u;
+    }
+    // everything on ONE stream, in order: weighted sum of this rank into the payload (its iteration count in the last float) -> ONE
+    // all-reduce of W*H*3 + 1 floats -> divide back into the caller's buffer.  No host synchronisation: the next render on the same
+    // stream simply queues behind it.
+    hipLaunchKernelGGL(comm_scale_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, (float)n_local_iterations, ctx->d_comm_buf);
     HIPCHK(ctx, hipGetLastError());
-    RCCLCHK(ctx, g_rccl.GroupStart());
-    RCCLCHK(ctx, g_rccl.AllReduce(accum, accum, (size_t)n_floats, ncclFloat32, ncclSum, ctx->comm, stream));
-    RCCLCHK(ctx, g_rccl.AllReduce(ctx->d_comm_count, ctx->d_comm_count, 1, ncclFloat32, ncclSum, ctx->comm, stream));
-    RCCLCHK(ctx, g_rccl.GroupEnd());
-    hipLaunchKernelGGL(comm_divide_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, ctx->d_comm_count);
+    RCCLCHK(ctx, g_rccl.AllReduce(ctx->d_comm_buf, ctx->d_comm_buf, (size_t)n_floats + 1u, ncclFloat32, ncclSum, ctx->comm, stream));
+    hipLaunchKernelGGL(comm_divide_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, ctx->d_comm_buf);
     HIPCHK(ctx, hipGetLastError());
     return VPT_OK;
 }
@@ -1334,7 +1349,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (chunk < 1) chunk = 1;
     if (chunk > 64) chunk = 64;
     if (chunk > iter_count) chunk = iter_count;
-    if (ctx->batch_iters > 0) chunk = std::min<size_t>((size_t)ctx->batch_iters, iter_count);
+    if (ctx->batch_iters > 0) chunk = std::min<size_t>(std::min<size_t>((size_t)ctx->batch_iters, iter_count), 64);     // (ResolveParams::rcp_n, split_slot: <= 64 per launch)
     if (ctx->records_capacity < chunk * per_iter) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
@@ -1580,6 +1595,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         const bool last = done + n >= iter_count;
         P.iter_begin = it0; P.iter_count = n;
         R.iter_begin = it0; R.iter_count = n;
+        for (unsigned int k = 0; k < 64u; ++k) {
+            const float nf = (float)(it0 / iter_stride + k + 1u);          // the tail's (float)(local_it + 1)
+            R.rcp_n[k] = (k < n && nf < 134217728.0f) ? 1.0 / (double)nf : 0.0;
+        }
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 16 * sizeof(uint32_t), stream));

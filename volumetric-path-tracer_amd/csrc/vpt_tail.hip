@@ -21,6 +21,16 @@ namespace vpt {
 // binary32 quotient.  __fdiv_rn is just `a / b` in HIP and follows the approximate-divide flag.
 VPT_D float div1_rn(float a, float b) { return (float)((double)a / (double)b); }
 VPT_D f3 div_rn(f3 a, float b) { return mk3(div1_rn(a.x, b), div1_rn(a.y, b), div1_rn(a.z, b)); }
+// The same correctly rounded quotients a / n for the running means' divisor n = (float)(iteration + 1) -- an integer-valued binary32, the
+// same for every pixel of an iteration -- by ONE binary64 reciprocal per iteration, rn = RN64(1 / n), made on the host (ResolveParams::rcp_n):
+// RN32(RN64(a * rn)) == RN32(a / n) for every binary32 a whenever n < 2^27.  Proof: a = A 2^e, |A| < 2^24; a rounding boundary of binary32
+// next to q = a / n is M 2^f with M an odd integer (|M| < 2^25) and e >= f, so q - M 2^f = 2^f (A 2^(e-f) - M n) / n is 0 or at least 2^f / n
+// in magnitude, i.e. >= 2^-25 / n relative to q; it is 0 only if n is a power of two (M n odd times a power of two cannot equal an integer of
+// 24 bits otherwise), and then a * rn is exact.  The computed product is within 2^-52 of q relatively (two binary64 roundings), which is
+// below 2^-25 / n for n < 2^27: it lies on q's side of every boundary.  (Subnormal quotients: coarser boundaries, same argument.)  Four
+// binary64 divisions per sample become four multiplications; host entries of 0 (n >= 2^27) keep the division.
+VPT_D float mul1_rn(float a, double rn) { return (float)((double)a * rn); }
+VPT_D f3 mul_rn(f3 a, double rn) { return mk3(mul1_rn(a.x, rn), mul1_rn(a.y, rn), mul1_rn(a.z, rn)); }
 VPT_D f3 rtt_and_odt_fit(f3 v) {                                                       // :2208
     f3 a = v * (v + 0.0245786f) - 0.000090537f;
     f3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
     // what volume_rt_kernel does with a sample value (:2263-2287): NaN guard, viz_dof tint, running means
-    auto accumulate = [&](f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it) {
+    auto accumulate = [&](f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it, double rn) {
         // :2263-2264
         if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
         if (isnan(tr) || isinf(tr)) tr = 1.0f;
@@ -282,11 +292,18 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
             dep = depth;
         } else if (iteration < R.max_interactions) {
             const float n = (float)(local_it + 1);
-            acc = acc + div_rn(value - acc, n);
-            // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the divisions are skipped then
-            if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
-            else cst = cst + div_rn(mk3(0.0f) - cst, n);
-            dep = dep + div1_rn(depth - dep, n);
+            if (rn != 0.0) {
+                acc = acc + mul_rn(value - acc, rn);
+                // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the quotients are skipped then
+                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+                else cst = cst + mul_rn(mk3(0.0f) - cst, rn);
+                dep = dep + mul1_rn(depth - dep, rn);
+            } else {
+                acc = acc + div_rn(value - acc, n);
+                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+                else cst = cst + div_rn(mk3(0.0f) - cst, n);
+                dep = dep + div1_rn(depth - dep, n);
+            }
         }
         tr_last = tr;
     };
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];
                 value = flerp3(flerp3(v00, v10, j.x), flerp3(v01, v11, j.x), j.y);
             }
-            accumulate(value, 0.0f, 0.0f, iteration, local_it0 + k);
+            accumulate(value, 0.0f, 0.0f, iteration, local_it0 + k, R.rcp_n[k]);
         }
     } else {
     // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 value += env_lookup(R.env_tex, dir) * sky_color * beta * (1.0f / (4.0f * VPT_PI));
             }
         }
-        accumulate(value, tr, depth, iteration, local_it);
+        accumulate(value, tr, depth, iteration, local_it, R.rcp_n[k]);
     }
     }
     R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 #endif
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;       // transitions, split (PROF builds)
     unsigned long long tskip = 0;                                         // skip loop inside the walk step (PROF builds)
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, nr0 = 0, nr1 = 0, nr2 = 0;   // refill, split: idle test, claim, record wait, unpack; refills, lanes refilled, claims
     unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
 #define VPT_TICK(acc) do { if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tstamp; tstamp = now_; } } while (0)
     for (;;) {
@@ -315,7 +316,9 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         if (idle != 0ull) {
             const unsigned long long active = __ballot(1);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
+            VPT_TICK(tr0);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
+                if (PROF) nr2++;
                 claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
@@ -325,10 +328,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 128u + (uint32_t)lane] : 0u;
                 qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 192u + (uint32_t)lane] : 0u;
             }
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }       // (study builds: charge the claim's latencies to the claim)
+            VPT_TICK(tr1);
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0u && !more && idle == active) {
                 if (PROF && lane == 0) {
-                    atomicAdd(&P.prof->cycles[0], tc0); atomicAdd(&P.prof->cycles[1], tc1);
+                    atomicAdd(&P.prof->coh[0], tr0); atomicAdd(&P.prof->coh[1], tr1); atomicAdd(&P.prof->coh[2], tr2); atomicAdd(&P.prof->coh[3], tr3);
+                    atomicAdd(&P.prof->coh[4], nr0); atomicAdd(&P.prof->coh[5], nr1); atomicAdd(&P.prof->coh[6], nr2);
+                    atomicAdd(&P.prof->cycles[0], tc0 + tr0 + tr1 + tr2 + tr3); atomicAdd(&P.prof->cycles[1], tc1);
                     atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3 + ts0 + ts1 + ts2 + ts3 + ts4);
                     atomicAdd(&P.prof->sched[0], ts0); atomicAdd(&P.prof->sched[1], ts1); atomicAdd(&P.prof->sched[2], ts2);
                     atomicAdd(&P.prof->sched[3], ts3); atomicAdd(&P.prof->sched[4], ts4);
@@ -338,20 +345,40 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
             if (avail != 0u && (n_idle >= regen_min || idle == active)) {
                 const uint32_t first = chunk_next;
-                chunk_next += min(n_idle, avail);
+                const uint32_t take = min(n_idle, avail);
+                chunk_next += take;
                 // entry e of the chunk sits in word (e >> 6) of lane (e & 63); all lanes take part in the exchange
                 const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
                 const uint32_t rel = first + rank - chunk_base;
                 const int src_lane = (int)(rel & 63u);
                 const uint32_t e0 = __shfl(qi0, src_lane), e1 = __shfl(qi1, src_lane), e2 = __shfl(qi2, src_lane), e3 = __shfl(qi3, src_lane);
+#ifdef VPT_PROFILE_SECTIONS
+                float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+#endif
                 if (phase == PH_IDLE) {
-                    if (rank < avail) {
+                    if (rank < take) {
                         const uint32_t word = rel >> 6;
                         const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
-                        split_slot(P, slot, kiter, pixel);
-                        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                        uint32_t new_kiter, new_pixel;
+                        split_slot(P, slot, new_kiter, new_pixel);
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
+#ifdef VPT_PROFILE_SECTIONS
+                        // (study builds: the wave waits for its records HERE, outside the divergent block, and times the wait apart from the unpacking)
+                        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                VPT_TICK(tr2);
+                if (phase == PH_IDLE) {
+                    if (rank < take) {
+                        uint32_t new_kiter, new_pixel;
+                        split_slot(P, rel >> 6 == 0u ? e0 : (rel >> 6 == 1u ? e1 : (rel >> 6 == 2u ? e2 : e3)), new_kiter, new_pixel);
+#else
                         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+#endif
+                        kiter = new_kiter;
+                        pixel = new_pixel;
+                        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         // obj word: bit 7 = (q0.w, q3.z, q3.w) is the position raygen's empty-node pushes reached (a box-first ray:
                         // depth 0, t_hit used up), bits 8.. = how many pushes that took
                         const uint32_t objw = __float_as_uint(q1.w);
@@ -399,6 +426,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         }
                     }
                 }
+                if (PROF) { nr0++; nr1 += take; }
+                VPT_TICK(tr3);
             }
         }
 

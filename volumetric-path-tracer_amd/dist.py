@@ -7,7 +7,7 @@ pixels into its own running mean; the G means are combined as sum(n_r * mean_r) 
 Payload: W*H*3 fp32 (24.9 MB at 1080p).
 
 The collective itself lives BELOW the C ABI (`vpt_allreduce_accum`, csrc/vpt_host.hip: scale kernel ->
-one grouped ncclAllReduce -> divide kernel, all on one HIP stream, no host synchronisation), so a C++
+ONE ncclAllReduce of W*H*3 + 1 floats (the count rides in the last one) -> divide kernel, all on one HIP stream, no host synchronisation), so a C++
 host gets it without Python (tools/vpt_cli.cpp --ranks).  This module is the Python host's use of it:
 torch.distributed only carries the 128-byte RCCL id from rank 0 to the others (and the barriers of
 bench.py).  `combine_means` falls back to a torch.distributed all-reduce when the context has no
