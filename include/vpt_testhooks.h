@@ -64,7 +64,9 @@ int vpt_test_fast_div_ok(float d, float r);
 int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, unsigned long long *with_patch);
 /* which per-view caches of the environment tail the LAST render used (csrc/vpt_host.hip: built for a batch of >= 2 iterations or a repeated
  * view): out[0] per-pixel sky patches, [1] never-traced pixel mask (raygen skips those pixels), [2] sky dome(s), [3] dome variants (1 behind
- * a closed lens, 2 k + 1 behind an open one), [4] camera-point scattering table, [5] view-point ground table(s) bound; [6..7] reserved */
+ * a closed lens, 2 k + 1 behind an open one), [4] camera-point scattering table, [5] view-point ground table(s) bound, [6] resolved samples
+ * (the tracer adds a finished path's environment term from the dome, sky_fix_kernel serves the rest, the tail streams 16 + 8 bytes per
+ * sample: csrc/vpt_device.h, ResolveParams::lean); [7] reserved */
 int vpt_test_get_cache_state(vpt_ctx *ctx, int out[8]);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
  * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */

@@ -438,6 +438,54 @@ def test_never_traced_pixels_change_nothing(pkg, sky, monkeypatch, view):
     assert sa.samples == w * h * 4
 
 
+@pytest.mark.parametrize("view", ["default", "horizon in view", "sphere in view", "inside the box", "render off", "chunks"])
+def test_resolved_samples_change_nothing(pkg, sky, monkeypatch, view):
+    """With the per-view caches in use behind a closed lens the TRACER adds a finished path's environment term (a sky-dome look-up where ~44
+    lanes finish together), sky_fix_kernel evaluates in full what neither the dome nor a patch serves (flagged dome cells, paths the sphere
+    bounce moved, the pixels without a usable patch), and the tail streams 16-byte heads + 8-byte {alpha, depth} pairs several iterations
+    ahead of its ordered running means (csrc/vpt_device.h: ResolveParams::lean).  Against VPT_NO_LEAN_TAIL=1 -- 64-byte path records, the
+    environment added inside the tail's per-pixel loop: the same operations on the same values in the same order, so every buffer is
+    bit-identical, on views that exercise every kind of sample."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    w, h = 320, 180
+    sd = pkg.scene.dragon_scene(w, h, "c2")
+    lib = pkg.load_library()
+    if view == "horizon in view":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(40.0, 3.0, 5.0), Float3(0.0, 3.0, 0.0), Float3(0, 1, 0), 70.0, w / h, 0.0)
+    if view == "sphere in view":
+        o = sd.camera.origin
+        sd.sphere.center = Float3(o.x * 0.55, o.y * 0.55 + 1.0, o.z * 0.55 - 2.0)
+        sd.sphere.radius = 1.5
+    if view == "inside the box":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(0.3, 0.2, 0.1), Float3(5.0, 1.0, 2.0), Float3(0, 1, 0), 60.0, w / h, 0.0)
+    if view == "render off":
+        sd.kp.max_interactions = 2
+    if view == "chunks":
+        monkeypatch.setenv("VPT_BATCH_ITERS", "3")       # 7 iterations in launches of 3 + 3 + 1
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    n = 7 if view == "chunks" else 4
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(True)
+        hb.render(n); hb.sync()
+        state = (C.c_int * 8)()
+        lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        assert lib.vpt_test_get_cache_state(hb.ctx.h, state) == 0
+        return hb, hb.ctx.stats(), list(state)
+    a, sa, ca = run()
+    assert ca[0] and ca[2] and ca[6], ca                  # patches, dome, resolved samples
+    monkeypatch.setenv("VPT_NO_LEAN_TAIL", "1")
+    b, sb, cb = run()
+    assert cb[0] and cb[2] and not cb[6], cb
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy(), err_msg=buf)
+    for k in ("samples", "density_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+        assert getattr(sa, k) == getattr(sb, k), k
+    assert np.isfinite(a.accum.cpu().numpy()).all() and float(a.accum.max()) > 0
+
+
 @pytest.mark.parametrize("view", ["default", "horizon in view", "sun in view", "1080p"])
 def test_sky_dome_matches_full_evaluation(pkg, sky, monkeypatch, view):
     """Traced samples that look from the camera origin take the environment term from the SKY DOME (csrc/vpt_tail.hip: sky_dome_kernel -- the

@@ -132,6 +132,16 @@ struct Counters {
 #endif
 #define VPT_SUB3 (VPT_SUB * VPT_SUB * VPT_SUB)
 
+struct ResolveInTracer {
+    const float4* sky_dome;          // ResolveParams::sky_dome
+    float4* heads;                   // == TraceParams::heads
+    float2* td;                      // [iter_count][n_pixels] {alpha, depth} of the resolved samples
+    uint32_t* queue2;                // record slots whose environment term needs the full evaluation
+    uint32_t* queue2_tail;
+    float cam_origin[3];
+    float pad_;
+};
+
 struct TraceParams {
     // work distribution
     uint32_t width, height, n_pixels;
@@ -156,6 +166,13 @@ struct TraceParams {
     Counters* prof;                  // section cycle counters of -DVPT_PROFILE_SECTIONS builds (else unused)
     const unsigned char* never_traced;   // [n_pixels] or NULL: 1 = no primary ray of this pixel can start a walk and its samples' values come
                                      // from the pixel's sky patch (ResolveParams::never_traced): raygen emits nothing for it
+    // RESOLVED SAMPLES (closed lens, direct integrator, procedural sky, per-view caches in use; ResolveParams::td): the tracer itself adds a
+    // finished path's environment term -- a sky-dome look-up along its exit direction, at the ~44 lanes a transition pass finishes together --
+    // and writes the sample as a 16-byte head {value, -1} + 8 bytes {alpha, depth} instead of a 64-byte path record; a path the dome cannot
+    // serve (a flagged cell, an origin moved by the sphere bounce) keeps its record and its slot goes into queue2 for sky_fix_kernel.
+    // What that takes sits behind ONE pointer to device memory (the tracer keeps 100 scalars live across its loop as it is; these are
+    // read where a batch of paths finishes, not carried).
+    const struct ResolveInTracer* resolve;   // or NULL: every finished path writes its 64-byte record (the tail adds the environment)
     float* pool_hist;                // pool tracer (vpt_trace_pool.hip): density histories of the fused first walk, [workgroup][entry][ray]
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera
@@ -252,6 +269,17 @@ struct ResolveParams {
     // costs four float4 reads and nine FMAs instead of sample_atmosphere; the others are evaluated as before.  VALUE-ONLY.
     const float4* sky_dome;          // [SKY_DOME_NV][SKY_DOME_NU] {value.rgb, cell flag}, or NULL
     const float2* blue_noise;        // [iter_count][65536]: the chunk's jitter tables (what raygen read), for the patch
+    // RESOLVED SAMPLES (TraceParams::resolve): with the per-view caches in use behind a closed lens the tail proper (tail_stream_kernel) evaluates
+    // no sky at all -- a sample is a head {dir0, depth >= 0} (untraced: the pixel's patch at its jitter), {-, -, -, -2} (not rendered) or
+    // {value, -1} + td {alpha, depth} (resolved by the tracer's dome look-up or by sky_fix_kernel) -- and streams its 16 + 8 bytes per sample
+    // several iterations ahead of the ordered running means.  sky_fix_kernel runs between tracer and tail over (a) queue2, the paths the dome
+    // could not serve, and (b) the untraced samples of the pixels WITHOUT a usable patch (nopatch_list, written with the patches).
+    int lean;
+    float2* td;
+    const uint32_t* queue2;
+    const uint32_t* queue2_count;
+    const uint32_t* nopatch_list;    // pixels whose patch failed its check (horizon, sun's disc: a few hundred of a 1080p frame)
+    const uint32_t* nopatch_count;
     float cam_llc[3], cam_h[3], cam_v[3];   // camera frame (lower_left_corner, horizontal, vertical), for the patch corners
     // NEVER-TRACED pixels (written by sky_patch_kernel next to the patches): a pixel whose whole jitter footprint lies outside the
     // screen-space bounds of the volumes' root box (cull_rect, in pixels, already grown by the margin), whose rays all pass the

@@ -33,12 +33,13 @@ bool trace_pool_supports(const TraceParams& P);
 hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
 hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
+hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream);
 hipError_t launch_sky_cam_table(const ResolveParams& R, SkyView* view, float4* out, int k, hipStream_t stream);
 size_t sky_cam_table_bytes();
 size_t sky_dir_table_bytes();
 hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
 hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
-hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream);
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, uint32_t* nopatch_list, uint32_t* nopatch_count, hipStream_t stream);
 hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* out, int k, hipStream_t stream);
 size_t sky_dome_bytes(int k);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
@@ -105,6 +106,13 @@ struct vpt_ctx {
     // scratch
     Record* d_records = nullptr;
     float4* d_heads = nullptr;             // 16-byte sample heads, same capacity as d_records
+    float2* d_td = nullptr;                // {alpha, depth} of the resolved samples (TraceParams::td), same capacity, allocated on first use
+    size_t td_capacity = 0;
+    uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td
+    uint32_t* d_nopatch = nullptr;         // [0]: count, [1..]: pixels without a usable sky patch (ResolveParams::nopatch_list), with d_sky_patch
+    ResolveInTracer* d_resolve = nullptr;  // TraceParams::resolve
+    ResolveInTracer resolve_host = {};     // what d_resolve holds
+    bool no_lean_tail = false;             // VPT_NO_LEAN_TAIL: finished paths keep their 64-byte records and the tail adds the environment (A/B, tests)
     float4* d_head_org = nullptr;          // ray origins of the heads (thin lens: lens_radius != 0), allocated on first use
     size_t head_org_capacity = 0;
     size_t records_capacity = 0;           // in records
@@ -354,6 +362,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_patch = std::getenv("VPT_NO_SKY_PATCH") != nullptr;
     ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
+    ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -391,6 +400,10 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_sub_offsets);
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_heads);
+    (void)hipFree(ctx->d_td);
+    (void)hipFree(ctx->d_queue2);
+    (void)hipFree(ctx->d_nopatch);
+    (void)hipFree(ctx->d_resolve);
     (void)hipFree(ctx->d_head_org);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_pool_hist);
@@ -938,6 +951,7 @@ int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
     out[3] = R.sky_dome != nullptr ? 2 * ctx->sky_dome_k + 1 : 0;
     out[4] = R.cam_tab_valid;
     out[5] = R.dir_tab != nullptr;
+    out[6] = R.lean;
     return VPT_OK;
 }
 
@@ -1355,6 +1369,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
         (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
+        (void)hipFree(ctx->d_td); ctx->d_td = nullptr; ctx->td_capacity = 0;
+        (void)hipFree(ctx->d_queue2); ctx->d_queue2 = nullptr;
         hipError_t e = hipMalloc(&ctx->d_records, chunk * per_iter * sizeof(Record));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, chunk * per_iter * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_heads, chunk * per_iter * sizeof(float4));
@@ -1498,6 +1514,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 (void)hipFree(ctx->d_never_traced); ctx->d_never_traced = nullptr;
                 HIPCHK(ctx, hipMalloc(&ctx->d_sky_patch, (size_t)n_pixels * 3u * sizeof(float4)));
                 HIPCHK(ctx, hipMalloc(&ctx->d_never_traced, (size_t)n_pixels));
+                (void)hipFree(ctx->d_nopatch); ctx->d_nopatch = nullptr;
+                HIPCHK(ctx, hipMalloc(&ctx->d_nopatch, ((size_t)n_pixels + 1u) * sizeof(uint32_t)));
                 ctx->sky_patch_pixels = n_pixels;
                 ctx->sky_patch_built = false;
             }
@@ -1512,7 +1530,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             if (use_caches && !built_for_this) {
                 if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
                 tables_written = true;
-                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, stream));
+                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, ctx->d_nopatch + 1, ctx->d_nopatch, stream));
                 if (!ctx->no_sky_dome) {
                     if (ctx->sky_dome_k < 0) {
                         HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sky_dome_bytes(0)));
@@ -1531,6 +1549,35 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 if (R.cull_enabled) {
                     R.never_traced = ctx->d_never_traced;
                     P.never_traced = ctx->d_never_traced;
+                }
+                // RESOLVED SAMPLES (vpt_device.h): patches + dome in use => the tracer resolves its finished paths from the dome and the tail
+                // streams heads only.  (The pool tracer, an A/B harness, keeps the records.)
+                if (R.sky_dome != nullptr && !ctx->no_lean_tail && !ctx->use_pool) {
+                    if (ctx->td_capacity < ctx->records_capacity) {
+                        HIPCHK(ctx, hipStreamSynchronize(stream));
+                        (void)hipFree(ctx->d_td); ctx->d_td = nullptr; ctx->td_capacity = 0;
+                        (void)hipFree(ctx->d_queue2); ctx->d_queue2 = nullptr;
+                        HIPCHK(ctx, hipMalloc(&ctx->d_td, ctx->records_capacity * sizeof(float2)));
+                        HIPCHK(ctx, hipMalloc(&ctx->d_queue2, ctx->records_capacity * sizeof(uint32_t)));
+                        ctx->td_capacity = ctx->records_capacity;
+                    }
+                    R.lean = 1;
+                    R.td = ctx->d_td;
+                    R.queue2 = ctx->d_queue2;
+                    R.queue2_count = ctx->d_work_counter + 4;
+                    R.nopatch_list = ctx->d_nopatch + 1;
+                    R.nopatch_count = ctx->d_nopatch;
+                    ResolveInTracer rt;
+                    std::memset(&rt, 0, sizeof(rt));
+                    rt.sky_dome = R.sky_dome; rt.heads = ctx->d_heads; rt.td = ctx->d_td; rt.queue2 = ctx->d_queue2; rt.queue2_tail = ctx->d_work_counter + 4;
+                    rt.cam_origin[0] = cam->origin.x; rt.cam_origin[1] = cam->origin.y; rt.cam_origin[2] = cam->origin.z;
+                    if (!ctx->d_resolve) HIPCHK(ctx, hipMalloc(&ctx->d_resolve, sizeof(ResolveInTracer)));
+                    if (std::memcmp(&rt, &ctx->resolve_host, sizeof(rt)) != 0) {
+                        // (kernels of an earlier render on this stream may still read the block: the copy is ordered behind them)
+                        ctx->resolve_host = rt;
+                        HIPCHK(ctx, hipMemcpyAsync(ctx->d_resolve, &ctx->resolve_host, sizeof(rt), hipMemcpyHostToDevice, stream));
+                    }
+                    P.resolve = ctx->d_resolve;
                 }
             }
         }
@@ -1636,7 +1683,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
-        HIPCHK(ctx, launch_tail_resolve(R, stream));             // environment tail + resolve, fused
+        if (R.lean) HIPCHK(ctx, launch_tail_stream(R, stream));  // sky_fix_kernel over what the dome did not serve, then the streaming tail
+        else HIPCHK(ctx, launch_tail_resolve(R, stream));        // environment tail + resolve, fused
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));
         for (int k = 0; k < 3; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
         ctx->last_samples += total;

@@ -23,6 +23,7 @@
 // Tolerance against the oracle (which restates the reference literally): tests/test_gpu_atmosphere.py.
 #pragma once
 
+#include "vpt_dome.h"
 #include "vpt_tex.h"
 
 namespace vpt {
@@ -42,13 +43,6 @@ enum {
     AF_COUNT = 34,
 };
 
-VPT_D float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-VPT_D float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-VPT_D float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-VPT_D float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-VPT_D float flerp(float a, float b, float t) { return ffma(t, b - a, a); }
-VPT_D f3 flerp3(f3 a, f3 b, float t) { return mk3(flerp(a.x, b.x, t), flerp(a.y, b.y, t), flerp(a.z, b.z, t)); }
-VPT_D f3 fscale_add3(f3 a, float s, f3 b) { return mk3(ffma(a.x, s, b.x), ffma(a.y, s, b.y), ffma(a.z, s, b.z)); }
 // texel fetch through a 32-bit BYTE offset (tables are <= 16 MiB): SGPR base + VGPR offset addressing
 VPT_D f3 ld_f3(const float4* __restrict__ p, uint32_t i) {
     const uint32_t off = i << 4;

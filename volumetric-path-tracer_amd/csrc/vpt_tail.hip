@@ -63,6 +63,65 @@ VPT_D f3 tonemap(f3 acc, float exposure_scale, unsigned int& packed) {
 #ifndef VPT_TAIL_WAVES_PER_EU
 #define VPT_TAIL_WAVES_PER_EU 4
 #endif
+// what volume_rt_kernel does with a sample value (:2263-2287): NaN guard, viz_dof tint, running means -- and with the means at the end of
+// a launch (:2292-2316).  One pixel's state; shared by the two tail kernels so that they cannot drift apart.
+struct RunningMeans {
+    f3 acc, cst;
+    float dep, tr_last;
+    VPT_D void add(const ResolveParams& R, f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it, double rn) {
+        // :2263-2264
+        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
+        if (isnan(tr) || isinf(tr)) tr = 1.0f;
+        // :2266-2274
+        if (R.viz_dof) {
+            float aof = clampf(__fdiv_rn(1.0f, R.lens_radius), .0f, 3.402823466e+38F);
+            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
+            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
+            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
+        }
+        // :2278-2287 (cost is always BLACK, :2249)
+        if (local_it == 0) {
+            acc = value;
+            cst = mk3(0.0f);
+            dep = depth;
+        } else if (iteration < R.max_interactions) {
+            const float n = (float)(local_it + 1);
+            if (rn != 0.0) {
+                acc = acc + mul_rn(value - acc, rn);
+                // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the quotients are skipped then
+                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+                else cst = cst + mul_rn(mk3(0.0f) - cst, rn);
+                dep = dep + mul1_rn(depth - dep, rn);
+            } else {
+                acc = acc + div_rn(value - acc, n);
+                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
+                else cst = cst + div_rn(mk3(0.0f) - cst, n);
+                dep = dep + div1_rn(depth - dep, n);
+            }
+        }
+        tr_last = tr;
+    }
+    VPT_D static RunningMeans load(const ResolveParams& R, uint32_t idx) {
+        RunningMeans m;
+        m.acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
+        m.cst = R.cost ? mk3(R.cost[3 * idx], R.cost[3 * idx + 1], R.cost[3 * idx + 2]) : mk3(0.0f);
+        m.dep = R.depth ? R.depth[idx] : 0.0f;
+        m.tr_last = 0.0f;
+        return m;
+    }
+    VPT_D void store(const ResolveParams& R, uint32_t idx) const {
+        R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;
+        if (R.cost) { R.cost[3 * idx] = cst.x; R.cost[3 * idx + 1] = cst.y; R.cost[3 * idx + 2] = cst.z; }
+        if (R.depth) R.depth[idx] = dep;
+        if (R.display || R.raw) {
+            unsigned int packed;
+            const f3 val = tonemap(acc, R.exposure_scale, packed);
+            if (R.display) R.display[idx] = packed;
+            if (R.raw) reinterpret_cast<float4*>(R.raw)[idx] = make_float4(val.x, val.y, val.z, tr_last);
+        }
+    }
+};
+
 // LENS: the tables have one variant per binary32 step of r across the lens disc (SkyView); else one, the camera origin's
 template <bool LENS>
 VPT_D void load_sky_view(const ResolveParams& R, Sky<ResolveParams>& sky) {
@@ -79,7 +138,8 @@ VPT_D void load_sky_view(const ResolveParams& R, Sky<ResolveParams>& sky) {
 // (ResolveParams).  Two instantiations: each keeps its own register budget (the kernel spills at 4 waves per SIMD).
 // per-pixel sky patch (ResolveParams::sky_patch): one thread per pixel evaluates the untraced-sample value at the pixel's four
 // corners and at its centre, keeps the corners when the bilinear patch reproduces the centre to 1e-3
-__global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, float4* __restrict__ out, unsigned char* __restrict__ never) {
+__global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, float4* __restrict__ out, unsigned char* __restrict__ never,
+                                                        uint32_t* __restrict__ nopatch_list, uint32_t* __restrict__ nopatch_count) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
     const uint32_t y = idx / R.width, x = idx - y * R.width;
@@ -121,6 +181,8 @@ __global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, f
     o[0] = make_float4(ok ? v00.x : __uint_as_float(0x7fc00000u), v00.y, v00.z, v10.x);
     o[1] = make_float4(v10.y, v10.z, v01.x, v01.y);
     o[2] = make_float4(v01.z, v11.x, v11.y, v11.z);
+    // the pixels without a usable patch, listed for sky_fix_kernel (ResolveParams::nopatch_list; the count was zeroed by the host)
+    if (!ok && nopatch_list) nopatch_list[atomicAdd(nopatch_count, 1u)] = idx;
     // never-traced pixels (ResolveParams::cull_*): the pixel's square [x, x+1] x [y, y+1] against the grown bounds
     if (never) {
         bool nt = ok && R.cull_enabled != 0;
@@ -138,31 +200,14 @@ __global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, f
         never[idx] = nt ? 1 : 0;
     }
 }
-hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, hipStream_t stream) {
-    hipLaunchKernelGGL(sky_patch_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R, out, never);
+hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, uint32_t* nopatch_list, uint32_t* nopatch_count, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(nopatch_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sky_patch_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R, out, never, nopatch_list, nopatch_count);
     return hipGetLastError();
 }
 
-// ---- sky dome (ResolveParams::sky_dome) ------------------------------------------------------------------------------------------
-// direction <-> dome coordinates: v = dir.y in [-1, 1] (rows), u in [0, 4) the L1 azimuth in the xz plane: t = x / (|x| + |z|),
-// u = 1 - t for z >= 0 (x runs +1 -> -1), u = 3 + t for z < 0 (x runs -1 -> +1); periodic, piecewise smooth with its kinks (the axes) on nodes
-VPT_D void dome_coords(f3 d, float& fu, float& fv) {
-    const float s = fabsf(d.x) + fabsf(d.z);
-    const float tt = s > 0.0f ? d.x * frcp(s) : 1.0f;
-    const float u = d.z >= 0.0f ? 1.0f - tt : 3.0f + tt;
-    fu = u * (float)(SKY_DOME_NU / 4);
-    fv = fmin_(fmax_(ffma(d.y, 0.5f, 0.5f), 0.0f), 1.0f) * (float)(SKY_DOME_NV - 1);
-}
-VPT_D f3 dome_direction(float fu, float fv) {
-    const float v = clampf(ffma(fv, 2.0f / (float)(SKY_DOME_NV - 1), -1.0f), -1.0f, 1.0f);
-    float u = fu * (4.0f / (float)SKY_DOME_NU);
-    u = u >= 4.0f ? u - 4.0f : u;
-    const bool front = u <= 2.0f;
-    const float tt = front ? 1.0f - u : u - 3.0f;
-    const float x = tt, z = (1.0f - fabsf(tt)) * (front ? 1.0f : -1.0f);
-    const float rxz = fsqrt(fmax_(1.0f - v * v, 0.0f)) * frcp(fsqrt(x * x + z * z));
-    return mk3(x * rxz, v, z * rxz);
-}
+// ---- sky dome (ResolveParams::sky_dome): coordinates and look-up in vpt_dome.h ---------------------------------------------------
 // one thread per cell (i, j): its four corner nodes and its centre, evaluated from the camera origin; writes node (i, j) and the cell's flag
 // LENS: one dome per table variant (SkyView: one per binary32 value of r across the lens disc) -- the sky sees a sample's origin only through
 // r and mu_s, so a dome built from the camera origin displaced by the variant's steps of r serves every lens origin of that r
@@ -220,24 +265,6 @@ hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* 
     else hipLaunchKernelGGL(sky_dome_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, stream, R, view, out);
     return hipGetLastError();
 }
-// the dome's value along d (ResolveParams::sky_dome); false: the cell is flagged, evaluate in full
-VPT_D bool dome_lookup(const float4* __restrict__ dome, f3 d, f3& value) {
-    float fu, fv;
-    dome_coords(d, fu, fv);
-    const float flu = floorf(fu), flv = fminf(floorf(fv), (float)(SKY_DOME_NV - 2));
-    const float au = fu - flu, av = fv - flv;
-    uint32_t i0 = (uint32_t)flu;
-    i0 = i0 >= (uint32_t)SKY_DOME_NU ? i0 - (uint32_t)SKY_DOME_NU : i0;
-    const uint32_t i1 = i0 + 1u == (uint32_t)SKY_DOME_NU ? 0u : i0 + 1u;
-    const uint32_t r0 = (uint32_t)flv * (uint32_t)SKY_DOME_NU, r1 = r0 + (uint32_t)SKY_DOME_NU;
-    const float4 a = dome[r0 + i0];
-    if (a.w == 0.0f) return false;
-    const float4 b = dome[r0 + i1], c = dome[r1 + i0], e = dome[r1 + i1];
-    const f3 lo = flerp3(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), au), hi = flerp3(mk3(c.x, c.y, c.z), mk3(e.x, e.y, e.z), au);
-    value = flerp3(lo, hi, av);
-    return true;
-}
-
 template <bool HEADS, bool LENS>
 __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,10 +286,6 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         bn_idx = (py & 255u) * 256u + (px & 255u);
     }
     if (idx >= R.n_pixels) return;
-    f3 acc = mk3(R.accum[3 * idx], R.accum[3 * idx + 1], R.accum[3 * idx + 2]);
-    f3 cst = R.cost ? mk3(R.cost[3 * idx], R.cost[3 * idx + 1], R.cost[3 * idx + 2]) : mk3(0.0f);
-    float dep = R.depth ? R.depth[idx] : 0.0f;
-    float tr_last = 0.0f;
     const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
     Sky<ResolveParams> sky = {R};
@@ -273,40 +296,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
 
     // floor((iter_begin + k * stride) / stride) = floor(iter_begin / stride) + k: one division per launch, not per sample
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
-    // what volume_rt_kernel does with a sample value (:2263-2287): NaN guard, viz_dof tint, running means
-    auto accumulate = [&](f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it, double rn) {
-        // :2263-2264
-        if (isnan(value.x) || isnan(value.y) || isnan(value.z) || isinf(value.x) || isinf(value.y) || isinf(value.z)) value = acc;
-        if (isnan(tr) || isinf(tr)) tr = 1.0f;
-        // :2266-2274
-        if (R.viz_dof) {
-            float aof = clampf(__fdiv_rn(1.0f, R.lens_radius), .0f, 3.402823466e+38F);
-            if (depth > (R.focus_dist + aof)) value = lerp3(value, mk3(1, 0, 0), 0.5f);
-            if (depth < (R.focus_dist - aof)) value = lerp3(value, mk3(0, 0, 1), 0.5f);
-            if (depth > (R.focus_dist - aof) && depth < (R.focus_dist + aof)) value = lerp3(value, mk3(0, 1, 0), 0.5f);
-        }
-        // :2278-2287 (cost is always BLACK, :2249)
-        if (local_it == 0) {
-            acc = value;
-            cst = mk3(0.0f);
-            dep = depth;
-        } else if (iteration < R.max_interactions) {
-            const float n = (float)(local_it + 1);
-            if (rn != 0.0) {
-                acc = acc + mul_rn(value - acc, rn);
-                // cost is always BLACK: 0 + (0 - 0)/n == +0 exactly (also from -0), so the quotients are skipped then
-                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
-                else cst = cst + mul_rn(mk3(0.0f) - cst, rn);
-                dep = dep + mul1_rn(depth - dep, rn);
-            } else {
-                acc = acc + div_rn(value - acc, n);
-                if (cst.x == 0.0f && cst.y == 0.0f && cst.z == 0.0f) cst = mk3(0.0f);
-                else cst = cst + div_rn(mk3(0.0f) - cst, n);
-                dep = dep + div1_rn(depth - dep, n);
-            }
-        }
-        tr_last = tr;
-    };
+    RunningMeans rm = RunningMeans::load(R, idx);
+    auto accumulate = [&](f3 value, float tr, float depth, uint32_t iteration, uint32_t local_it, double rn) { rm.add(R, value, tr, depth, iteration, local_it, rn); };
     if (never) {
         // a pixel raygen emitted nothing for (ResolveParams::never_traced): every sample is untraced with depth 0, its value the patch at the
         // sample's jitter -- or WHITE when the sample is not rendered (:2248, :2254).  No head, no record, no sky code: waves over the background
@@ -407,16 +398,113 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         accumulate(value, tr, depth, iteration, local_it, R.rcp_n[k]);
     }
     }
-    R.accum[3 * idx] = acc.x; R.accum[3 * idx + 1] = acc.y; R.accum[3 * idx + 2] = acc.z;
-    if (R.cost) { R.cost[3 * idx] = cst.x; R.cost[3 * idx + 1] = cst.y; R.cost[3 * idx + 2] = cst.z; }
-    if (R.depth) R.depth[idx] = dep;
+    rm.store(R, idx);
+}
 
-    if (R.display || R.raw) {
-        unsigned int packed;
-        const f3 val = tonemap(acc, R.exposure_scale, packed);
-        if (R.display) R.display[idx] = packed;
-        if (R.raw) reinterpret_cast<float4*>(R.raw)[idx] = make_float4(val.x, val.y, val.z, tr_last);
+// ---- RESOLVED SAMPLES (ResolveParams::lean; TraceParams::resolve) ------------------------------------------------------------------
+// sky_fix_kernel: the full sample_atmosphere for the few samples nothing cheaper serves, one thread each at full occupancy (inside the
+// per-pixel loop of the tail a wave ran it as soon as ONE lane needed it -- a third of the waves over the volume, for 1-2 % of their samples):
+//   (a) queue2: finished paths whose exit direction falls into a flagged dome cell, or whose origin the sphere bounce moved -- their 64-byte
+//       record is read, the environment term added as the tail would (:1838-1842), the sample written as head + td;
+//   (b) the untraced samples of the pixels without a usable patch (nopatch_list x the launch's iterations): L = 0, beta = 1, from the camera origin.
+__global__ __launch_bounds__(256) void sky_fix_kernel(const ResolveParams R, float4* __restrict__ heads) {
+    Sky<ResolveParams> sky = {R};
+    load_sky_view<false>(R, sky);
+    const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
+    const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
+    const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
+    const uint32_t n_a = *R.queue2_count, n_b = *R.nopatch_count * R.iter_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_a + n_b; t += stride) {
+        if (t < n_a) {
+            const uint32_t slot = R.queue2[t];
+            const float4* rec = reinterpret_cast<const float4*>(R.records + slot);
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            f3 value = mk3(q0.x, q0.y, q0.z);
+            const f3 beta = mk3(q1.x, q1.y, q1.z);
+            value += sky.sample(mk3(q2.x, q2.y, q2.z), mk3(q3.x, q3.y, q3.z), sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
+            heads[slot] = make_float4(value.x, value.y, value.z, -1.0f);
+            R.td[slot] = make_float2(q0.w, q1.w);
+        } else {
+            const uint32_t e = t - n_a;
+            const uint32_t p = e / R.iter_count, k = e - p * R.iter_count;
+            const size_t slot = (size_t)k * R.n_pixels + R.nopatch_list[p];
+            const float4 h = heads[slot];
+            if (h.w >= 0.0f) {
+                // (as the tail did for such a sample: L = 0, beta = 1, the dome where its cell passed, else in full)
+                const f3 dir = mk3(h.x, h.y, h.z);
+                f3 value = mk3(0.0f), dv;
+                if (dome_lookup(R.sky_dome, dir, dv)) value += dv * mk3(1.0f);
+                else value += sky.sample(mk3(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2]), dir, sun_dir, use_dir_tab) * mk3(1.0f) * R.sky_mult * sky_color;
+                heads[slot] = make_float4(value.x, value.y, value.z, -1.0f);
+                R.td[slot] = make_float2(0.0f, h.w);
+            }
+        }
     }
+}
+// tail_stream_kernel: the tail proper once every sample is a head (ResolveParams::lean).  One thread per pixel; the running means are an
+// ordered recurrence, so a pixel's iterations stay sequential -- but nothing it reads depends on what it computes: the heads, jitters and
+// {alpha, depth} pairs of VPT_TAIL_GROUP iterations are requested together (two memory round trips per group instead of one or two per
+// iteration: the old loop's 64 iterations were a chain of ~100 dependent latencies).
+#ifndef VPT_TAIL_GROUP
+#define VPT_TAIL_GROUP 8
+#endif
+__global__ __launch_bounds__(256) void tail_stream_kernel(const ResolveParams R) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R.n_pixels) return;
+    const float4* pp = R.sky_patch + 3u * (size_t)idx;
+    const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+    const f3 v00 = mk3(pa.x, pa.y, pa.z), v10 = mk3(pa.w, pb.x, pb.y), v01 = mk3(pb.z, pb.w, pc.x), v11 = mk3(pc.y, pc.z, pc.w);
+    const bool never = R.never_traced != nullptr && R.never_traced[idx] != 0;
+    const uint32_t py = idx / R.width, px = idx - py * R.width;
+    const float2* bnp = R.blue_noise + ((py & 255u) * 256u + (px & 255u));
+    const uint32_t local_it0 = R.iter_begin / R.iter_stride;
+    RunningMeans rm = RunningMeans::load(R, idx);
+    for (uint32_t k0 = 0; k0 < R.iter_count; k0 += (uint32_t)VPT_TAIL_GROUP) {
+        float4 h[VPT_TAIL_GROUP];
+        float2 j[VPT_TAIL_GROUP], td[VPT_TAIL_GROUP];
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
+            const uint32_t k = k0 + u;
+            const bool live = k < R.iter_count;
+            // a pixel raygen emitted nothing for has no heads: every sample is untraced with depth 0 (or not rendered)
+            h[u] = (live && !never) ? R.heads[(size_t)k * R.n_pixels + idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
+            const uint32_t k = k0 + u;
+            td[u] = (k < R.iter_count && h[u].w == -1.0f) ? R.td[(size_t)k * R.n_pixels + idx] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
+            const uint32_t k = k0 + u;
+            if (k < R.iter_count) {
+                const uint32_t iteration = R.iter_begin + k * R.iter_stride;
+                f3 value;
+                float tr = 0.0f, depth = 0.0f;
+                if (never) {
+                    value = (iteration < R.max_interactions && R.render) ? flerp3(flerp3(v00, v10, j[u].x), flerp3(v01, v11, j[u].x), j[u].y) : mk3(1.0f);
+                } else if (h[u].w >= 0.0f) {
+                    value = flerp3(flerp3(v00, v10, j[u].x), flerp3(v01, v11, j[u].x), j[u].y);      // untraced: the patch at the sample's jitter
+                    depth = h[u].w;
+                } else if (h[u].w == -1.0f) {
+                    value = mk3(h[u].x, h[u].y, h[u].z);                                               // resolved by the tracer or by sky_fix_kernel
+                    tr = td[u].x;
+                    depth = td[u].y;
+                } else {
+                    value = mk3(1.0f);                                                                 // not rendered: WHITE (:2248, :2254)
+                }
+                rm.add(R, value, tr, depth, iteration, local_it0 + k, R.rcp_n[k]);
+            }
+        }
+    }
+    rm.store(R, idx);
+}
+hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream) {
+    hipLaunchKernelGGL(sky_fix_kernel, dim3(512), dim3(256), 0, stream, R, const_cast<float4*>(R.heads));
+    hipLaunchKernelGGL(tail_stream_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
+    return hipGetLastError();
 }
 
 // display / raw images of an accumulation buffer that was changed outside the render (vpt_allreduce_accum: the batch

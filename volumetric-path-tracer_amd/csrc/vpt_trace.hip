@@ -35,6 +35,7 @@
 //   * the Philox counter, not the schedule, defines a sample: results are bit-identical
 //     for any grid size / refill order;
 //   * octree occupancy bits sit in LDS; node boxes are re-derived by halving.
+#include "vpt_dome.h"
 #include "vpt_trace_direct.h"
 
 namespace vpt {
@@ -677,11 +678,37 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             VPT_TICK(ts2);                       // OUTER_SECOND + OUTER_TOP
             if (phase == PH_T_FINISH) {
                 const f3 od = w.dir, oL = L, ob = beta, oe = env_pos;
-                float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
-                dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // tr = fminf(tr, 1) :1854
-                dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
-                dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
-                dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
+                const size_t slot = (size_t)kiter * P.n_pixels + pixel;
+                // RESOLVED SAMPLES (TraceParams::resolve): what the tail would add to L -- beta x the sky along the exit direction, seen from the
+                // camera origin -- is a dome look-up, done here where ~44 lanes finish together; the sample then leaves as 24 bytes instead of 64.
+                bool resolved = false;
+                const ResolveInTracer* rt = P.resolve;
+                if (rt != nullptr) {
+                    asm volatile("" : "+s"(rt));       // (its fields are fetched here, per batch of finishing paths, not hoisted into the loop's live scalars)
+                    f3 dv;
+                    if (oe.x == rt->cam_origin[0] && oe.y == rt->cam_origin[1] && oe.z == rt->cam_origin[2] && dome_lookup(rt->sky_dome, od, dv)) {
+                        const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
+                        rt->heads[slot] = make_float4(val.x, val.y, val.z, -1.0f);
+                        rt->td[slot] = make_float2(fmin_(w.alpha, 1.0f), depth);
+                        resolved = true;
+                    }
+                }
+                if (!resolved) {
+                    float4* dst = reinterpret_cast<float4*>(P.records + slot);
+                    dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // tr = fminf(tr, 1) :1854
+                    dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
+                    dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
+                    dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
+                    if (rt != nullptr) {
+                        // the full evaluation is sky_fix_kernel's (vpt_tail.hip): one queue entry per such path, one atomic per wave
+                        const unsigned long long qm = __ballot(1);
+                        const int ql = __ffsll((long long)qm) - 1;
+                        uint32_t qb = 0;
+                        if (lane == ql) qb = atomicAdd(rt->queue2_tail, (uint32_t)__popcll(qm));
+                        qb = (uint32_t)__shfl((int)qb, ql);
+                        rt->queue2[qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+                    }
+                }
                 if (COUNT) {
                     atomicAdd(&P.counters->samples, 1ull);
                     if (cnt.n_steps == 0u) atomicAdd(&P.counters->coh[6], 1ull);       // traced rays that crossed empty nodes only (no draw, no look-up)
