@@ -67,43 +67,53 @@ def make_scene(pkg, cfg, W, H, spp, grid_scale, dev, local_rank):
     return sd, workload, data, W, H
 
 
-def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator):
-    """cs: stats of a counted pass, st: HIP-event times of the last timed step.
+def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator, lean=False):
+    """cs: stats of a counted pass, st: HIP-event times of the last timed step; lean: the tracer resolved its finished paths itself
+    (24 bytes out per ray instead of a 64-byte path record, csrc/vpt_device.h ResolveParams::lean).
 
-    Three fractions of the 8 TB/s HBM peak, each recomputable from this line and profiles/ of the same commit:
-      frac_kernel (= `frac`): bytes the tracer has to move (the trilinear fetches it issues: density at every step for
-          the instances whose domain holds the point, colour at real collisions, emission; plus its record stream:
-          4 + 64 B read and 64 B written per traced ray) / its HIP-event duration
-      frac_step: the same look-up bytes + the 88-byte framebuffer term of BASELINE.md 3, x samples / whole-step time
-      hbm_measured_frac: FETCH_SIZE x 2 + WRITE_SIZE of the tracer (rocprofv3 --pmc, profiles/traffic.json) / its duration
-    and, for reference, frac_step_reference_counts with the reference-defined look-up counts of SURVEY 8d (every
-    instance of the leaf at every step, the first walk twice): not a bound on this kernel (it exceeds 1 on config 5)."""
+    `frac` IS BASELINE.md 3 / SURVEY 8d VERBATIM: B = 32 N_d + 128 N_c + 32 N_e + 88 bytes per pixel-sample with the REFERENCE-defined look-up
+    counts (every instance of the leaf at every step, the colour at every step, the first walk twice -- what render_kernel.cu evaluates and the
+    oracle counts), x samples per step / whole-step wall time / 8 TB/s.  `kernel` names the dominant kernel of the step.  (Not a bound on this
+    implementation where the reference evaluates and discards: config 5's 13 colour look-ups per sample put it above 1.)
+    Next to it, recomputable from this line and profiles/ of the same commit:
+      frac_kernel_issued_fetches: bytes the tracer itself has to move -- `lookup_bytes` (the trilinear fetches it ISSUES: density for the
+          instances whose domain holds the point, colour at real collisions, emission) + `record_stream_bytes` (its own ray / path records:
+          4 + 64 B read and 64 B -- 24 B when `lean` -- written per traced ray; self-imposed traffic) / the tracer's HIP-event duration
+      frac_step_issued_fetches: the issued look-up bytes + the 88-byte framebuffer term, x samples / whole-step time
+      hbm_measured_frac: FETCH_SIZE x 2 + WRITE_SIZE of the tracer (rocprofv3 --pmc, profiles/traffic.json) / its duration"""
     n = float(max(1, cs.samples))
     nd, nc, ne = cs.density_lookups / n, cs.color_lookups / n, cs.emission_lookups / n
     fd, fc, fe = cs.density_fetches / n, cs.color_fetches / n, cs.emission_fetches / n
     counted_iters = max(1.0, n / float(W * H))
     traced = cs.queued_rays / float(W * H) / counted_iters
     b_lookup = 32.0 * fd + 128.0 * fc + 32.0 * fe
-    b_kernel = b_lookup + 132.0 * traced
+    b_records = (4.0 + 64.0 + (24.0 if lean else 64.0)) * traced
+    b_kernel = b_lookup + b_records
     b_step = b_lookup + 88.0
     b_ref = 32.0 * nd + 128.0 * nc + 32.0 * ne + 88.0
     kernel_name = "vpt::trace_vol_kernel" if integrator else "vpt::trace_kernel"
     trace_s = st.trace_ms * 1e-3
-    achieved = b_kernel * samples_per_step / trace_s / 1e9 if trace_s > 0 else 0.0
+    achieved_kernel = b_kernel * samples_per_step / trace_s / 1e9 if trace_s > 0 else 0.0
+    achieved = b_ref * samples_per_step / step_s / 1e9
     r = {
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "frac_kernel": round(achieved / HBM_PEAK_GBS, 5),
-        "frac_step": round(b_step * samples_per_step / step_s / 1e9 / HBM_PEAK_GBS, 5),
-        "frac_step_reference_counts": round(b_ref * samples_per_step / step_s / 1e9 / HBM_PEAK_GBS, 5),
+        "definition": "BASELINE.md 3 verbatim: (32 N_d + 128 N_c + 32 N_e + 88) B per pixel-sample with the reference-defined look-up counts x samples/s of the whole step",
+        "frac_kernel_issued_fetches": round(achieved_kernel / HBM_PEAK_GBS, 5),
+        "achieved_kernel_issued_fetches": round(achieved_kernel, 3),
+        "frac_step_issued_fetches": round(b_step * samples_per_step / step_s / 1e9 / HBM_PEAK_GBS, 5),
         "hbm_measured_frac": None,
-        "bytes_per_sample": {"kernel_must_move": round(b_kernel, 2), "step_required": round(b_step, 2), "survey_8d_reference_counts": round(b_ref, 2)},
+        "bytes_per_sample": {"survey_8d_reference_counts": round(b_ref, 2), "lookup_bytes": round(b_lookup, 2), "record_stream_bytes": round(b_records, 2),
+                             "kernel_must_move": round(b_kernel, 2), "step_issued_fetches": round(b_step, 2)},
         "per_sample": {"density_fetches": round(fd, 4), "color_fetches": round(fc, 4), "emission_fetches": round(fe, 4),
                        "density_lookups_reference": round(nd, 4), "color_lookups_reference": round(nc, 4), "emission_lookups_reference": round(ne, 4),
                        "tracking_steps": round(cs.tracking_steps / n, 4), "skip_steps": round(cs.skip_steps / n, 4), "rays_traced_fraction": round(traced, 4)},
         "raygen_ms_per_step": round(st.raygen_ms, 3), "trace_ms_per_step": round(st.trace_ms, 3),
         "tail_resolve_ms_per_step": round(st.tail_ms, 3),
-        "note": "achieved = bytes the tracer must move per sample x samples per step / HIP-event time of its launches in the step",
+        # the tracer's own rate: rays it walks per second (the headline counts every pixel-sample, most of which start no walk on config 2)
+        "tracer_grays_per_s": round(traced * samples_per_step / trace_s / 1e9, 3) if trace_s > 0 else None,
+        "resolved_samples": bool(lean),
+        "note": "kernel times: HIP events on the context's stream around every launch of the LAST timed step",
     }
     # measured HBM traffic of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
     # command, corrected per MI355X_MICROARCH.md; tools/profile_bench.sh + tools/make_traffic_json.py write the file)
@@ -205,15 +215,16 @@ def main():
     cfg = args.config
     job_spp = args.spp or DEFAULT_SPP.get(cfg, 64)
     if args.scaling == "strong" and world > 1:
-        if job_spp % world:
-            raise SystemExit("--scaling strong needs spp (%d) divisible by the number of ranks (%d)" % (job_spp, world))
-        spp = job_spp // world
+        # the job's iterations striped over the ranks: rank r renders iterations r, r + G, ... (one more on the first spp % G ranks);
+        # the all-reduce weights every rank's mean with its own count
+        spp = len(range(rank, job_spp, world))
     else:
         spp = job_spp
 
     def measure(cfg, spp, steps, warmup, W, H, with_extras):
         """one workload: returns the dict of the JSON line (rank 0) or None"""
-        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or args.scaling == "weak" else spp * world, args.grid_scale, dev, local_rank)
+        job_iters = spp * world if (world == 1 or args.scaling == "weak") else job_spp       # iterations of the whole job per step
+        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or args.scaling == "weak" else job_spp, args.grid_scale, dev, local_rank)
         # scene set-up as a rank pays it at start (outside the timed region): texture uploads / adoption, the re-lay of big grids
         # into corner quads (config 4: 3.5 GB -> 14 GB on the GPU), the host octree and its candidate lists, buffer allocation
         torch.cuda.synchronize(dev)
@@ -243,7 +254,8 @@ def main():
                 hb.blue_noise.copy_(bn0)
             if bn_pre:
                 hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre, sd.width * sd.height)
-            hb.render(spp, iter_stride=stride, iteration=first_it)
+            if spp:                                         # (a rank beyond the job's iterations renders nothing and carries weight 0)
+                hb.render(spp, iter_stride=stride, iteration=first_it)
             if use_comm:
                 pkg.dist.combine_means(hb.accum, spp, ctx=hb.ctx)
             else:
@@ -271,7 +283,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         samples_per_step_rank = W * H * spp
-        value = samples_per_step_rank * world * steps / elapsed / 1e6
+        value = W * H * job_iters * steps / elapsed / 1e6
         out = None
         if rank == 0:
             # ---- look-up counts: an untimed 2-iteration counted pass
@@ -283,12 +295,28 @@ def main():
             cs = hb.ctx.stats()
             hb.ctx.set_counting(False)
             step_s = elapsed / steps
-            roofline = roofline_block(cfg, W, H, spp, cs, st, samples_per_step_rank, step_s, sd.kp.integrator)
+            import ctypes as C
+            lib = pkg.load_library()
+            cstate = (C.c_int * 8)()
+            lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            lib.vpt_test_get_cache_state(hb.ctx.h, cstate)
+            roofline = roofline_block(cfg, W, H, spp, cs, st, samples_per_step_rank, step_s, sd.kp.integrator, lean=bool(cstate[6]))
+            if not multi:
+                # what the per-view caches of the environment tail cost to build (once per view, in the warm-up): one step right after
+                # vpt_invalidate_sky_tables against the timed step
+                hb.blue_noise.copy_(bn0)
+                torch.cuda.synchronize(dev)
+                hb.ctx.invalidate_sky_tables()
+                tb = time.perf_counter()
+                hb.render(spp, iteration=0)
+                hb.sync()
+                roofline["cache_build_ms_per_view"] = round(max(0.0, (time.perf_counter() - tb) - step_s) * 1e3, 3)
+                roofline["caches_in_use"] = dict(zip(("sky_patch", "never_traced", "sky_dome", "dome_variants", "cam_table", "dir_table", "resolved_samples"), [int(x) for x in list(cstate)[:7]]))
             out = {
                 "metric": "Msamples/s (W*H*spp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
                 "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": data,
-                "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp,
+                "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp, "spp_job": job_iters,
                            "parallelism": "iteration-striped x%d + 1 RCCL all-reduce under the C ABI" % world if world > 1 else "1 GPU",
                            # what carried the reduce: the rank count read back from the context's RCCL communicator, or the
                            # host-staged torch.distributed fallback (VPT_BENCH_BACKEND=gloo: ranks sharing one GPU)

@@ -173,7 +173,8 @@ typedef struct vpt_kernel_params {
     float         exposure_scale;
     unsigned int *display_buffer;     /* W*H 0xffRRGGBB                                */
     vpt_float4   *raw_buffer;         /* W*H tonemapped rgb + alpha                    */
-    vpt_float3   *blue_noise_buffer;  /* 256*256, advanced in place every iteration    */
+    vpt_float3   *blue_noise_buffer;  /* 256*256, advanced in place every iteration; values in [0, 1] (the reference's: an 8-bit image / 255).
+                                       * A value outside is used CLAMPED to [0, 1] as the pixel jitter (its in-place advance is the reference's fmod). */
     vpt_float3   *emission_texture;   /* 256-entry blackbody LUT                       */
     float         emission_scale;
     float         emission_pivot;
@@ -388,7 +389,10 @@ int  vpt_atmosphere_precompute(vpt_ctx *ctx, vpt_atmosphere_parameters *atm, int
  * the table passes.  use_luminance 0 / 1: one pass, i.e. vpt_atmosphere_model followed by vpt_atmosphere_precompute.
  * use_luminance 2 (PRECOMPUTED): five passes over 15 wavelengths with per-pass model scalars, luminance-from-radiance matrices and
  * blending as the reference runs them (its argument-passing quirks included, csrc/vpt_atmosphere.hip), then the transmittance
- * table for opt->lambdas.  `atm` is an OUTPUT: scalars, the nine device buffers (allocated here) and the four texture handles. */
+ * table for opt->lambdas (the reference's init() has no wavelength input: its final pass uses kDefaultLambdas = 680 / 550 / 440 nm, the
+ * defaults of opt->lambdas; other wavelengths are this entry point's extension).  `atm`: the scalars are an OUTPUT; the nine device buffers
+ * and the four texture handles are IN/OUT -- ZERO the struct before the first call (NULL buffers are allocated), a later call with the same
+ * struct (another sun model, other options) refills the buffers and re-creates the handles it already holds. */
 int  vpt_atmosphere_precompute_model(vpt_ctx *ctx, const vpt_atmosphere_model_options *opt, const char *spectra_file,
                                      vpt_atmosphere_parameters *atm, int num_scattering_orders, void *stream);
 int  vpt_atmosphere_read_lut(vpt_ctx *ctx, const vpt_atmosphere_parameters *atm, int which, float *host_out, size_t n_floats);

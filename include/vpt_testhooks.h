@@ -29,6 +29,10 @@ int vpt_test_device_product_stream(vpt_ctx *ctx, unsigned int key, unsigned int 
  * executed the tracking step proper; [8..11] wave-level shader-clock cycles spent in refill, Philox
  * top-up, the walk step and the transition states (direct tracer only) */
 int vpt_test_get_schedule(vpt_ctx *ctx, unsigned long long out[12]);
+/* vol_integrator's runs of empty sample() calls in the last counted render (wave-level sums of lane-passes through the tracking step of
+ * its delta-tracking walks): [0] lane-passes that reached a density look-up, [1] lane-passes that ended in retry spins only, [2] retry
+ * draws in all, [3] lane-passes whose walk ended at t >= distance with no retry left */
+int vpt_test_get_retry_stats(vpt_ctx *ctx, unsigned long long out[4]);
 /* spatial coherence of the density look-ups of the last counted render of a single-volume scene (a 1-in-16 sample of
  * the wave-level gather events): [0] events, [1] lanes taking part, [2] distinct 8x8x8-voxel bricks among them,
  * [3] distinct 4x4x4 bricks, [4] 128-byte lines per lane summed over lanes, [5] distinct 128-byte lines per event */

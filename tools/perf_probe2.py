@@ -61,3 +61,10 @@ if o[0]:
     print("schedule: passes %d | per pass: walking %.1f, parked-in-T %.1f, idle %.1f lanes | trans passes %.3f/pass with %.1f lanes each (%.2f inner passes) | tracking-step lanes %.1f/pass"
           % (o[0], o[1] / o[0], o[2] / o[0], o[3] / o[0], o[4] / o[0], o[6] / max(1, o[5]), o[5] / max(1, o[4]), o[7] / o[0]))
     print("per traced ray: passes*64/rays = %.1f lane-passes, steps %.2f, skips %.2f" % (o[0] * 64 / max(1, st.queued_rays), st.tracking_steps / max(1, st.queued_rays), st.skip_steps / max(1, st.queued_rays)))
+rs = (C.c_ulonglong * 4)()
+pkg.load_library().vpt_test_get_retry_stats(hb.ctx.h, rs)
+rs = list(rs)
+if sum(rs):
+    tot = float(rs[0] + rs[1] + rs[3])
+    print("vol_integrator's delta-tracking walks, lane-passes through the step proper: %.1f%% reach a look-up, %.1f%% end in retry spins only, %.1f%% end the walk (t >= distance, no retry left); retry draws per lane-pass %.2f (%.2f per retry-only pass)"
+          % (100.0 * rs[0] / tot, 100.0 * rs[1] / tot, 100.0 * rs[3] / tot, rs[2] / tot, rs[2] / max(1.0, float(rs[1]))))

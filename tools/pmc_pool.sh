@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC comparison of the two direct tracers on one bench configuration (GPU box): tools/pmc_pool.sh c2 16
+# the pool tracer lives in a STUDY library: python volumetric-path-tracer_amd/build.py --variant pool --with-pool
+export VPT_LIB_PATH=${VPT_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/volumetric-path-tracer_amd/libvpt_hip_pool.so}
 CFG=${1:-c2}; SPP=${2:-16}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $REPO/gpurun_out

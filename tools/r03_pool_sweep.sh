@@ -1,5 +1,7 @@
 #!/bin/bash
 # pool tracer: schedule counters and a sweep of waves per CU / start threshold (GPU box)
+# the pool tracer lives in a STUDY library: python volumetric-path-tracer_amd/build.py --variant pool --with-pool
+export VPT_LIB_PATH=${VPT_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/volumetric-path-tracer_amd/libvpt_hip_pool.so}
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 mkdir -p gpurun_out
 OUT=gpurun_out/r03_pool_sweep.txt

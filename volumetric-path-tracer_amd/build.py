@@ -1,6 +1,6 @@
 """Build libvpt_hip.so (the C-ABI library of include/vpt_abi.h) for gfx950 with hipcc.
 
-    python volumetric-path-tracer_amd/build.py [--force] [--verbose] [-DNAME=VALUE ...]
+    python volumetric-path-tracer_amd/build.py [--force] [--verbose] [--variant NAME [--with-pool]] [-DNAME=VALUE ...]
 
 Flags that matter for parity (Arithmetic): the tracer, the host code and the
 resolve kernel are compiled STRICT: -ffp-contract=off (no FMA contraction on the decision
@@ -28,8 +28,8 @@ STRICT = ["-ffp-contract=off", "-fno-fast-math"]
 VALUE_ONLY = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 SOURCES = {
     "vpt_host.hip": STRICT,
+    "vpt_caches.hip": STRICT,
     "vpt_trace.hip": STRICT,
-    "vpt_trace_pool.hip": STRICT,
     "vpt_trace_vol.hip": STRICT,
     "vpt_resolve.hip": STRICT,
     "vpt_tail.hip": VALUE_ONLY,
@@ -47,10 +47,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=(), variant=None):
+# study sources that are NOT part of the product library (--with-pool: the round-3 pool tracer, selected at run time by VPT_TRACER=pool)
+POOL_SOURCE = os.path.join("variants", "vpt_trace_pool.hip")
+
+
+def build(force=False, verbose=False, extra_flags=(), variant=None, with_pool=False):
     """variant: build libvpt_hip_<variant>.so with `extra_flags` next to the default library (perf
     experiments: select it at run time with VPT_LIB_PATH)."""
     global OBJ, OUT
+    sources = dict(SOURCES)
+    if with_pool:
+        if not variant:
+            raise RuntimeError("--with-pool builds a study library: give it a --variant name")
+        sources[POOL_SOURCE] = STRICT
+        extra_flags = list(extra_flags) + ["-DVPT_WITH_POOL"]
     if variant:
         # objects of a study build live outside the tree (nothing to clean up, nothing extra for gpurun to push)
         OBJ = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vpt_obj_" + variant)
@@ -59,8 +69,8 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
     common_deps = list(HEADERS) + [os.path.abspath(__file__)]
     jobs = []
     objs = []
-    for src, flags in SOURCES.items():
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    for src, flags in sources.items():
+        obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
         if force or (extra_flags and not variant) or _stale(obj, [os.path.join(CSRC, src)] + common_deps):
             jobs.append([HIPCC] + COMMON + flags + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj])
@@ -119,5 +129,6 @@ if __name__ == "__main__":
         variant = argv[i + 1]
         del argv[i:i + 2]
     build(force="--force" in argv, verbose="--verbose" in argv,
-          extra_flags=[a for a in argv if a.startswith("-") and a not in ("--force", "--verbose")], variant=variant)
+          extra_flags=[a for a in argv if a.startswith("-") and a not in ("--force", "--verbose", "--with-pool")], variant=variant,
+          with_pool="--with-pool" in argv)
     print("built", OUT)

@@ -22,7 +22,7 @@
 // What moved out of LDS to make 832 rays fit in 160 KB: the density history of the fused first walk (HBM, written once
 // per look-up of that walk, read once), the primary ray (re-read from the ray record when depth_calculator's distance or
 // a replay needs it), the draw counter (derived from the Philox state).
-#include "vpt_trace_direct.h"
+#include "../vpt_trace_direct.h"
 
 namespace vpt {
 

@@ -688,6 +688,10 @@ static int precompute_textures(vpt_ctx* ctx, vpt_atmosphere_parameters* p) {
     vpt_texture_desc d2 = {TW, TH, 1, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_WRAP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
     vpt_texture_desc d3 = {SW, SH, SD, 4, 1, VPT_FILTER_LINEAR, {VPT_ADDR_CLAMP, VPT_ADDR_CLAMP, VPT_ADDR_CLAMP}};
     int rc;
+    // a repeated precompute over the same buffers: the old handles (adopted device memory: destroying them frees nothing) make way
+    vpt_texture_t* old[4] = {&p->transmittance_texture, &p->irradiance_texture, &p->scattering_texture, &p->single_mie_scattering_texture};
+    for (vpt_texture_t* h : old)
+        if (*h) { (void)vpt_texture_destroy(ctx, *h); *h = 0; }
     if ((rc = vpt_texture_create_device(ctx, &d2, (const float*)p->transmittance_buffer, &p->transmittance_texture))) return rc;
     d2.width = IW; d2.height = IH;
     if ((rc = vpt_texture_create_device(ctx, &d2, (const float*)p->irradiance_buffer, &p->irradiance_texture))) return rc;
@@ -724,6 +728,22 @@ int vpt_atmosphere_precompute_model(vpt_ctx* ctx, const vpt_atmosphere_model_opt
     vpt_atmosphere_parameters fin;
     int rc = vpt_atmosphere_model(opt, spectra_file, &fin);
     if (rc != VPT_OK) return rc;
+    // `atm` is IN/OUT for the nine device buffers and the four texture handles: a repeated call (another sun, other options) fills the
+    // tables it already holds instead of leaking them (the precompute passes allocate only what is NULL, precompute_textures re-creates
+    // handles over the same buffers) -- which is why a first call needs them zeroed.
+    fin.delta_irradience_buffer = atm->delta_irradience_buffer;
+    fin.delta_rayleigh_scattering_buffer = atm->delta_rayleigh_scattering_buffer;
+    fin.delta_mie_scattering_buffer = atm->delta_mie_scattering_buffer;
+    fin.delta_scattering_density_buffer = atm->delta_scattering_density_buffer;
+    fin.delta_multiple_scattering_buffer = atm->delta_multiple_scattering_buffer;
+    fin.transmittance_buffer = atm->transmittance_buffer;
+    fin.irradiance_buffer = atm->irradiance_buffer;
+    fin.scattering_buffer = atm->scattering_buffer;
+    fin.optional_mie_single_scattering_buffer = atm->optional_mie_single_scattering_buffer;
+    fin.transmittance_texture = atm->transmittance_texture;
+    fin.scattering_texture = atm->scattering_texture;
+    fin.irradiance_texture = atm->irradiance_texture;
+    fin.single_mie_scattering_texture = atm->single_mie_scattering_texture;
     if (opt->use_luminance != 2) {
         *atm = fin;
         return vpt_atmosphere_precompute(ctx, atm, num_scattering_orders, stream_v);

@@ -122,6 +122,10 @@ struct Counters {
     // [0] density, [1] colour (float4 texels), [2] emission -- what the tracer really moves, as opposed to the
     // reference-defined look-up counts above (one per instance of the leaf and step, fetched or not)
     unsigned long long fetches[4];
+    // vol_integrator's runs of empty sample() calls (vpt_walk.h: use_retries; counting builds only; wave-level sums of LANE-passes through
+    // the tracking step proper): [0] lane-passes that reached a density look-up, [1] lane-passes that ended in retry spins only (the
+    // Philox words buffered for the pass ran out, or VPT_RETRY_SPINS), [2] retry draws in all, [3] lane-passes whose walk ended at t >= distance
+    unsigned long long retry[4];
 };
 
 #ifndef VPT_CHUNK
@@ -284,7 +288,8 @@ struct ResolveParams {
     // NEVER-TRACED pixels (written by sky_patch_kernel next to the patches): a pixel whose whole jitter footprint lies outside the
     // screen-space bounds of the volumes' root box (cull_rect, in pixels, already grown by the margin), whose rays all pass the
     // reference sphere at more than its radius INFLATED by what the binary32 discriminant of sphere::intersect can lose
-    // (B^2 - 4AC cancels to ~36 eps D^2 at distance D: false hits out to sqrt(r^2 + 9 eps D^2), several pixels at 1080p), away from
+    // (B^2 - 4AC carries up to ~60 eps D^2 of error at distance D: false hits out to sqrt(r^2 + 15 eps D^2), several pixels at 1080p --
+    // vpt_cull.h inflates the radius to r^2 + 64 eps D^2), away from
     // the line on which that function's `B == 0` case reports a hit at distance 0 whatever the sphere's place (geometry.h:118-121:
     // cull_line, a x + b y + c in pixels), and that has a patch: raygen skips it altogether (no ray, no head), the tail takes every
     // sample's value from the patch.  cull_enabled = 0: a box corner at or behind the camera plane, the origin on a slab plane, ...

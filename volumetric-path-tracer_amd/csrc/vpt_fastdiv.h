@@ -12,7 +12,12 @@
 #include <cstring>
 namespace vpt {
 // r: the reciprocal the device will multiply by (RN(1 / d) in the product; a parameter so that tests can break it)
-__attribute__((target("fma"))) inline bool fast_div_check_fma(float d, float r) {
+#if defined(__x86_64__)
+#define VPT_FASTDIV_TARGET __attribute__((target("fma")))
+#else
+#define VPT_FASTDIV_TARGET
+#endif
+VPT_FASTDIV_TARGET inline bool fast_div_check_fma(float d, float r) {
     uint32_t bad = 0;
     for (uint32_t m = 0; m < (1u << 23); ++m) {
         const uint32_t bits = 0x3f800000u | m;                // q in [1, 2)
@@ -20,7 +25,7 @@ __attribute__((target("fma"))) inline bool fast_div_check_fma(float d, float r) 
         std::memcpy(&q, &bits, 4);
         const float ref = q / d;
         float y = q * r;
-        const float e = __builtin_fmaf(-d, y, q);
+        const float e = __builtin_fmaf(-d, y, q);             // (x86: one vfmadd; elsewhere the target's fma or libm's correctly rounded fmaf)
         y = __builtin_fmaf(e, r, y);
         bad |= (ref != y) ? 1u : 0u;
     }
@@ -29,7 +34,9 @@ __attribute__((target("fma"))) inline bool fast_div_check_fma(float d, float r) 
 // d: a grid extent (integer-valued, 1 <= d <= 2^16: with |q| in [2^-40, 2^40] no intermediate of the sequence is subnormal)
 inline bool fast_div_ok(float d, float r) {
     if (!(d >= 1.0f && d <= 65536.0f)) return false;
-    if (!__builtin_cpu_supports("fma")) return false;         // no exact residual to check with: keep the division
+#if defined(__x86_64__)
+    if (!__builtin_cpu_supports("fma")) return false;         // no hardware FMA to check with in reasonable time: keep the division
+#endif
     return fast_div_check_fma(d, r);
 }
 }  // namespace vpt

@@ -19,32 +19,9 @@
 #include <string>
 #include <vector>
 
-#include "../../include/vpt_abi.h"
-#include "../../include/vpt_testhooks.h"
-#include "vpt_device.h"
+#include "vpt_ctx.h"
 #include "vpt_cull.h"
 #include "vpt_fastdiv.h"
-
-namespace vpt {
-hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
-hipError_t launch_trace_pool(const TraceParams& P, bool multi, bool color, bool emit, int blocks, int threads, hipStream_t stream);
-size_t trace_pool_hist_floats_per_block();
-bool trace_pool_supports(const TraceParams& P);
-hipError_t launch_trace_vol(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
-hipError_t launch_raygen(const TraceParams& P, hipStream_t stream);
-hipError_t launch_tail_resolve(const ResolveParams& R, hipStream_t stream);
-hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream);
-hipError_t launch_sky_cam_table(const ResolveParams& R, SkyView* view, float4* out, int k, hipStream_t stream);
-size_t sky_cam_table_bytes();
-size_t sky_dir_table_bytes();
-hipError_t launch_sky_dir_table(const ResolveParams& R, SkyView* view, float4* tab, unsigned long long* err, int k, hipStream_t stream);
-hipError_t launch_sky_samples(const ResolveParams& R, const float* origins, const float* dirs, float* out, uint32_t n, int use_table, hipStream_t stream);
-hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* never, uint32_t* nopatch_list, uint32_t* nopatch_count, hipStream_t stream);
-hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* out, int k, hipStream_t stream);
-size_t sky_dome_bytes(int k);
-hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
-hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
-}  // namespace vpt
 
 using namespace vpt;
 
@@ -53,128 +30,9 @@ namespace {
 std::mutex g_err_mutex;
 std::string g_last_error;
 
-struct TexEntry {
-    DTexture t;
-    void* owned;     // device allocation owned by the ctx (NULL when adopted)
-    bool live;
-};
-
-struct Box { f3 lo, hi; };
-
 }  // namespace
 
-struct vpt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int num_cus = 0;
-    int blocks_per_cu = 3;
-    uint32_t regen_min = 8;        // direct_integrator tracer: refill once >= 8 lanes are idle
-    uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
-    uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
-    uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
-    // pool tracer (vpt_trace_pool.hip): direct_integrator with the rays in an LDS pool per CU
-    bool use_pool = false;         // VPT_TRACER=pool: measured slower than the lane-bound tracer, kept as the evidence and for A/B runs
-    int pool_waves = 12;           // VPT_POOL_WAVES: waves of the one workgroup per CU (8..12)
-    uint32_t pool_min_lanes = 40;  // VPT_POOL_MIN_LANES: fewest lanes a pass starts with while other waves still hold rays
-    float* d_pool_hist = nullptr;
-    std::string last_error;
-    std::vector<TexEntry> textures;
-    // scene
-    std::vector<vpt_gpu_vdb> host_volumes;
-    std::vector<DVolume> host_dvolumes;
-    DVolume* d_volumes = nullptr;
-    float4* d_insts = nullptr;        // compact per-instance matrices (TraceParams::insts)
-    bool single_file = false;
-    std::vector<void*> bricked;       // re-tiled copies of large density grids (owned)
-    float4* d_cam_tab = nullptr;      // camera-point scattering tables, (2 k + 1) x 8 x 128 x 2 float4 (vpt_sky.h)
-    SkyView* d_sky_view = nullptr;    // their view point and variants
-    float4* d_dir_tab = nullptr;      // view-point ground table (vpt_sky.h, GroundNode) ...
-    unsigned long long* d_dir_err = nullptr;    // ... and its measured interpolation error (high word: float bits, low word: the cell)
-    bool dir_tab_built = false;       // for the view point / sun / model of cam_tab_key
-    ResolveParams last_resolve;       // environment side of the last render (vpt_test_sky_samples)
-    bool have_last_resolve = false;
-    uint32_t* d_leaf_offsets = nullptr;
-    uint32_t* d_leaf_indices = nullptr;
-    uint32_t* d_sub_offsets = nullptr;     // single-file scenes: candidate lists per sub-cell of every leaf (512 * VPT_SUB3 + 1)
-    float sub_inv[3] = {0.0f, 0.0f, 0.0f}; // VPT_SUB / leaf extent per axis
-    uint32_t occ[19] = {0};
-    Box root = {{0, 0, 0}, {0, 0, 0}};
-    float max_ext = 0.0f, min_ext = 0.0f;
-    int nonempty[3] = {0, 0, 0};
-    bool scene_ready = false;
-    bool any_color = false, any_emission = false;
-    // scratch
-    Record* d_records = nullptr;
-    float4* d_heads = nullptr;             // 16-byte sample heads, same capacity as d_records
-    float2* d_td = nullptr;                // {alpha, depth} of the resolved samples (TraceParams::td), same capacity, allocated on first use
-    size_t td_capacity = 0;
-    uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td
-    uint32_t* d_nopatch = nullptr;         // [0]: count, [1..]: pixels without a usable sky patch (ResolveParams::nopatch_list), with d_sky_patch
-    ResolveInTracer* d_resolve = nullptr;  // TraceParams::resolve
-    ResolveInTracer resolve_host = {};     // what d_resolve holds
-    bool no_lean_tail = false;             // VPT_NO_LEAN_TAIL: finished paths keep their 64-byte records and the tail adds the environment (A/B, tests)
-    float4* d_head_org = nullptr;          // ray origins of the heads (thin lens: lens_radius != 0), allocated on first use
-    size_t head_org_capacity = 0;
-    size_t records_capacity = 0;           // in records
-    float2* d_bn_table = nullptr;
-    size_t bn_capacity = 0;                // in iterations
-    uint32_t* d_work_counter = nullptr;     // [0] the tracer's dequeue cursor, [8] raygen's queue tail (own cache line apart)
-    uint32_t* d_queue = nullptr;
-    float* d_vdc = nullptr;
-    Counters* d_counters = nullptr;
-    DPointLight* d_lights = nullptr;
-    size_t lights_capacity = 0;
-    std::vector<DPointLight> lights_cache;
-    // multi-GPU: one RCCL communicator per context (vpt_comm_init_rank); librccl.so is loaded on first use, so a
-    // single-GPU host never maps it
-    ncclComm_t comm = nullptr;
-    int comm_nranks = 0, comm_rank = 0;
-    float* d_comm_buf = nullptr;           // the collective's payload: this rank's weighted image + its iteration count in the last float
-    size_t comm_buf_floats = 0;
-    // tuning / test switches, read from the environment ONCE, when the context is created (vpt_create)
-    size_t relaid_min_bytes = (size_t)8 << 20;    // VPT_RELAID_MIN_BYTES: density / emission grids below this stay dense (they live in L2)
-    int grid_layout = -1;                  // VPT_GRID_LAYOUT (tests): force "dense" / "bricks" / "quads" for grids >= relaid_min_bytes; -1: quads, bricks if those do not fit
-    bool force_no_addr24 = false;          // VPT_NO_ADDR24: tests force the 32-bit texel index arithmetic
-    unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
-    bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
-    bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
-    bool no_fast_div = false;              // VPT_NO_FAST_DIV: every look-up divides by the grid extent (tests: both forms give the same bits)
-    bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
-    float dir_tab_tol = 5e-4f;             // VPT_DIR_TABLE_TOL: largest relative mid-cell error the ground table may show
-    // camera-point scattering table: rebuilt only when its inputs change (per-frame calls reuse it)
-    float cam_tab_key[47] = {0};
-    const void* cam_tab_tex[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool cam_tab_built = false;
-    // per-pixel sky patches of the untraced samples (ResolveParams::sky_patch): rebuilt when the sky tables or the camera frame change
-    float4* d_sky_dome = nullptr;              // sky dome(s) (ResolveParams::sky_dome), rebuilt with the patches (closed lens) / the tables (open lens)
-    int sky_dome_k = -1;                       // variants the allocation holds: 2 k + 1
-    bool lens_dome_built = false;              // open lens: domes valid for the current camera-point tables
-    float lens_dome_key[4] = {0};              // sky_mult, sky_color
-    bool no_sky_dome = false;                  // VPT_NO_SKY_DOME (tests)
-    float4* d_sky_patch = nullptr;
-    unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
-    size_t sky_patch_pixels = 0;           // capacity, in pixels
-    float sky_patch_key[40] = {0};         // camera frame, image size, sky_mult, sky_color, the cull bounds
-    float sky_patch_seen[40] = {0};        // the same of the previous render call, built or not
-    bool sky_patch_seen_valid = false;
-    bool sky_patch_built = false;
-    bool no_sky_patch = false;             // VPT_NO_SKY_PATCH: every untraced sample evaluated in full (tests)
-    bool no_pixel_cull = false;            // VPT_NO_PIXEL_CULL: raygen emits every pixel's samples (tests)
-    hipEvent_t tab_event = nullptr;        // recorded behind the table kernels; a render on ANOTHER stream waits for it
-    hipStream_t tab_stream = nullptr;      // the stream the tables were built on
-    bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
-    // stats
-    bool counting = false;
-    std::vector<hipEvent_t> ev_pool;
-    struct Span { int e0, e1; int kind; };
-    std::vector<Span> spans;
-    int ev_used = 0;
-    unsigned long long last_samples = 0;
-};
-
-namespace {
-
-void set_error(vpt_ctx* ctx, const char* fmt, ...) {
+void vpt_set_error(vpt_ctx* ctx, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -185,14 +43,7 @@ void set_error(vpt_ctx* ctx, const char* fmt, ...) {
     g_last_error = buf;
 }
 
-#define HIPCHK(ctx, expr)                                                                        \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            set_error(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return VPT_E_HIP;                                                                    \
-        }                                                                                        \
-    } while (0)
+namespace {
 
 inline f3 v3(vpt_float3 v) { return mk3(v.x, v.y, v.z); }
 inline vpt_float3 tov(f3 v) { vpt_float3 r = {v.x, v.y, v.z}; return r; }
@@ -348,7 +199,9 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (rgm && std::atoi(rgm) > 0 && std::atoi(rgm) <= 64) ctx->regen_min = ctx->regen_min_vol = (uint32_t)std::atoi(rgm);
     const char* trm = std::getenv("VPT_TRANS_MIN");
     if (trm && std::atoi(trm) > 0 && std::atoi(trm) <= 64) ctx->trans_min = ctx->trans_min_vol = (uint32_t)std::atoi(trm);
+#ifdef VPT_WITH_POOL
     if (const char* e = std::getenv("VPT_TRACER")) ctx->use_pool = std::strcmp(e, "pool") == 0;
+#endif
     if (const char* e = std::getenv("VPT_POOL_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 12) ctx->pool_waves = v; }
     if (const char* e = std::getenv("VPT_POOL_MIN_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->pool_min_lanes = (uint32_t)v; }
     if (const char* e = std::getenv("VPT_RELAID_MIN_BYTES")) ctx->relaid_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
@@ -416,25 +269,12 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_lights);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->tab_event) (void)hipEventDestroy(ctx->tab_event);
+    if (ctx->render_event) (void)hipEventDestroy(ctx->render_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-
-// The per-frame sky tables (camera-point scattering table, view-point ground table) are cached on the view point, the sun, the
-// model scalars and the ADDRESSES of the four look-up tables -- not on the tables' contents.  Whatever can change those
-// contents behind an unchanged address drops the cache: every texture create / destroy (a re-upload of the same size
-// usually lands on the address just freed), vpt_atmosphere_precompute (it refills the buffers it is handed), and this
-// entry point for a host that rewrites a device table in place.
-int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
-    if (!ctx) return VPT_E_INVALID;
-    ctx->cam_tab_built = false;
-    ctx->dir_tab_built = false;
-    ctx->sky_patch_built = false;
-    return VPT_OK;
-}
 
 int vpt_sync(vpt_ctx* ctx) {
     if (!ctx) return VPT_E_INVALID;
@@ -537,6 +377,7 @@ static bool divisor_checked(float d, float r) {
     for (const auto& s : seen)
         if (s.first == d) return s.second;
     const bool ok = vpt::fast_div_ok(d, r);
+    if (seen.size() >= 256u) seen.erase(seen.begin());       // (a host that keeps changing its image or grid extents: the oldest verdict goes)
     seen.emplace_back(d, ok);
     return ok;
 }
@@ -544,7 +385,7 @@ static bool divisor_checked(float d, float r) {
 // Screen-space bounds, in pixels, of the world box [lo, hi] as camera::get_ray (camera.h:131-136, closed lens) sees it: a world point
 // X is hit by the ray of image-plane coordinates (u, v) with X - o = s (llc - o + u h + v vert), s > 0.  false: a corner at or
 // behind the camera plane (no bound can be given).
-static bool project_box(const vpt_camera* cam, const double lo[3], const double hi[3], double W, double H, double rect[4]) {
+bool vpt_project_box(const vpt_camera* cam, const double lo[3], const double hi[3], double W, double H, double rect[4]) {
     const double o[3] = {cam->origin.x, cam->origin.y, cam->origin.z};
     const double A[3] = {cam->lower_left_corner.x - o[0], cam->lower_left_corner.y - o[1], cam->lower_left_corner.z - o[2]};
     const double hv[3] = {cam->horizontal.x, cam->horizontal.y, cam->horizontal.z}, vv[3] = {cam->vertical.x, cam->vertical.y, cam->vertical.z};
@@ -882,6 +723,15 @@ int vpt_test_get_schedule(vpt_ctx* ctx, unsigned long long out[12]) {
     return VPT_OK;
 }
 
+int vpt_test_get_retry_stats(vpt_ctx* ctx, unsigned long long out[4]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    Counters c;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    std::memcpy(out, c.retry, sizeof(c.retry));
+    return VPT_OK;
+}
+
 int vpt_test_get_coherence(vpt_ctx* ctx, unsigned long long out[8]) {
     if (!ctx || !out) return VPT_E_INVALID;
     Counters c;
@@ -912,7 +762,7 @@ int vpt_test_project_box(const vpt_camera* cam, const float lo[3], const float h
     if (!cam || !lo || !hi || !rect || width <= 0 || height <= 0) return VPT_E_INVALID;
     const double l[3] = {lo[0], lo[1], lo[2]}, h[3] = {hi[0], hi[1], hi[2]};
     double r[4];
-    if (!project_box(cam, l, h, (double)width, (double)height, r)) return VPT_E_UNSUPPORTED;       // a corner at or behind the camera plane
+    if (!vpt_project_box(cam, l, h, (double)width, (double)height, r)) return VPT_E_UNSUPPORTED;       // a corner at or behind the camera plane
     for (int i = 0; i < 4; ++i) rect[i] = (float)r[i];
     return VPT_OK;
 }
@@ -937,21 +787,6 @@ int vpt_test_get_sky_patch_coverage(vpt_ctx* ctx, unsigned long long* pixels, un
     for (size_t i = 0; i < n; ++i) ok += first[i] == first[i] ? 1ull : 0ull;
     *pixels = n;
     *with_patch = ok;
-    return VPT_OK;
-}
-
-int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
-    if (!ctx || !out) return VPT_E_INVALID;
-    for (int i = 0; i < 8; ++i) out[i] = 0;
-    if (!ctx->have_last_resolve) return VPT_OK;
-    const ResolveParams& R = ctx->last_resolve;
-    out[0] = R.sky_patch != nullptr;
-    out[1] = R.never_traced != nullptr;
-    out[2] = R.sky_dome != nullptr;
-    out[3] = R.sky_dome != nullptr ? 2 * ctx->sky_dome_k + 1 : 0;
-    out[4] = R.cam_tab_valid;
-    out[5] = R.dir_tab != nullptr;
-    out[6] = R.lean;
     return VPT_OK;
 }
 
@@ -1211,6 +1046,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const uint32_t n_pixels = W * H;
+    // one context's renders share its scratch buffers and per-view caches: a render on another stream than the previous one starts
+    // (on the device) behind that one's last kernel
+    if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
 
     // ---- resolve-side parameters
     ResolveParams R;
@@ -1345,6 +1183,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (changed) {
             if (ctx->lights_capacity < n) {
                 HIPCHK(ctx, hipStreamSynchronize(stream));
+                if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
                 (void)hipFree(ctx->d_lights);
                 HIPCHK(ctx, hipMalloc(&ctx->d_lights, n * sizeof(DPointLight)));
                 ctx->lights_capacity = n;
@@ -1366,6 +1205,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (ctx->batch_iters > 0) chunk = std::min<size_t>(std::min<size_t>((size_t)ctx->batch_iters, iter_count), 64);     // (ResolveParams::rcp_n, split_slot: <= 64 per launch)
     if (ctx->records_capacity < chunk * per_iter) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
+        if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
         (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
@@ -1382,6 +1222,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     }
     if (ctx->bn_capacity < chunk) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
+        if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
         (void)hipFree(ctx->d_bn_table); ctx->d_bn_table = nullptr;
         HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, chunk * 65536 * sizeof(float2)));
         ctx->bn_capacity = chunk;
@@ -1396,6 +1237,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (compact && cam->lens_radius != 0.0f) {
         if (ctx->head_org_capacity < ctx->records_capacity) {
             HIPCHK(ctx, hipStreamSynchronize(stream));
+            if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
             (void)hipFree(ctx->d_head_org); ctx->d_head_org = nullptr; ctx->head_org_capacity = 0;
             HIPCHK(ctx, hipMalloc(&ctx->d_head_org, ctx->records_capacity * sizeof(float4)));
             ctx->head_org_capacity = ctx->records_capacity;
@@ -1411,209 +1253,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.blue_noise = ctx->d_bn_table;
     R.records = ctx->d_records;
 
-    // per-frame sky tables (vpt_sky.h): valid for samples whose env_pos has the camera origin's (r, mu_s) -- or, behind an open
-    // lens, an r within k binary32 steps of it (the lens disc spans lens_radius of height: k = that in steps of r, + 1)
-    if (R.has_atmosphere && !ctx->no_cam_table) {
-        if (!ctx->d_cam_tab) {
-            HIPCHK(ctx, hipMalloc(&ctx->d_cam_tab, sky_cam_table_bytes()));
-            HIPCHK(ctx, hipMalloc(&ctx->d_sky_view, sizeof(SkyView)));
-        }
-        R.cam_tab = ctx->d_cam_tab;
-        R.sky_view = ctx->d_sky_view;
-        R.cam_tab_pos[0] = cam->origin.x; R.cam_tab_pos[1] = cam->origin.y; R.cam_tab_pos[2] = cam->origin.z;
-        int view_k = 0;
-        if (cam->lens_radius != 0.0f) {
-            const double py = (double)cam->origin.y + (double)R.atm_f[0], r = std::sqrt((double)cam->origin.x * cam->origin.x + py * py + (double)cam->origin.z * cam->origin.z);
-            const double step = std::ldexp(1.0, std::ilogb(r) - 23);                  // binary32 spacing at r
-            view_k = (int)std::min<double>((double)SKY_VIEW_MAX_K, std::ceil(std::fabs((double)cam->lens_radius) / step) + 1.0);
-        }
-        // the tables are a function of the view point, the lens (variants), the sun direction, the model scalars and the two 4-D
-        // tables: a frame loop that changes none of them (main.cpp:1822-1829, one launch per iteration) builds them once
-        float key[47];
-        std::memcpy(key, R.cam_tab_pos, sizeof(float) * 3);
-        std::memcpy(key + 3, R.sun_dir, sizeof(float) * 3);
-        std::memcpy(key + 6, R.atm_f, sizeof(float) * 40);
-        key[46] = (float)view_k;
-        const void* tex[4] = {R.transmittance_tex.data, R.scattering_tex.data, R.irradiance_tex.data, R.single_mie_tex.data};
-        bool tables_written = false;
-        if (!ctx->cam_tab_built || std::memcmp(key, ctx->cam_tab_key, sizeof(key)) != 0 || std::memcmp(tex, ctx->cam_tab_tex, sizeof(tex)) != 0) {
-            // a rebuild overwrites tables a render on the previous stream may still be reading
-            if (ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-            tables_written = true;
-            HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_sky_view, ctx->d_cam_tab, view_k, stream));
-            std::memcpy(ctx->cam_tab_key, key, sizeof(key));
-            std::memcpy(ctx->cam_tab_tex, tex, sizeof(tex));
-            ctx->cam_tab_built = true;
-            ctx->dir_tab_built = false;
-            ctx->sky_patch_built = false;
-        }
-        R.cam_tab_valid = 1;
-        // view-point ground tables (vpt_sky.h): the direct integrator's procedural sky; which variants get one (view point between
-        // the ground and the top of the atmosphere) is sky_view_kernel's decision
-        if (!ctx->no_dir_table && kp->integrator == 0 && kp->environment_type == 0) {
-            if (!ctx->d_dir_tab) {
-                HIPCHK(ctx, hipMalloc(&ctx->d_dir_tab, sky_dir_table_bytes()));
-                HIPCHK(ctx, hipMalloc(&ctx->d_dir_err, SKY_DIR_ERR_WORDS * sizeof(unsigned long long)));
-            }
-            R.dir_tab_tol = ctx->dir_tab_tol;
-            R.dir_tab = ctx->d_dir_tab;                  // (before the build: its check evaluates real rays through the table path)
-            R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
-            if (!ctx->dir_tab_built) {
-                if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-                tables_written = true;
-                HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_sky_view, ctx->d_dir_tab, ctx->d_dir_err, view_k, stream));
-                ctx->dir_tab_built = true;
-            }
-            R.dir_tab = ctx->d_dir_tab;
-            R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
-        }
-        // per-pixel sky patches (ResolveParams::sky_patch): untraced samples behind a closed lens, direct integrator, procedural sky, heads
-        if (!ctx->no_sky_patch && compact && cam->lens_radius == 0.0f && kp->integrator == 0 && kp->environment_type == 0) {
-            float pk[40] = {cam->lower_left_corner.x, cam->lower_left_corner.y, cam->lower_left_corner.z, cam->horizontal.x, cam->horizontal.y, cam->horizontal.z,
-                            cam->vertical.x, cam->vertical.y, cam->vertical.z, (float)W, (float)H, kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z,
-                            (ctx->no_dir_table ? 0.0f : 1.0f) + ctx->dir_tab_tol};
-            for (int i = 0; i < 3; ++i) { R.cam_llc[i] = pk[i]; R.cam_h[i] = pk[3 + i]; R.cam_v[i] = pk[6 + i]; }
-            // never-traced pixels: screen-space bounds of the root box grown by 3 pixels (the rounding of a slab test moves a hit by ~eps / pixel
-            // angle: a tenth of a pixel at most), the sphere by its inflated radius per pixel (sky_patch_kernel), and the line
-            // dir . (origin - centre) = 0 of sphere::intersect's B == 0 case.  No culling when a box corner is at or behind the camera plane,
-            // or the origin sits exactly on a slab plane (0 x inf in the slab test).
-            R.render = kp->render ? 1 : 0;
-            R.cull_enabled = 0;
-            if (!ctx->no_pixel_cull) {
-                const double blo[3] = {P.root_pmin[0], P.root_pmin[1], P.root_pmin[2]}, bhi[3] = {P.root_pmax[0], P.root_pmax[1], P.root_pmax[2]};
-                double rb[4];
-                const double o[3] = {cam->origin.x, cam->origin.y, cam->origin.z};
-                bool on_plane = false;
-                for (int i = 0; i < 3; ++i) on_plane = on_plane || o[i] == blo[i] || o[i] == bhi[i];
-                if (!on_plane && project_box(cam, blo, bhi, (double)W, (double)H, rb)) {
-                    const double m = 3.0;
-                    for (int i = 0; i < 2; ++i) { R.cull_rect[i] = (float)(rb[i] - m); R.cull_rect[2 + i] = (float)(rb[2 + i] + m); }
-                    const double orig[3] = {o[0] - ref_sphere->center.x, o[1] - ref_sphere->center.y, o[2] - ref_sphere->center.z};
-                    const double A[3] = {cam->lower_left_corner.x - o[0], cam->lower_left_corner.y - o[1], cam->lower_left_corner.z - o[2]};
-                    R.cull_line[0] = (float)((cam->horizontal.x * orig[0] + cam->horizontal.y * orig[1] + cam->horizontal.z * orig[2]) / (double)W);
-                    R.cull_line[1] = (float)((cam->vertical.x * orig[0] + cam->vertical.y * orig[1] + cam->vertical.z * orig[2]) / (double)H);
-                    R.cull_line[2] = (float)(A[0] * orig[0] + A[1] * orig[1] + A[2] * orig[2]);
-                    R.cull_sph[0] = ref_sphere->center.x; R.cull_sph[1] = ref_sphere->center.y; R.cull_sph[2] = ref_sphere->center.z;
-                    R.cull_sph[3] = ref_sphere->radius;
-                    // worth its flag look-ups only when a good part of the frame lies outside the box's rectangle (config 3's fireball fills the
-                    // picture: raygen 4 % slower with the flags than without)
-                    const double ix0 = std::max(0.0, (double)R.cull_rect[0]), iy0 = std::max(0.0, (double)R.cull_rect[1]);
-                    const double ix1 = std::min((double)W, (double)R.cull_rect[2]), iy1 = std::min((double)H, (double)R.cull_rect[3]);
-                    const double inside = std::max(0.0, ix1 - ix0) * std::max(0.0, iy1 - iy0);
-                    R.cull_enabled = inside <= 0.7 * (double)W * (double)H ? 1 : 0;
-                }
-            }
-            pk[16] = (float)R.cull_enabled; pk[17] = (float)R.render;
-            std::memcpy(pk + 18, R.cull_rect, sizeof(float) * 4);
-            std::memcpy(pk + 22, R.cull_line, sizeof(float) * 3);
-            std::memcpy(pk + 25, R.cull_sph, sizeof(float) * 4);
-            if (ctx->sky_patch_pixels < (size_t)n_pixels) {
-                if (ctx->tab_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-                HIPCHK(ctx, hipStreamSynchronize(stream));
-                (void)hipFree(ctx->d_sky_patch); ctx->d_sky_patch = nullptr; ctx->sky_patch_pixels = 0;
-                (void)hipFree(ctx->d_never_traced); ctx->d_never_traced = nullptr;
-                HIPCHK(ctx, hipMalloc(&ctx->d_sky_patch, (size_t)n_pixels * 3u * sizeof(float4)));
-                HIPCHK(ctx, hipMalloc(&ctx->d_never_traced, (size_t)n_pixels));
-                (void)hipFree(ctx->d_nopatch); ctx->d_nopatch = nullptr;
-                HIPCHK(ctx, hipMalloc(&ctx->d_nopatch, ((size_t)n_pixels + 1u) * sizeof(uint32_t)));
-                ctx->sky_patch_pixels = n_pixels;
-                ctx->sky_patch_built = false;
-            }
-            // The patches, the mask and the dome cost ~0.3 ms to build: they are built for a batch (>= 2 iterations), or once a view repeats (the
-            // progressive render of a still camera, main.cpp:1822-1829 frame after frame) -- a camera that moves every frame with one iteration
-            // per frame never pays for them.
-            const bool built_for_this = ctx->sky_patch_built && std::memcmp(pk, ctx->sky_patch_key, sizeof(pk)) == 0;
-            const bool view_repeats = ctx->sky_patch_seen_valid && std::memcmp(pk, ctx->sky_patch_seen, sizeof(pk)) == 0;
-            std::memcpy(ctx->sky_patch_seen, pk, sizeof(pk));
-            ctx->sky_patch_seen_valid = true;
-            const bool use_caches = built_for_this || iter_count >= 2u || view_repeats;
-            if (use_caches && !built_for_this) {
-                if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-                tables_written = true;
-                HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, ctx->d_nopatch + 1, ctx->d_nopatch, stream));
-                if (!ctx->no_sky_dome) {
-                    if (ctx->sky_dome_k < 0) {
-                        HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sky_dome_bytes(0)));
-                        ctx->sky_dome_k = 0;
-                    }
-                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_view, ctx->d_sky_dome, 0, stream));
-                    ctx->lens_dome_built = false;
-                }
-                std::memcpy(ctx->sky_patch_key, pk, sizeof(pk));
-                ctx->sky_patch_built = true;
-            }
-            if (use_caches) {
-                R.sky_patch = ctx->d_sky_patch;
-                R.sky_dome = ctx->no_sky_dome ? nullptr : ctx->d_sky_dome;
-                R.blue_noise = ctx->d_bn_table;
-                if (R.cull_enabled) {
-                    R.never_traced = ctx->d_never_traced;
-                    P.never_traced = ctx->d_never_traced;
-                }
-                // RESOLVED SAMPLES (vpt_device.h): patches + dome in use => the tracer resolves its finished paths from the dome and the tail
-                // streams heads only.  (The pool tracer, an A/B harness, keeps the records.)
-                if (R.sky_dome != nullptr && !ctx->no_lean_tail && !ctx->use_pool) {
-                    if (ctx->td_capacity < ctx->records_capacity) {
-                        HIPCHK(ctx, hipStreamSynchronize(stream));
-                        (void)hipFree(ctx->d_td); ctx->d_td = nullptr; ctx->td_capacity = 0;
-                        (void)hipFree(ctx->d_queue2); ctx->d_queue2 = nullptr;
-                        HIPCHK(ctx, hipMalloc(&ctx->d_td, ctx->records_capacity * sizeof(float2)));
-                        HIPCHK(ctx, hipMalloc(&ctx->d_queue2, ctx->records_capacity * sizeof(uint32_t)));
-                        ctx->td_capacity = ctx->records_capacity;
-                    }
-                    R.lean = 1;
-                    R.td = ctx->d_td;
-                    R.queue2 = ctx->d_queue2;
-                    R.queue2_count = ctx->d_work_counter + 4;
-                    R.nopatch_list = ctx->d_nopatch + 1;
-                    R.nopatch_count = ctx->d_nopatch;
-                    ResolveInTracer rt;
-                    std::memset(&rt, 0, sizeof(rt));
-                    rt.sky_dome = R.sky_dome; rt.heads = ctx->d_heads; rt.td = ctx->d_td; rt.queue2 = ctx->d_queue2; rt.queue2_tail = ctx->d_work_counter + 4;
-                    rt.cam_origin[0] = cam->origin.x; rt.cam_origin[1] = cam->origin.y; rt.cam_origin[2] = cam->origin.z;
-                    if (!ctx->d_resolve) HIPCHK(ctx, hipMalloc(&ctx->d_resolve, sizeof(ResolveInTracer)));
-                    if (std::memcmp(&rt, &ctx->resolve_host, sizeof(rt)) != 0) {
-                        // (kernels of an earlier render on this stream may still read the block: the copy is ordered behind them)
-                        ctx->resolve_host = rt;
-                        HIPCHK(ctx, hipMemcpyAsync(ctx->d_resolve, &ctx->resolve_host, sizeof(rt), hipMemcpyHostToDevice, stream));
-                    }
-                    P.resolve = ctx->d_resolve;
-                }
-            }
-        }
-        // open lens: one dome per table variant (vpt_tail.hip: sky_dome_kernel<true>), for batches; traced AND untraced samples use them
-        if (!ctx->no_sky_dome && compact && cam->lens_radius != 0.0f && kp->integrator == 0 && kp->environment_type == 0) {
-            const float dk[4] = {kp->sky_mult, kp->sky_color.x, kp->sky_color.y, kp->sky_color.z};
-            const bool valid = ctx->lens_dome_built && ctx->sky_patch_built && ctx->sky_dome_k >= view_k && std::memcmp(dk, ctx->lens_dome_key, sizeof(dk)) == 0;
-            if (valid || iter_count >= 2u) {
-                if (!valid) {
-                    if (ctx->sky_dome_k < view_k) {
-                        if (ctx->tab_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-                        HIPCHK(ctx, hipStreamSynchronize(stream));
-                        (void)hipFree(ctx->d_sky_dome); ctx->d_sky_dome = nullptr; ctx->sky_dome_k = -1;
-                        HIPCHK(ctx, hipMalloc(&ctx->d_sky_dome, sky_dome_bytes(view_k)));
-                        ctx->sky_dome_k = view_k;
-                    }
-                    if (!tables_written && ctx->tab_stream && ctx->tab_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tab_stream));
-                    tables_written = true;
-                    HIPCHK(ctx, launch_sky_dome(R, ctx->d_sky_view, ctx->d_sky_dome, view_k, stream));
-                    std::memcpy(ctx->lens_dome_key, dk, sizeof(dk));
-                    ctx->lens_dome_built = true;
-                    ctx->sky_patch_built = true;          // (the flag the table rebuilds clear: "caches valid for the current tables")
-                    std::memset(ctx->sky_patch_key, 0, sizeof(ctx->sky_patch_key));     // ... but no closed-lens patches exist
-                }
-                R.sky_dome = ctx->d_sky_dome;
-            }
-        }
-        // stream order: the tables are built on the stream of the render that needed them; a later render on another stream
-        // reuses them only behind the event recorded after that build
-        if (tables_written) {
-            if (!ctx->tab_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->tab_event, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventRecord(ctx->tab_event, stream));
-            ctx->tab_stream = stream;
-        } else if (ctx->tab_event && ctx->tab_stream != stream) {
-            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->tab_event, 0));
-        }
+    // the per-view caches of the environment tail (vpt_caches.hip): tables, patches, never-traced pixels, dome(s), resolved samples
+    {
+        const int rc = vpt_view_caches_prepare(ctx, cam, ref_sphere, kp, compact, iter_count, R, P, stream);
+        if (rc != VPT_OK) return rc;
     }
     ctx->last_resolve = R;
     ctx->have_last_resolve = true;
@@ -1672,6 +1315,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (kernel_multi) P.octree_full_single = 0;
         if (kp->integrator != 0) {
             HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
+#ifdef VPT_WITH_POOL
         } else if (ctx->use_pool && trace_pool_supports(P)) {
             // one workgroup per CU, each with its own pool of rays in LDS
             if (!ctx->d_pool_hist) HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus));
@@ -1679,6 +1323,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             P.trans_min = ctx->pool_min_lanes;
             const int pool_blocks = (int)std::min<unsigned long long>((total + 831) / 832, (unsigned long long)ctx->num_cus);
             HIPCHK(ctx, launch_trace_pool(P, multi, color, emit, std::max(pool_blocks, 1), 64 * ctx->pool_waves, stream));
+#endif
         } else {
             HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         }
@@ -1689,6 +1334,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         for (int k = 0; k < 3; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
         ctx->last_samples += total;
     }
+    if (!ctx->render_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->render_event, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->render_event, stream));
+    ctx->render_stream = stream;
     return VPT_OK;
 }
 

@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void blue_noise_kernel(float* bn /* float3[655
     float x = bn[3 * i], y = bn[3 * i + 1], z = bn[3 * i + 2];
     const float phi = (1.0f + sqrtf(5.0f)) / 2.0f;
     for (uint32_t k = 0; k < count; ++k) {
-        if (table) table[(size_t)k * 65536u + i] = make_float2(x, y);
+        // CONTRACT (vpt_abi.h): jitter values lie in [0, 1] (the reference's come from an 8-bit image / 255, then x -> fmod(x + phi, 1)); what
+        // raygen and the tail READ is clamped to it -- the never-traced pixel mask and the sky patches are built for that footprint
+        if (table) table[(size_t)k * 65536u + i] = make_float2(fminf(fmaxf(x, 0.0f), 1.0f), fminf(fmaxf(y, 0.0f), 1.0f));
         for (uint32_t s = 0; s < stride && i < live; ++s) {
             x = fmodf(x + phi, 1.0f);
             y = fmodf(y + phi, 1.0f);

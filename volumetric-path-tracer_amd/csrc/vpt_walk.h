@@ -293,6 +293,12 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         }
     }
     int spins = 0;
+    auto tally = [&](int which, unsigned long long n) {          // counting builds: one atomic per wave and event (Counters::retry)
+        const unsigned long long m = __ballot(1);
+        unsigned long long s = 0;
+        for (unsigned long long mm = m; mm != 0ull; mm &= mm - 1ull) s += (unsigned long long)__shfl((int)n, __ffsll((long long)mm) - 1);
+        if (__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&P.counters->retry[which], s);
+    };
     for (;;) {
         const float lg = det_logf(1 - rnd(rng, draws));
         if (COUNT) c.n_steps++;
@@ -307,13 +313,18 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
                 // a retry draws once and a step that goes on draws a second time: stay within the words
                 // buffered since the pass's refill point (vpt_rng.h), and do not hold the wave up for long
                 const uint32_t buffered = (rng.has_carry ? 1u : 0u) + (4u - rng.idx);
-                if (buffered < 2u || ++spins >= VPT_RETRY_SPINS) return WALK_GOES_ON;
+                if (buffered < 2u || ++spins >= VPT_RETRY_SPINS) {
+                    if (COUNT) { tally(1, 1ull); tally(2, (unsigned long long)(spins > 0 ? spins : 1)); }
+                    return WALK_GOES_ON;
+                }
                 continue;
             }
+            if (COUNT && use_retries) { tally(3, 1ull); if (spins > 0) tally(2, (unsigned long long)spins); }
             return WALK_DONE;
         }
         break;
     }
+    if (COUNT && use_retries) { tally(0, 1ull); if (spins > 0) tally(2, (unsigned long long)spins); }
     w.pos += w.dir * w.t;                                                     // cumulative t (Q-list 1)
     if (!contains(K.root_lo, K.root_hi, w.pos)) return WALK_DONE;
     if (SPLIT && !MULTI && !is_emit) {

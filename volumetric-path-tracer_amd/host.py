@@ -198,6 +198,10 @@ class Context:
         self._chk(self.lib.vpt_scene_get_octree_stats(self.h, C.byref(out)), "vpt_scene_get_octree_stats")
         return list(out)
 
+    def invalidate_sky_tables(self):
+        """drop the per-view caches of the environment tail (they are rebuilt by the next render that needs them)"""
+        self._chk(self.lib.vpt_invalidate_sky_tables(self.h), "vpt_invalidate_sky_tables")
+
     def set_counting(self, on):
         self._chk(self.lib.vpt_set_counting(self.h, int(bool(on))), "vpt_set_counting")
 
