@@ -70,7 +70,7 @@ def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1
     # against the oracle's strict arithmetic.  Measured on one iteration (profiles/r03_sky_error_probe.txt): config 2 median 7e-6,
     # 99th percentile 6e-4, worst pixel 7e-3 (the same with the ground table switched off: the outliers are ground points whose
     # binary32 radius flips between the two arithmetics, not the table); config 3 6e-4 / 2e-3; config 5 (open lens: table variants)
-    # 3.7e-3 / 5.2e-3 -- 7e-4 / 5.2e-3 without its ground tables.  (Over a few iterations the 99th percentile first RISES -- 1.5e-3
+    # 3.7e-3 / 5.2e-3 after ONE iteration -- 7e-4 / 5.2e-3 without its ground tables; after the two iterations the tests render 1.98e-3 / 4.7e-3.  (Over a few iterations the 99th percentile first RISES -- 1.5e-3
     # after three frames of config 2: more pixels have met one outlier sample, each diluted by the mean -- before it falls.)
     rel = _per_pixel(got, ob.accum)
     assert rel.size > 0.5 * got.shape[0] or ob.accum.max(1).mean() < 1e-3
@@ -182,5 +182,8 @@ def test_config4_cloud_benchmark_size_grid_1080p(pkg, monkeypatch):
 def test_config5_100_instances_4k_dof_sun_and_sky(pkg):
     sd = pkg.scene.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0, sky=True)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    e, st = _compare(pkg, sd, 2, p99=5e-3, caches=("sky_dome", "cam_table", "dir_table"))    # the open lens' ground-table variants: see _compare; one dome per variant
+    # the open lens: one ground table and one dome per binary32 step of r across the lens disc, each variant gated at build time on real rays
+    # through both paths (worst <= 2 %, <= 2 % above 1e-3, <= 1 % above 2e-3: vpt_tail.hip sky_dir_table_verdict_kernel); measured here after the
+    # two iterations: per-pixel p99 1.98e-3 with the tables, 1.79e-3 without (profiles/r04_c5_p99.txt) -- the common 2e-3 bound holds
+    e, st = _compare(pkg, sd, 2, caches=("sky_dome", "cam_table", "dir_table"))
     assert st.color_lookups > 0 and st.density_lookups > 2 * st.tracking_steps       # several instances per leaf and step

@@ -618,9 +618,12 @@ __global__ void sky_dir_table_check_kernel(const ResolveParams R, const SkyView*
 // open lens, horizontally within the lens radius) -- is evaluated
 // twice through sample_atmosphere: in full (the reference's arithmetic: binary32 ground point, its radius as the reference finds
 // it) and through the table; the two tone-curved radiances the tail would add to L are compared.  Per variant v, at err[8 + 4 v]:
-// largest relative difference (high word) and its cell, rays compared, rays off by more than 1e-3.  The interpolation check above
+// largest relative difference (high word) and its cell, rays compared, rays off by more than 1e-3, rays off by more than VPT_DIR_TAB_P99.  The interpolation check above
 // cannot see what this one sees: the rays whose binary32 ground point lies one step (0.5 m) above the ground (vpt_sky.h,
 // GroundFromTable) -- more of them from the off-centre origins of an open lens.
+#ifndef VPT_DIR_TAB_P99
+#define VPT_DIR_TAB_P99 2e-3f
+#endif
 template <bool LENS>
 __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* view, unsigned long long* err) {
     typedef Sky<ResolveParams> S;
@@ -684,6 +687,7 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
         const unsigned long long m = __ballot(valid && cv == v);
         if (m == 0ull) continue;
         const unsigned long long above = __ballot(valid && cv == v && !(dev <= 1e-3f));
+        const unsigned long long above2 = __ballot(valid && cv == v && !(dev <= VPT_DIR_TAB_P99));
         unsigned long long key = (valid && cv == v) ? (((unsigned long long)bits << 32) | c) : 0ull;
         for (int s = 32; s >= 1; s >>= 1) {
             const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), s) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, s);
@@ -694,6 +698,7 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
             if ((key >> 32) != 0ull) atomicMax(e, key);
             atomicAdd(e + 1, (unsigned long long)__popcll(m));
             if (above != 0ull) atomicAdd(e + 2, (unsigned long long)__popcll(above));
+            if (above2 != 0ull) atomicAdd(e + 3, (unsigned long long)__popcll(above2));
         }
     }
 }
@@ -707,7 +712,9 @@ __global__ void sky_dir_table_verdict_kernel(unsigned long long* err, SkyView* v
     for (int v = 0; v <= 2 * k; ++v) {
         const unsigned long long* e = err + 8 + 4 * v;
         const float worst = __uint_as_float((uint32_t)(e[0] >> 32));
-        const bool ok = view->tab[v].w != 0.0f && e[1] > 0ull && worst <= 2e-2f && e[2] * 50ull <= e[1];
+        // ... and its 99th percentile within VPT_DIR_TAB_P99 (2e-3: the per-pixel bound the full-size tests hold every config to): behind an
+        // open lens the off-centre variants meet the ground point's binary32 radius flip more often than the centre one
+        const bool ok = view->tab[v].w != 0.0f && e[1] > 0ull && worst <= 2e-2f && e[2] * 50ull <= e[1] && e[3] * 100ull <= e[1];
         if (!ok) view->tab[v].w = 0.0f;
         in_use += ok ? 1ull : 0ull;
     }

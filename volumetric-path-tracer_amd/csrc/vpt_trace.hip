@@ -140,9 +140,6 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             const f3 inv0 = rcp3(dir0);
             if (rendered) obj = closest_object(P, org0, dir0, inv0, t_hit);
             bool traced = obj != 0;
-#ifdef VPT_STUDY_RG_NOTRACE
-            traced = false;
-#endif
             if (P.integrator != 0) {
                 // vol_integrator (:1732) enters its loop iff the ray hits the root box, whatever
                 // the sphere does; depth_calculator (:1875) still uses get_closest_object
@@ -161,11 +158,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
             // repeating the pushes at its own lane occupancy.
             f3 adv_pos = mk3(0.0f);
             uint32_t adv = 0u;
-#ifdef VPT_STUDY_RG_NOWALK
-            if (false) {
-#else
             if (traced && P.integrator == 0 && obj == 1 && !P.octree_full_single) {
-#endif
                 f3 pos = org0;
                 pos += dir0 * (t_hit + VPT_EPS);                                    // :1783-1785, as the tracer's refill does
                 const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
@@ -193,11 +186,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
                     adv = 0x80u | (pushes << 8);
                 }
             }
-#ifdef VPT_STUDY_RG_NOPHILOX
-            if (false) {
-#else
             if (closed && traced) {
-#endif
                 rng_init(rng, pixel, iteration * 4096u);
                 f3 pd;
                 do {
