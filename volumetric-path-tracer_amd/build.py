@@ -23,7 +23,10 @@ HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("
           sorted(os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include")) if f.endswith(".h"))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of fp32 operations into packed v_pk_* instructions -- the same issue cost as the two
+# scalar ones on gfx950 (profiles/r02_valu_issue_probe.txt) but operands in aligned VGPR pairs, constants included: the direct tracer needs
+# 133 registers without them and 158 with (profiles/r04_four_waves.txt); every kernel of the path is at least as fast without.
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-fno-slp-vectorize"]
 STRICT = ["-ffp-contract=off", "-fno-fast-math"]
 VALUE_ONLY = ["-ffp-contract=off", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 SOURCES = {

@@ -245,13 +245,27 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
     if (COUNT && n_empty_skips) atomicAdd(&P.counters->skip_steps, (unsigned long long)n_empty_skips);
 }
+// Waves per SIMD.  The plain instantiation -- one volume, no colour grid, no emission march: config 2 -- fits 128 registers without a spill
+// once the compiler is kept from forming packed-fp32 instructions (build.py: -fno-slp-vectorize; with them it needed 158), and four
+// workgroups per CU fit the LDS with a density history of 8 entries: FOUR waves per SIMD, +17 % throughput of the same code over three
+// (profiles/r04_four_waves.txt).  The others keep three: their instance loop / colour fetch / emission march needs the registers, and their
+// longer first walks the 12-entry history (an overflow replays the walk).
 #ifndef VPT_TRACE_WAVES_PER_EU
 #define VPT_TRACE_WAVES_PER_EU 3
 #endif
+#ifndef VPT_TRACE_WAVES_PER_EU_PLAIN
+#define VPT_TRACE_WAVES_PER_EU_PLAIN 4
+#endif
+#ifndef VPT_HIST_CAP_PLAIN
+#define VPT_HIST_CAP_PLAIN 8
+#endif
+constexpr bool trace_plain(bool multi, bool color, bool emit) { return !multi && !color && !emit; }
+int trace_blocks_per_cu(bool multi, bool color, bool emit) { return trace_plain(multi, color, emit) ? VPT_TRACE_WAVES_PER_EU_PLAIN : VPT_TRACE_WAVES_PER_EU; }
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool A24>
-__global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, trace_plain(MULTI, COLOR, EMIT) ? VPT_TRACE_WAVES_PER_EU_PLAIN : VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
+    constexpr int HCAP = trace_plain(MULTI, COLOR, EMIT) ? VPT_HIST_CAP_PLAIN : VPT_HIST_CAP;
     __shared__ uint32_t s_occ[20];
-    __shared__ float s_hist[VPT_HIST_CAP * 256];      // [entry][thread]: densities seen by the fused first walk
+    __shared__ float s_hist[HCAP * 256];              // [entry][thread]: densities seen by the fused first walk
     __shared__ float s_park[30 * 256];                // [field][thread]: path-level state parked in LDS
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     if (EMIT) stage_emission_lut(P);
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             // (one-piece step: moving the refill behind the step, as the split-phase look-up of the vol tracer needs, costs this tracer
             // 16 % -- its refilled lanes would idle for a pass -- against 1 % gained from the overlap; measured, not used here)
             Pending no_pd;
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false, 256, HCAP>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 // ... and direct_integrator's first sample() call (:1789), which would add the same
                 // densities to Alpha a second time (:1670)
                 if (w.alpha < 1.0f) {
-                    if (n_hist > VPT_HIST_CAP) {
+                    if (n_hist > (uint32_t)HCAP) {
                         phase = PH_T_REPLAY;
                     } else {
                         for (uint32_t i = 0; i < n_hist; ++i)

@@ -200,8 +200,8 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
 // a pass of the walk loop each.
 // What follows a step's density look-up: sample() accepts or rejects the collision (:1667-1675), Tr() multiplies its estimate
 // (:1239, :1261).  Shared by the one-piece step and the second half of the split-phase step.  Returns true when the walk ended.
-// HS: floats between two entries of a lane's density history (256: [entry][thread] in LDS; the pool tracer keeps it in HBM)
-template <bool MULTI, bool COLOR, bool COUNT, bool A24, int HS = 256>
+// HS: floats between two entries of a lane's density history (256: [entry][thread] in LDS; the pool tracer keeps it in HBM); HCAP: its entries
+template <bool MULTI, bool COLOR, bool COUNT, bool A24, int HS = 256, int HCAP = VPT_HIST_CAP>
 VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample, bool record_hist, float* hist, uint32_t& n_hist, Walk& w, Rng& rng,
                        uint32_t& draws, float density, int leaf, int cell) {
     if (is_sample) {
@@ -209,7 +209,7 @@ VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample,
         // emission_pivot) and fetch are evaluated there.
         if (w.alpha < 1.0f) w.alpha += density;
         if (record_hist) {
-            if (n_hist < VPT_HIST_CAP) hist[n_hist * HS] = density;
+            if (n_hist < (uint32_t)HCAP) hist[n_hist * HS] = density;
             n_hist++;
         }
         if (density * K.inv_max > rnd(rng, draws)) {
@@ -241,7 +241,7 @@ VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample,
 // lanes from the ray queue, itself a ~1 us record read -- before walk_finish interpolates and decides: the two memory
 // latencies of a pass overlap instead of adding up.  Per lane the operations and their order are unchanged.
 enum { WALK_GOES_ON = 0, WALK_DONE = 1, WALK_PENDING = 2 };
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false, int HS = 256>
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false, int HS = 256, int HCAP = VPT_HIST_CAP>
 VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
                     int& retries, bool use_retries, Pending& pd) {
@@ -373,7 +373,7 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         w.Ld += em;                                                           // :1335
         return WALK_GOES_ON;
     }
-    return walk_decide<MULTI, COLOR, COUNT, A24, HS>(P, K, is_sample, record_hist, hist, n_hist, w, rng, draws, density, leaf, cell) ? WALK_DONE : WALK_GOES_ON;
+    return walk_decide<MULTI, COLOR, COUNT, A24, HS, HCAP>(P, K, is_sample, record_hist, hist, n_hist, w, rng, draws, density, leaf, cell) ? WALK_DONE : WALK_GOES_ON;
 }
 
 // second half of a split-phase step: the texels requested by walk_step have (had time to) arrive
