@@ -15,7 +15,8 @@
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
-int trace_blocks_per_cu(bool multi, bool color, bool emit);      // workgroups per CU the direct tracer's instantiation is built for
+int trace_vol_blocks_per_cu();
+int trace_blocks_per_cu();                                         // workgroups per CU the direct tracer is built for (its waves per SIMD)
 #ifdef VPT_WITH_POOL              // study builds only (csrc/variants/vpt_trace_pool.hip, build.py --with-pool): the round-3 pool tracer
 hipError_t launch_trace_pool(const TraceParams& P, bool multi, bool color, bool emit, int blocks, int threads, hipStream_t stream);
 size_t trace_pool_hist_floats_per_block();
@@ -67,7 +68,7 @@ struct vpt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    int blocks_per_cu = 0;         // VPT_BLOCKS_PER_CU: tracer workgroups per CU; 0 = what the instantiation is built for (3, or 4: vpt_trace.hip)
+    int blocks_per_cu = 0;         // VPT_BLOCKS_PER_CU: tracer workgroups per CU; 0 = what the tracer is built for (direct: 4, vpt_trace.hip; vol: 3)
     uint32_t regen_min = 8;        // direct_integrator tracer: refill once >= 8 lanes are idle
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them

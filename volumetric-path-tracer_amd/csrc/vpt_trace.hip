@@ -245,28 +245,24 @@ __global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
     if (COUNT && n_empty_skips) atomicAdd(&P.counters->skip_steps, (unsigned long long)n_empty_skips);
 }
-// Waves per SIMD.  The plain instantiation -- one volume, no colour grid, no emission march: config 2 -- fits 128 registers without a spill
-// once the compiler is kept from forming packed-fp32 instructions (build.py: -fno-slp-vectorize; with them it needed 158), and four
-// workgroups per CU fit the LDS with a density history of 8 entries: FOUR waves per SIMD, +17 % throughput of the same code over three
-// (profiles/r04_four_waves.txt).  The others keep three: their instance loop / colour fetch / emission march needs the registers, and their
-// longer first walks the 12-entry history (an overflow replays the walk).
+// FOUR waves per SIMD.  Kept from forming packed-fp32 instructions (build.py: -fno-slp-vectorize) the compiler needs 128-147 registers for
+// these kernels instead of 158, the plain and the instanced instantiations fit 128 without a spill (the others spill 2-4 words), and four
+// workgroups per CU fit the LDS with 28 parked fields and a density history of 11 entries (8 next to the emission march's 3 KB table: an
+// overflow replays the first walk, config 3 +4 % look-ups).  The fourth wave is worth +17 % throughput of the same code on config 2,
+// +13 % on config 5, +10 % on config 3 (profiles/r04_four_waves.txt) -- at three waves the SIMDs issued 69 % of the time.
 #ifndef VPT_TRACE_WAVES_PER_EU
-#define VPT_TRACE_WAVES_PER_EU 3
+#define VPT_TRACE_WAVES_PER_EU 4
 #endif
-#ifndef VPT_TRACE_WAVES_PER_EU_PLAIN
-#define VPT_TRACE_WAVES_PER_EU_PLAIN 4
+#ifndef VPT_HIST_CAP_EMIT
+#define VPT_HIST_CAP_EMIT 8
 #endif
-#ifndef VPT_HIST_CAP_PLAIN
-#define VPT_HIST_CAP_PLAIN 8
-#endif
-constexpr bool trace_plain(bool multi, bool color, bool emit) { return !multi && !color && !emit; }
-int trace_blocks_per_cu(bool multi, bool color, bool emit) { return trace_plain(multi, color, emit) ? VPT_TRACE_WAVES_PER_EU_PLAIN : VPT_TRACE_WAVES_PER_EU; }
+int trace_blocks_per_cu() { return VPT_TRACE_WAVES_PER_EU; }
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool A24>
-__global__ __launch_bounds__(256, trace_plain(MULTI, COLOR, EMIT) ? VPT_TRACE_WAVES_PER_EU_PLAIN : VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
-    constexpr int HCAP = trace_plain(MULTI, COLOR, EMIT) ? VPT_HIST_CAP_PLAIN : VPT_HIST_CAP;
+__global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
+    constexpr int HCAP = EMIT ? VPT_HIST_CAP_EMIT : VPT_HIST_CAP;
     __shared__ uint32_t s_occ[20];
     __shared__ float s_hist[HCAP * 256];              // [entry][thread]: densities seen by the fused first walk
-    __shared__ float s_park[30 * 256];                // [field][thread]: path-level state parked in LDS
+    __shared__ float s_park[28 * 256];                // [field][thread]: path-level state parked in LDS (28 fields)
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     if (EMIT) stage_emission_lut(P);
     __syncthreads();

@@ -38,7 +38,7 @@ struct LdsF3S {
 typedef LdsF3S<256> LdsF3;
 
 #ifndef VPT_HIST_CAP
-#define VPT_HIST_CAP 12
+#define VPT_HIST_CAP 11
 #endif
 
 VPT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }

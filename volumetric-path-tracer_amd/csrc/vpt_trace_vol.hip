@@ -147,11 +147,19 @@ VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
     return mk3(o[0], o[1], o[2]);
 }
 
+#ifndef VPT_VOL_WAVES_PER_EU
+#define VPT_VOL_WAVES_PER_EU 3
+#endif
+#ifndef VPT_VOL_HIST_CAP
+#define VPT_VOL_HIST_CAP VPT_HIST_CAP
+#endif
+int trace_vol_blocks_per_cu() { return VPT_VOL_WAVES_PER_EU; }
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT, bool A24>
-__global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(const TraceParams P) {
+    constexpr int HCAP = VPT_VOL_HIST_CAP;
     __shared__ uint32_t s_occ[20];
-    __shared__ float s_hist[VPT_HIST_CAP * 256];
-    __shared__ float s_park[40 * 256];                // [field][thread]: path-level state parked in LDS (vpt_trace_common.h)
+    __shared__ float s_hist[HCAP * 256];
+    __shared__ float s_park[38 * 256];                // [field][thread]: path-level state parked in LDS (vpt_trace_common.h), 38 fields
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
 
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
     const LdsF3 Li = {park + 24 * 256}, wi = {park + 27 * 256};        // estimate_sky scratch
     const LdsF light_pdf = {park + 30 * 256}, phase_pdf = {park + 31 * 256}, mis_w = {park + 32 * 256};
     const LdsF depth = {park + 33 * 256}, t_box = {park + 34 * 256};
-    const LdsI budget = {parki + 36 * 256}, light_index = {parki + 37 * 256}, cam_draws_p = {parki + 38 * 256};
+    const LdsI budget = {parki + 35 * 256}, light_index = {parki + 36 * 256}, cam_draws_p = {parki + 37 * 256};
     uint32_t n_hist = 0;
     int retry = 0;                 // vol_integrator's depth loop (:1737): iterations left after the sample() call being
                                    // walked, i.e. current depth = ray_depth - retry (retries run inline, vpt_walk.h)
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
             int r = WALK_GOES_ON;
             if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
                 const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
-                r = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24, SPLIT>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
+                r = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24, SPLIT, 256, HCAP>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
                                                                             retry, phase == VH_W_TRACK, pd);
             }
             if (r != WALK_PENDING) pd.state = 0;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
         // ==== ... and the steps with texels in flight interpolate and decide ====================
         if (SPLIT && pd.state != 0) {
             const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : WALK_TR;
-            const bool done = walk_finish<COLOR, COUNT, A24>(P, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, pd);
+            const bool done = walk_finish<COLOR, COUNT, A24, HCAP>(P, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, pd);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
                 else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void trace_vol_kernel(const TraceParams P) 
                 depth = w.mi ? length(f3(org0) - w.pos) : .0f;                      // :1879-1881
                 // vol_integrator's first sample() (:1740) adds the same densities to Alpha again
                 if (w.alpha < 1.0f) {
-                    if (n_hist > VPT_HIST_CAP) {
+                    if (n_hist > (uint32_t)HCAP) {
                         phase = VH_T_REPLAY;
                     } else {
                         for (uint32_t i = 0; i < n_hist; ++i)

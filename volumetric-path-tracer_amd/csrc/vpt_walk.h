@@ -377,11 +377,11 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
 }
 
 // second half of a split-phase step: the texels requested by walk_step have (had time to) arrive
-template <bool COLOR, bool COUNT, bool A24>
+template <bool COLOR, bool COUNT, bool A24, int HCAP = VPT_HIST_CAP>
 VPT_D bool walk_finish(const TraceParams& P, const WalkConst& K, int kind, bool record_hist, float* hist, uint32_t& n_hist, Walk& w, Rng& rng,
                        uint32_t& draws, const Pending& pd) {
     const float density = pd.state == 2 ? lerp8(pd) : 0.0f;
-    return walk_decide<false, COLOR, COUNT, A24>(P, K, kind == WALK_SAMPLE, record_hist, hist, n_hist, w, rng, draws, density, 0, 0);
+    return walk_decide<false, COLOR, COUNT, A24, 256, HCAP>(P, K, kind == WALK_SAMPLE, record_hist, hist, n_hist, w, rng, draws, density, 0, 0);
 }
 
 // Tr prologue :1153-1167 (shared by sun / point-light / sky / sphere shadow rays): returns true
