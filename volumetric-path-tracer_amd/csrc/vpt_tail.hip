@@ -447,9 +447,12 @@ __global__ __launch_bounds__(256) void sky_fix_kernel(const ResolveParams R, flo
 // {alpha, depth} pairs of VPT_TAIL_GROUP iterations are requested together (two memory round trips per group instead of one or two per
 // iteration: the old loop's 64 iterations were a chain of ~100 dependent latencies).
 #ifndef VPT_TAIL_GROUP
-#define VPT_TAIL_GROUP 8
+#define VPT_TAIL_GROUP 4                   // x 6 waves per SIMD (8 x 4 waves: 4 % slower; 16: registers; profiles/r04_resolved_samples.txt, r04_four_waves.txt)
 #endif
-__global__ __launch_bounds__(256) void tail_stream_kernel(const ResolveParams R) {
+#ifndef VPT_TAIL_STREAM_WAVES_PER_EU
+#define VPT_TAIL_STREAM_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
     const float4* pp = R.sky_patch + 3u * (size_t)idx;

@@ -50,8 +50,11 @@ namespace vpt {
 //     slot index into the work queue (wave-ballot compaction, one atomic per wave).
 // ROWS: pixel rows per raygen block (block = 64 x 4 threads, ROWS / 4 passes): 64 for batches (one queue-tail atomic per 4096
 // samples), 16 for launches of a few iterations (the per-frame call, main.cpp:1822-1829: four times the blocks to fill the chip)
+#ifndef VPT_RAYGEN_WAVES_PER_EU
+#define VPT_RAYGEN_WAVES_PER_EU 7          // 72 registers, no spill (8: 64 registers + 8 spilled, slower; profiles/r04_four_waves.txt)
+#endif
 template <bool COUNT, int VPT_RAYGEN_ROWS>
-__global__ __launch_bounds__(256) void raygen_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(const TraceParams P) {
     // grid: tiles x iterations (1-D, tile-major); a block sweeps a 64x64 pixel tile in 16 passes and
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
     __shared__ uint32_t s_q[64 * VPT_RAYGEN_ROWS];
