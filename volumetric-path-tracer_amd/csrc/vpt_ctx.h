@@ -16,6 +16,7 @@
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
 int trace_vol_blocks_per_cu();
+size_t trace_vol_hist_floats_per_block();                          // > 0: the vol tracer keeps its first-walk density history in HBM (TraceParams::pool_hist)
 int trace_blocks_per_cu();                                         // workgroups per CU the direct tracer is built for (its waves per SIMD)
 #ifdef VPT_WITH_POOL              // study builds only (csrc/variants/vpt_trace_pool.hip, build.py --with-pool): the round-3 pool tracer
 hipError_t launch_trace_pool(const TraceParams& P, bool multi, bool color, bool emit, int blocks, int threads, hipStream_t stream);
@@ -78,6 +79,7 @@ struct vpt_ctx {
     int pool_waves = 12;           // VPT_POOL_WAVES: waves of the one workgroup per CU (8..12)
     uint32_t pool_min_lanes = 40;  // VPT_POOL_MIN_LANES: fewest lanes a pass starts with while other waves still hold rays
     float* d_pool_hist = nullptr;
+    size_t pool_hist_floats = 0;
     std::string last_error;
     std::vector<TexEntry> textures;
     // scene

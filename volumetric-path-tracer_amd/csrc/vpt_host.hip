@@ -1315,11 +1315,21 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         const bool kernel_multi = kp->integrator != 0 ? (multi || color || emit) : multi;
         if (kernel_multi) P.octree_full_single = 0;
         if (kp->integrator != 0) {
+            if (trace_vol_hist_floats_per_block() != 0u) {
+                const size_t need = trace_vol_hist_floats_per_block() * (size_t)max_blocks;
+                if (ctx->pool_hist_floats < need) {
+                    HIPCHK(ctx, hipStreamSynchronize(stream));
+                    (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, need * sizeof(float)));
+                    ctx->pool_hist_floats = need;
+                }
+                P.pool_hist = ctx->d_pool_hist;
+            }
             HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
 #ifdef VPT_WITH_POOL
         } else if (ctx->use_pool && trace_pool_supports(P)) {
             // one workgroup per CU, each with its own pool of rays in LDS
-            if (!ctx->d_pool_hist) HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus));
+            if (ctx->pool_hist_floats < trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus) { (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus; HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * ctx->pool_hist_floats)); }
             P.pool_hist = ctx->d_pool_hist;
             P.trans_min = ctx->pool_min_lanes;
             const int pool_blocks = (int)std::min<unsigned long long>((total + 831) / 832, (unsigned long long)ctx->num_cus);

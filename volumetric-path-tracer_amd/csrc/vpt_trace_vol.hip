@@ -147,18 +147,32 @@ VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
     return mk3(o[0], o[1], o[2]);
 }
 
+// FOUR waves per SIMD here too (round 4), which takes the density history of the fused first walk out of the LDS: next to the 38 parked
+// fields only one history entry would fit four workgroups per CU (measured: the replayed first walks, +39 % look-ups on config 4, cost more
+// than the wave returns).  So the history lives in HBM ([workgroup][entry][thread], TraceParams::pool_hist: one coalesced 4-byte store per
+// lane and first-walk step, read back eight entries at a time when the walk ends), 32 entries deep.  Config 4's tracer 14.7 -> 13.9 ms per
+// 16 spp; the same history at three waves: 15.0 (profiles/r04_four_waves.txt).
 #ifndef VPT_VOL_WAVES_PER_EU
-#define VPT_VOL_WAVES_PER_EU 3
+#define VPT_VOL_WAVES_PER_EU 4
+#endif
+#ifndef VPT_VOL_HIST_HBM
+#define VPT_VOL_HIST_HBM 1
 #endif
 #ifndef VPT_VOL_HIST_CAP
-#define VPT_VOL_HIST_CAP VPT_HIST_CAP
+#define VPT_VOL_HIST_CAP (VPT_VOL_HIST_HBM ? 32 : VPT_HIST_CAP)
 #endif
 int trace_vol_blocks_per_cu() { return VPT_VOL_WAVES_PER_EU; }
+size_t trace_vol_hist_floats_per_block() { return VPT_VOL_HIST_HBM ? (size_t)VPT_VOL_HIST_CAP * 256u : 0u; }
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT, bool A24>
 __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(const TraceParams P) {
     constexpr int HCAP = VPT_VOL_HIST_CAP;
     __shared__ uint32_t s_occ[20];
+#if VPT_VOL_HIST_HBM
+    float* const hist = P.pool_hist + (size_t)blockIdx.x * (size_t)(HCAP * 256) + threadIdx.x;
+#else
     __shared__ float s_hist[HCAP * 256];
+    float* const hist = s_hist + threadIdx.x;
+#endif
     __shared__ float s_park[38 * 256];                // [field][thread]: path-level state parked in LDS (vpt_trace_common.h), 38 fields
     if (threadIdx.x < 19) s_occ[threadIdx.x] = P.occ[threadIdx.x];
     __syncthreads();
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
             int r = WALK_GOES_ON;
             if (phase >= VH_W_FIRST && phase <= VH_W_LAST) {
                 const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : (phase == VH_W_EMIT ? WALK_EMIT : WALK_TR);
-                r = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24, SPLIT, 256, HCAP>(P, s_occ, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt,
+                r = walk_step<MULTI, COLOR, EMIT, COUNT, false, A24, SPLIT, 256, HCAP>(P, s_occ, K, kind, phase == VH_W_FIRST, hist, n_hist, w, rng, draws, cnt,
                                                                             retry, phase == VH_W_TRACK, pd);
             }
             if (r != WALK_PENDING) pd.state = 0;
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
         // ==== ... and the steps with texels in flight interpolate and decide ====================
         if (SPLIT && pd.state != 0) {
             const int kind = phase <= VH_W_TRACK ? WALK_SAMPLE : WALK_TR;
-            const bool done = walk_finish<COLOR, COUNT, A24, HCAP>(P, K, kind, phase == VH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, pd);
+            const bool done = walk_finish<COLOR, COUNT, A24, HCAP>(P, K, kind, phase == VH_W_FIRST, hist, n_hist, w, rng, draws, pd);
             if (done) {
                 if (phase == VH_W_FIRST) phase = VH_T_FIRST_DONE;
                 else if (phase == VH_W_TRACK) phase = VH_T_VTRACK_DONE;
@@ -345,8 +359,19 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                     if (n_hist > (uint32_t)HCAP) {
                         phase = VH_T_REPLAY;
                     } else {
+#if VPT_VOL_HIST_HBM
+                        for (uint32_t i0 = 0; i0 < n_hist; i0 += 8u) {          // eight entries per round trip
+                            float hv[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) hv[j] = i0 + j < n_hist ? hist[(i0 + j) * 256u] : 0.0f;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j)
+                                if (i0 + j < n_hist && w.alpha < 1.0f) w.alpha += hv[j];
+                        }
+#else
                         for (uint32_t i = 0; i < n_hist; ++i)
-                            if (w.alpha < 1.0f) w.alpha += s_hist[i * 256 + threadIdx.x];
+                            if (w.alpha < 1.0f) w.alpha += hist[i * 256];
+#endif
                     }
                 }
                 if (phase == VH_T_FIRST_DONE) {
