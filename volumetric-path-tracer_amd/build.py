@@ -1,6 +1,6 @@
 """Build libvpt_hip.so (the C-ABI library of include/vpt_abi.h) for gfx950 with hipcc.
 
-    python volumetric-path-tracer_amd/build.py [--force] [--verbose] [--variant NAME [--with-pool]] [-DNAME=VALUE ...]
+    python volumetric-path-tracer_amd/build.py [--force] [--verbose] [--variant NAME [--with-pool] [--arith fast]] [-DNAME=VALUE ...]
 
 Flags that matter for parity (Arithmetic): the tracer, the host code and the
 resolve kernel are compiled STRICT: -ffp-contract=off (no FMA contraction on the decision
@@ -54,11 +54,22 @@ def _stale(target, deps):
 POOL_SOURCE = os.path.join("variants", "vpt_trace_pool.hip")
 
 
-def build(force=False, verbose=False, extra_flags=(), variant=None, with_pool=False):
+# --arith fast (study builds only): the tracer compiled the way a renderer without a bit-parity contract would be -- FMA contraction, approximate
+# divide / sqrt.  A DIAGNOSTIC of what the arithmetic contract costs; its images are close to, not equal to, the reference's.
+FAST_ARITH = ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+FAST_ARITH_SOURCES = ("vpt_trace.hip", "vpt_trace_vol.hip")
+
+
+def build(force=False, verbose=False, extra_flags=(), variant=None, with_pool=False, arith=None):
     """variant: build libvpt_hip_<variant>.so with `extra_flags` next to the default library (perf
     experiments: select it at run time with VPT_LIB_PATH)."""
     global OBJ, OUT
     sources = dict(SOURCES)
+    if arith == "fast":
+        if not variant:
+            raise RuntimeError("--arith fast builds a study library: give it a --variant name")
+        for src in FAST_ARITH_SOURCES:
+            sources[src] = FAST_ARITH
     if with_pool:
         if not variant:
             raise RuntimeError("--with-pool builds a study library: give it a --variant name")
@@ -131,7 +142,12 @@ if __name__ == "__main__":
         i = argv.index("--variant")
         variant = argv[i + 1]
         del argv[i:i + 2]
+    arith = None
+    if "--arith" in argv:
+        i = argv.index("--arith")
+        arith = argv[i + 1]
+        del argv[i:i + 2]
     build(force="--force" in argv, verbose="--verbose" in argv,
           extra_flags=[a for a in argv if a.startswith("-") and a not in ("--force", "--verbose", "--with-pool")], variant=variant,
-          with_pool="--with-pool" in argv)
+          with_pool="--with-pool" in argv, arith=arith)
     print("built", OUT)

@@ -58,6 +58,9 @@ struct DVolume {
     int addr24;            // every texel-index product of this volume's grids fits the 24-bit multiplier (see imul)
     float rdim[3];         // RN(1 / fdim)
     int fast_div;          // q / fdim may be formed as y + (q - fdim y) rdim, y = q rdim: the host checked all three extents (vpt_fastdiv.h)
+    // (float) of the three texture extents, host-converted: the compiler keeps a launch-uniform conversion in a VECTOR register for the whole
+    // kernel (gfx950 has no scalar float unit); as descriptor fields they are scalar operands (profiles/r04_four_waves.txt (i))
+    float dimf[3], edimf[3], cdimf[3];
 };
 
 struct DTexture {          // CUDA sampler state restated
@@ -184,6 +187,11 @@ struct TraceParams {
     // octree / scene
     float root_pmin[3], root_pmax[3];
     float max_ext, min_ext;
+    // launch-uniform values of the walk, host-evaluated (IEEE single: the same bits as the device's correctly rounded divide; a uniform quotient
+    // formed in the kernel lives in a vector register for the whole launch): 1 / max_ext (:1645), 1 / density_mult (:1646),
+    // 1 / (max_ext - min_ext) (:1165), and the root's centre (root_pmin + root_pmax) * 0.5 (the first octree split)
+    float inv_max_ext, inv_density_mult, sigma_r_inv;
+    float root_mid[3];
     uint32_t occ[19];                // [0]: level-1, [1..2]: level-2, [3..18]: level-3 occupancy
     const uint32_t* leaf_offsets;    // 513 CSR offsets (multi-volume scenes)
     const uint32_t* leaf_indices;

@@ -521,6 +521,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
         st3(d.bmin, vi.bmin);
         d.fdim[0] = (float)vi.dim.x; d.fdim[1] = (float)vi.dim.y; d.fdim[2] = (float)vi.dim.z;
         d.dim[0] = vi.dim.x; d.dim[1] = vi.dim.y; d.dim[2] = vi.dim.z;
+        for (int a = 0; a < 3; ++a) { d.dimf[a] = (float)d.dim[a]; d.edimf[a] = (float)d.edim[a]; d.cdimf[a] = (float)d.cdim[a]; }
         d.fast_div = ctx->no_fast_div ? 0 : 1;
         for (int a = 0; a < 3; ++a) {
             d.rdim[a] = 1.0f / d.fdim[a];
@@ -1121,6 +1122,9 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     std::memcpy(&P.cam, cam, sizeof(DCamera));
     st3(P.root_pmin, ctx->root.lo); st3(P.root_pmax, ctx->root.hi);
     P.max_ext = ctx->max_ext; P.min_ext = ctx->min_ext;
+    P.inv_max_ext = 1.0f / P.max_ext;
+    P.sigma_r_inv = 1.0f / (P.max_ext - P.min_ext);
+    for (int a = 0; a < 3; ++a) P.root_mid[a] = (P.root_pmin[a] + P.root_pmax[a]) * 0.5f;
     std::memcpy(P.occ, ctx->occ, sizeof(P.occ));
     P.leaf_offsets = ctx->d_leaf_offsets; P.leaf_indices = ctx->d_leaf_indices;
     P.volumes = ctx->d_volumes; P.num_volumes = (int)ctx->host_dvolumes.size();
@@ -1143,6 +1147,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.phase_g1 = kp->phase_g1;
     st3(P.albedo, kp->albedo); st3(P.extinction, kp->extinction);
     P.tr_depth = kp->tr_depth; P.density_mult = kp->density_mult;
+    P.inv_density_mult = 1.0f / P.density_mult;
     P.emission_scale = kp->emission_scale; P.emission_pivot = kp->emission_pivot;
     st3(P.sun_color, kp->sun_color); P.sun_mult = kp->sun_mult;
     st3(P.sun_dir, sun_dir);

@@ -140,9 +140,9 @@ VPT_D int locate(const TraceParams& P, const uint32_t* occ, const OccTop& o, f3 
     int path = 0;
 #pragma unroll
     for (int level = 0; level < 3; ++level) {
-        const float hx = (lo.x + hi.x) * 0.5f;
-        const float hy = (lo.y + hi.y) * 0.5f;
-        const float hz = (lo.z + hi.z) * 0.5f;
+        const float hx = level == 0 ? P.root_mid[0] : (lo.x + hi.x) * 0.5f;
+        const float hy = level == 0 ? P.root_mid[1] : (lo.y + hi.y) * 0.5f;
+        const float hz = level == 0 ? P.root_mid[2] : (lo.z + hi.z) * 0.5f;
         const bool xh = !(p.x <= hx);
         const bool yh = p.y >= hy;
         const bool zh = !(p.z <= hz);
@@ -219,7 +219,7 @@ VPT_D void split_slot(const TraceParams& P, uint32_t slot, uint32_t& kiter, uint
 VPT_D void claim_chunk(const TraceParams& P, uint32_t total, int lane, int leader, uint32_t& chunk_next, uint32_t& chunk_end, bool& more) {
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(P.work_counter, P.chunk);
-    base = __shfl(base, leader);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);     // wave-uniform: the claim lives in scalar registers
     chunk_next = min(base, total);
     chunk_end = min(base + P.chunk, total);
     if (chunk_end == total) more = false;
@@ -243,11 +243,11 @@ struct Taps {
     int jr, kr;           // floor of the y / z texel coordinate before clamping (GRID_QUADS rows)
     float ax, ay, az;
 };
-VPT_D Taps make_taps(const int* dim, f3 u) {
+VPT_D Taps make_taps(const int* dim, const float* dimf, f3 u) {      // dimf[a] = (float)dim[a] (DVolume)
     Taps t;
-    float xb = u.x * (float)dim[0] - 0.5f;
-    float yb = u.y * (float)dim[1] - 0.5f;
-    float zb = u.z * (float)dim[2] - 0.5f;
+    float xb = u.x * dimf[0] - 0.5f;
+    float yb = u.y * dimf[1] - 0.5f;
+    float zb = u.z * dimf[2] - 0.5f;
     float fx = floorf(xb), fy = floorf(yb), fz = floorf(zb);
     t.ax = xb - fx;
     t.ay = yb - fy;
@@ -424,7 +424,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (COUNT) n_d++;
         if (FC) count_fetch(P, 0, inside);
         if (inside) {
-            const Taps t = make_taps(v.dim, u);
+            const Taps t = make_taps(v.dim, v.dimf, u);
             density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
                        : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)
                                                  : fetch_f32<A24>(v.density, v.dim, t);
@@ -437,7 +437,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         } else {
             if (COUNT) n_c++;
             if (FC) count_fetch(P, 1, inside);
-            f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, u)) : mk3(0.0f);
+            f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, v.cdimf, u)) : mk3(0.0f);
             color = fmax3(color, c);
         }
     }
@@ -446,7 +446,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             if (COUNT) n_e++;
             if (FC) count_fetch(P, 2, inside);
             if (inside) {
-                const Taps t = make_taps(v.edim, u);
+                const Taps t = make_taps(v.edim, v.edimf, u);
                 float index = v.elayout == GRID_QUADS ? fetch_f32_quads<A24>(v.emission, v.edim, t) : fetch_f32<A24>(v.emission, v.edim, t);
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
                 const int e = 3 * (int)index;

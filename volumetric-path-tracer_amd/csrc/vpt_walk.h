@@ -42,10 +42,10 @@ VPT_D WalkConst make_walk_const(const TraceParams& P) {
     WalkConst K;
     K.root_lo = ld3(P.root_pmin);
     K.root_hi = ld3(P.root_pmax);
-    K.inv_max = 1.0f / P.max_ext;
-    K.inv_dm = 1.0f / P.density_mult;
+    K.inv_max = P.inv_max_ext;
+    K.inv_dm = P.inv_density_mult;
     K.sigma_c = P.min_ext;
-    K.sigma_r_inv = 1.0f / (P.max_ext - K.sigma_c);
+    K.sigma_r_inv = P.sigma_r_inv;
     return K;
 }
 
@@ -127,7 +127,7 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
     const bool inside = to_unit(P.vol0.m, P.vol0, p, u);
     if (!inside) return;
     const DVolume& v = P.vol0;
-    const Taps t = make_taps(v.dim, u);
+    const Taps t = make_taps(v.dim, v.dimf, u);
     // 128-byte line of each of the 8 taps in the layout actually used
     uint32_t a[8];
     if (v.layout == GRID_QUADS) {
@@ -336,7 +336,7 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         if (COLOR && COUNT && is_sample && P.vol0.has_color) c.n_c++;          // the reference looks the colour up here (:1662)
         pd.state = 1;
         if (inside) {
-            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, u), pd);
+            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, P.vol0.dimf, u), pd);
             pd.state = 2;
         }
         if (COUNT) coherence_stats<A24>(P, w.pos);
