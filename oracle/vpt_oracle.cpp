@@ -86,13 +86,21 @@ static inline AxisTap axis_tap(float u, int n, int mode, int normalized, int lin
     return r;
 }
 
-static f4 tex_sample(const Tex* t, float u, float v, float w) {
+// DIAGNOSTIC switch (orc_set_volume_tex_weights; never on in the parity tests): the CUDA texture unit holds the linear filter's weights in 9-bit
+// fixed point with 8 fractional bits (CUDA C Programming Guide, "Linear Filtering"); the reference's tex3D calls on the volume grids
+// (render_kernel.cu:999-1014) run on that hardware, while the parity contract -- the reference compiled for the CPU, this oracle, the HIP path -- is full
+// binary32 weights.  Model of the hardware, for the three volume-grid look-ups only: weight = floor(a * 256 + 0.5) / 256, the same nested lerps.
+static int g_volume_weight_bits = 32;
+static inline float quant8(float a) { return std::floor(a * 256.0f + 0.5f) * 0.00390625f; }
+
+static f4 tex_sample(const Tex* t, float u, float v, float w, bool volume_grid = false) {
     const int lin = t->d.filter_mode == VPT_FILTER_LINEAR;
     const int nrm = t->d.normalized_coords;
     AxisTap ax = axis_tap(u, t->d.width, t->d.address_mode[0], nrm, lin);
     AxisTap ay = {0, 0, 0.0f}, az = {0, 0, 0.0f};
     if (t->d.height > 1 || t->d.depth > 1) ay = axis_tap(v, t->d.height, t->d.address_mode[1], nrm, lin);
     if (t->d.depth > 1) az = axis_tap(w, t->d.depth, t->d.address_mode[2], nrm, lin);
+    if (volume_grid && g_volume_weight_bits == 8) { ax.a = quant8(ax.a); ay.a = quant8(ay.a); az.a = quant8(az.a); }
     if (!lin) return texel(t, ax.i0, ay.i0, az.i0);
     // nested lerp: x, then y, then z; lerp(a,b,t) = a + t*(b-a)
     f4 c00 = lerp4(texel(t, ax.i0, ay.i0, az.i0), texel(t, ax.i1, ay.i0, az.i0), ax.a);
@@ -740,7 +748,7 @@ static inline bool to_unit(const Volume& v, f3& pos) {
 static inline float get_density(Ctx& c, f3 pos, const Volume& v) {
     c.st.density_lookups++;
     if (!to_unit(v, pos)) return .0f;
-    return tex_sample(as_tex(v.vdb.vdb_info.density_texture), pos.x, pos.y, pos.z).x;
+    return tex_sample(as_tex(v.vdb.vdb_info.density_texture), pos.x, pos.y, pos.z, true).x;
 }
 // sum_density :1003-1014
 static inline float sum_density(Ctx& c, f3 ray_pos, const Node* leaf) {
@@ -753,7 +761,7 @@ static inline f3 get_color(Ctx& c, f3 pos, const Volume& v) {
     if (!v.vdb.vdb_info.has_color) return WHITE();
     c.st.color_lookups++;
     if (!to_unit(v, pos)) return mk3(.0f);
-    return xyz(tex_sample(as_tex(v.vdb.vdb_info.color_texture), pos.x, pos.y, pos.z));
+    return xyz(tex_sample(as_tex(v.vdb.vdb_info.color_texture), pos.x, pos.y, pos.z, true));
 }
 // sum_color :931-943 (component-wise max)
 static inline f3 sum_color(Ctx& c, f3 ray_pos, const Node* leaf) {
@@ -766,7 +774,7 @@ static inline f3 get_emission(Ctx& c, f3 pos, const Volume& v) {
     if (!v.vdb.vdb_info.has_emission) return BLACK();
     c.st.emission_lookups++;
     if (!to_unit(v, pos)) return mk3(.0f);
-    float index = tex_sample(as_tex(v.vdb.vdb_info.emission_texture), pos.x, pos.y, pos.z).x;
+    float index = tex_sample(as_tex(v.vdb.vdb_info.emission_texture), pos.x, pos.y, pos.z, true).x;
     index = clampf(index * 255.0f / c.kp->emission_pivot, .0f, 255.0f);
     return to_f3(c.kp->emission_texture[(int)index]) * c.kp->emission_scale;
 }
@@ -1255,6 +1263,13 @@ static PixelOut trace_pixel(Ctx& c, const vpt_camera& cam, int x, int y, const v
 // C API
 // ======================================================================================
 extern "C" {
+
+// 32 (default: the parity contract) or 8 (diagnostic model of the CUDA texture unit's weights, volume grids only); returns the previous value
+int orc_set_volume_tex_weights(int bits) {
+    const int prev = g_volume_weight_bits;
+    if (bits == 8 || bits == 32) g_volume_weight_bits = bits;
+    return prev;
+}
 
 vpt_texture_t orc_texture_create(const vpt_texture_desc* desc, const float* data) {
     Tex* t = new Tex();

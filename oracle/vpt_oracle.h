@@ -52,6 +52,9 @@ vpt_texture_t orc_texture_create(const vpt_texture_desc *desc, const float *data
 void orc_texture_destroy(vpt_texture_t tex);
 /* sample a texture directly (unit tests of the sampler restatement) */
 void orc_texture_sample(vpt_texture_t tex, float u, float v, float w, float out[4]);
+/* DIAGNOSTIC (never on in the parity tests): 8 = the volume-grid look-ups quantise their linear-filter weights to 1/256, a model of the CUDA texture
+ * unit's 1.8 fixed-point weights; 32 = binary32 weights (default, the parity contract).  Returns the previous setting. */
+int orc_set_volume_tex_weights(int bits);
 
 /* Philox4x32-10 block function + cuRAND stream semantics (unit tests) */
 void orc_philox4x32_10(const unsigned int ctr[4], const unsigned int key[2], unsigned int out[4]);

@@ -46,6 +46,8 @@ def load_oracle():
     o.orc_texture_destroy.restype = None
     o.orc_texture_sample.argtypes = [abi.vpt_texture_t, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float * 4)]
     o.orc_texture_sample.restype = None
+    o.orc_set_volume_tex_weights.argtypes = [C.c_int]
+    o.orc_set_volume_tex_weights.restype = C.c_int
     o.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint * 4), C.POINTER(C.c_uint * 2), C.POINTER(C.c_uint * 4)]
     o.orc_philox4x32_10.restype = None
     o.orc_curand_uniform_stream.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_int, vp]

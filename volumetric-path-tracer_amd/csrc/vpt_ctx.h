@@ -141,6 +141,7 @@ struct vpt_ctx {
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
     bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
     bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
+    bool tex_fixed8 = false;               // VPT_TEX_WEIGHTS=fixed8: diagnostic model of the CUDA texture unit's 1.8 fixed-point weights (vpt_trace_common.h: make_taps)
     bool no_fast_div = false;              // VPT_NO_FAST_DIV: every look-up divides by the grid extent (tests: both forms give the same bits)
     bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
     float dir_tab_tol = 5e-4f;             // VPT_DIR_TABLE_TOL: largest relative mid-cell error the ground table may show

@@ -154,6 +154,7 @@ struct TraceParams {
     uint32_t width, height, n_pixels;
     float inv_n_pixels;              // 1 / n_pixels (fp32), see split_slot
     float rcp_w, rcp_h;              // RN(1 / width), RN(1 / height)
+    int tex_fixed8;                  // VPT_TEX_WEIGHTS=fixed8 (diagnostic): the grid look-ups quantise their interpolation weights to 1/256 (make_taps)
     int fast_uv;                     // get_ray's u and v may be formed with them (both extents checked, vpt_fastdiv.h)
     uint32_t iter_begin, iter_stride, iter_count;
     uint32_t max_interactions;

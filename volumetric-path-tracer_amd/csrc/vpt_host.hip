@@ -217,6 +217,8 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
+    { const char* tw = std::getenv("VPT_TEX_WEIGHTS"); ctx->tex_fixed8 = tw != nullptr && std::strcmp(tw, "fixed8") == 0; }
+    if (ctx->tex_fixed8) ctx->counting = true;       // a diagnostic: carried by the counting instantiations of the tracers only (make_taps)
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -676,7 +678,7 @@ int vpt_scene_get_octree_stats(vpt_ctx* ctx, int out_nonempty[3]) {
 
 int vpt_set_counting(vpt_ctx* ctx, int enable) {
     if (!ctx) return VPT_E_INVALID;
-    ctx->counting = enable != 0;
+    ctx->counting = enable != 0 || ctx->tex_fixed8;          // (the fixed8 diagnostic lives in the counting instantiations)
     return VPT_OK;
 }
 
@@ -1107,6 +1109,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.width = W; P.height = H; P.n_pixels = n_pixels;
     P.inv_n_pixels = 1.0f / (float)n_pixels;
     P.rcp_w = 1.0f / (float)W; P.rcp_h = 1.0f / (float)H;
+    P.tex_fixed8 = ctx->tex_fixed8 ? 1 : 0;
     P.fast_uv = !ctx->no_fast_div && divisor_checked((float)W, P.rcp_w) && divisor_checked((float)H, P.rcp_h) ? 1 : 0;
     P.iter_stride = iter_stride;
     P.max_interactions = kp->max_interactions;

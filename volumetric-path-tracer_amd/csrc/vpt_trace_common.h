@@ -243,7 +243,13 @@ struct Taps {
     int jr, kr;           // floor of the y / z texel coordinate before clamping (GRID_QUADS rows)
     float ax, ay, az;
 };
-VPT_D Taps make_taps(const int* dim, const float* dimf, f3 u) {      // dimf[a] = (float)dim[a] (DVolume)
+// fixed8 (TraceParams::tex_fixed8, VPT_TEX_WEIGHTS=fixed8): a DIAGNOSTIC model of the CUDA texture unit, which holds the interpolation weights in
+// 9-bit fixed point with 8 fractional bits (CUDA C Programming Guide, "Linear Filtering"); the reference's tex3D calls (render_kernel.cu:999-1014)
+// run on that hardware, the parity contract here is full binary32 weights.  Model: weight = floor(a * 256 + 0.5) / 256, same lerps.
+// Only the COUNTING instantiations of the tracers carry the switch (the host runs them when it is set): a launch-uniform scalar branch per look-up
+// moved the timed instantiation's schedule by 1.6 % on config 2 (profiles/r04_four_waves.txt (m)), and a diagnostic must cost the product nothing.
+VPT_D float quant8(float a) { return floorf(a * 256.0f + 0.5f) * 0.00390625f; }
+VPT_D Taps make_taps(const int* dim, const float* dimf, f3 u, int fixed8) {      // dimf[a] = (float)dim[a] (DVolume)
     Taps t;
     float xb = u.x * dimf[0] - 0.5f;
     float yb = u.y * dimf[1] - 0.5f;
@@ -252,6 +258,7 @@ VPT_D Taps make_taps(const int* dim, const float* dimf, f3 u) {      // dimf[a] 
     t.ax = xb - fx;
     t.ay = yb - fy;
     t.az = zb - fz;
+    if (fixed8) { t.ax = quant8(t.ax); t.ay = quant8(t.ay); t.az = quant8(t.az); }      // launch-uniform: a scalar branch
     int i = (int)fx, j = (int)fy, k = (int)fz;
     t.i0 = min(max(i, 0), dim[0] - 1);
     t.i1 = min(max(i + 1, 0), dim[0] - 1);
@@ -424,7 +431,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (COUNT) n_d++;
         if (FC) count_fetch(P, 0, inside);
         if (inside) {
-            const Taps t = make_taps(v.dim, v.dimf, u);
+            const Taps t = make_taps(v.dim, v.dimf, u, (COUNT || FC) ? P.tex_fixed8 : 0);
             density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
                        : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)
                                                  : fetch_f32<A24>(v.density, v.dim, t);
@@ -437,7 +444,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         } else {
             if (COUNT) n_c++;
             if (FC) count_fetch(P, 1, inside);
-            f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, v.cdimf, u)) : mk3(0.0f);
+            f3 c = inside ? fetch_f4<A24>(v.color, v.cdim, make_taps(v.cdim, v.cdimf, u, (COUNT || FC) ? P.tex_fixed8 : 0)) : mk3(0.0f);
             color = fmax3(color, c);
         }
     }
@@ -446,7 +453,7 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
             if (COUNT) n_e++;
             if (FC) count_fetch(P, 2, inside);
             if (inside) {
-                const Taps t = make_taps(v.edim, v.edimf, u);
+                const Taps t = make_taps(v.edim, v.edimf, u, (COUNT || FC) ? P.tex_fixed8 : 0);
                 float index = v.elayout == GRID_QUADS ? fetch_f32_quads<A24>(v.emission, v.edim, t) : fetch_f32<A24>(v.emission, v.edim, t);
                 index = clampf(index * 255.0f / P.emission_pivot, .0f, 255.0f);
                 const int e = 3 * (int)index;

@@ -127,7 +127,7 @@ VPT_D void coherence_stats(const TraceParams& P, f3 p) {
     const bool inside = to_unit(P.vol0.m, P.vol0, p, u);
     if (!inside) return;
     const DVolume& v = P.vol0;
-    const Taps t = make_taps(v.dim, v.dimf, u);
+    const Taps t = make_taps(v.dim, v.dimf, u, P.tex_fixed8);
     // 128-byte line of each of the 8 taps in the layout actually used
     uint32_t a[8];
     if (v.layout == GRID_QUADS) {
@@ -336,7 +336,7 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         if (COLOR && COUNT && is_sample && P.vol0.has_color) c.n_c++;          // the reference looks the colour up here (:1662)
         pd.state = 1;
         if (inside) {
-            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, P.vol0.dimf, u), pd);
+            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, P.vol0.dimf, u, COUNT ? P.tex_fixed8 : 0), pd);
             pd.state = 2;
         }
         if (COUNT) coherence_stats<A24>(P, w.pos);
