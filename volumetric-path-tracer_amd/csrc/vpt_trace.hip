@@ -273,7 +273,6 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
     const uint32_t total = *P.queue_count;          // rays that entered the volume box / hit the sphere
     const int lane = __lane_id();
     const WalkConst K = make_walk_const(P);
-    const f3 sun_dir = ld3(P.sun_dir);
     const uint32_t regen_min = P.regen_min;
     const uint32_t trans_min = P.trans_min;
 
@@ -484,7 +483,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 if (run_trans) atomicAdd(&P.counters->sched[4], 1ull);
             }
         }
-        while (run_trans && __any(phase >= PH_T_FIRST)) {
+        // (the launch constants of the transition states: scalar loads per pass, see ColdConst)
+        if (run_trans) {
+        const ColdConst C = load_cold_const();
+        while (__any(phase >= PH_T_FIRST)) {
             if (COUNT) {
                 const unsigned long long tm = __ballot(phase >= PH_T_FIRST);
                 if (lane == 0) {
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             if (phase == PH_T_REPLAY) {
                 // history overflow (long walk through thin medium): replay the integrator's first walk
                 // for real, from the primary ray and the post-camera rng state
-                const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                const uint32_t iteration = C.iter_begin + kiter * C.iter_stride;
                 const uint32_t cam_draws = (uint32_t)(int)cam_draws_p;
                 rng_init(rng, pixel, iteration * 4096u + cam_draws);
                 draws = cam_draws;
@@ -537,12 +539,12 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 beta *= w.wgt;
                 const bool brk = is_black(f3(beta)) || w.obj2;
                 if (!brk && w.mi) {
-                    sample_hg(w.dir, rng, draws, P.phase_g1);
+                    sample_hg(w.dir, rng, draws, C.phase_g1);
                     w.inv = rcp3(w.dir);
                 }
                 gco_obj = -1;
                 vd++;
-                if (!brk && (int)vd <= P.volume_depth) {
+                if (!brk && (int)vd <= C.volume_depth) {
                     w.mi = false;
                     w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
                     phase = PH_W_TRACK;
@@ -550,16 +552,16 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     // estimate_sun :1478-1516
                     ppos = w.pos;
                     pdir = w.dir;
-                    start_tr = true; tr_dir = sun_dir; tr_walk_phase = PH_W_SUN; tr_done_phase = PH_T_SUN_DONE;
+                    start_tr = true; tr_dir = C.sun_dir; tr_walk_phase = PH_W_SUN; tr_done_phase = PH_T_SUN_DONE;
                 } else {
                     phase = PH_T_OUTER_SECOND;
                 }
             } else if (phase == PH_T_SUN_DONE) {
-                const float cos_theta = dot(f3(pdir), sun_dir);
-                const float phase_pdf = henyey_greenstein(cos_theta, P.phase_g1);
+                const float cos_theta = dot(f3(pdir), C.sun_dir);
+                const float phase_pdf = henyey_greenstein(cos_theta, C.phase_g1);
                 const f3 Lsun = mk3(w.trw) * phase_pdf;
-                L += (Lsun * ld3(P.sun_color) * P.sun_mult) * f3(beta);             // :1514, :1798
-                if (P.num_lights > 0) {
+                L += (Lsun * C.sun_color * C.sun_mult) * f3(beta);             // :1514, :1798
+                if (C.num_lights > 0) {
                     budget = 10;                                                    // :1459
                     w.Ld = mk3(0.0f);
                     phase = PH_T_PL_NEXT;
@@ -567,14 +569,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     phase = PH_T_EMIT_CHECK;
                 }
             } else if (phase == PH_T_PL_DONE) {
-                if ((int)budget < P.num_lights) {
+                if ((int)budget < C.num_lights) {
                     // point_light::Le, light.h:104-121
-                    const DPointLight& lt = P.lights[(int)light_index];
+                    const DPointLight& lt = C.lights[(int)light_index];
                     const f3 lp = ld3(lt.pos);
                     const f3 pp = ppos;
                     const f3 wi = normalize(lp - pp);
                     const float cos_theta = dot(f3(pdir), wi);
-                    const float phase_pdf = henyey_greenstein(cos_theta, P.phase_g1);
+                    const float phase_pdf = henyey_greenstein(cos_theta, C.phase_g1);
                     const float sqr_dist = length(lp * lp - pp * pp);
                     const float falloff = 1 / sqr_dist;
                     w.Ld += ld3(lt.color) * lt.power * mk3(w.trw) * phase_pdf * falloff;
@@ -588,19 +590,19 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
             if (phase == PH_T_PL_NEXT) {
                 // estimate_point_light :1461-1466 (1 draw)
-                int li = (int)floorf(rnd(rng, draws) * P.num_lights);
-                if (li > P.num_lights - 1) li = P.num_lights - 1;                    // rand()==1.0f guard
+                int li = (int)floorf(rnd(rng, draws) * C.num_lights);
+                if (li > C.num_lights - 1) li = C.num_lights - 1;                    // rand()==1.0f guard
                 light_index = li;
-                const DPointLight& lt = P.lights[li];
+                const DPointLight& lt = C.lights[li];
                 start_tr = true; tr_dir = normalize(ld3(lt.pos) - f3(ppos)); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
             } else if (phase == PH_T_EMIT_CHECK || phase == PH_T_EMIT_DONE || phase == PH_T_SPH_DONE) {
                 if (phase == PH_T_EMIT_DONE) L += w.Ld;                             // :1803
-                if (phase == PH_T_SPH_DONE) L += ld3(P.sun_color) * P.sun_mult * mk3(w.trw) * (float)sph_factor * f3(beta);  // :1832
+                if (phase == PH_T_SPH_DONE) L += C.sun_color * C.sun_mult * mk3(w.trw) * (float)sph_factor * f3(beta);  // :1832
                 w.pos = f3(ppos);
                 w.dir = f3(pdir);
                 w.inv = rcp3(w.dir);
                 gco_obj = -1;
-                if (phase == PH_T_EMIT_CHECK && EMIT && P.emission_scale > 0) {     // :1802 (mi is true here)
+                if (phase == PH_T_EMIT_CHECK && EMIT && C.emission_scale > 0) {     // :1802 (mi is true here)
                     w.t = 0.0f;
                     w.Ld = mk3(0.0f);
                     phase = PH_W_EMIT;
@@ -614,11 +616,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             }
             VPT_TICK(ts1);                       // TRACK_DONE .. EMIT / SPH
             if (phase == PH_T_OUTER_SECOND) {
-                if (gco_obj < 0) gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t); // :1806
+                if (gco_obj < 0) gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t); // :1806
                 if (gco_obj == 2) {
                     // sphere bounce :1809-1833 (2 draws)
                     w.pos += w.dir * gco_t;
-                    const f3 normal = normalize((w.pos - ld3(P.sph_center)) / P.sph_radius);
+                    const f3 normal = normalize((w.pos - C.sph_center) / C.sph_radius);
                     const f3 nl = dot(normal, w.dir) < 0 ? normal : normal * -1;
                     const float phi = 2 * VPT_PI * rnd(rng, draws);
                     const float r2 = rnd(rng, draws);
@@ -630,24 +632,24 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     det_sincosf(phi, &sp, &cp);
                     const f3 hemisphere_dir = normalize(uu * cp * r2s + vv * sp * r2s + ww * sqrtf(1 - r2));
                     const f3 ref = reflect(w.dir, nl);
-                    w.dir = lerp3(ref, hemisphere_dir, P.sph_roughness);
+                    w.dir = lerp3(ref, hemisphere_dir, C.sph_roughness);
                     w.pos += normal * VPT_EPS;
-                    beta *= ld3(P.sph_color);
-                    sph_factor = fmax_(dot(sun_dir, normal), .0f);
+                    beta *= C.sph_color;
+                    sph_factor = fmax_(dot(C.sun_dir, normal), .0f);
                     ppos = w.pos;
                     pdir = w.dir;
                     gco_obj = -1;
-                    start_tr = true; tr_dir = sun_dir; tr_walk_phase = PH_W_SPH; tr_done_phase = PH_T_SPH_DONE;
+                    start_tr = true; tr_dir = C.sun_dir; tr_walk_phase = PH_W_SPH; tr_done_phase = PH_T_SPH_DONE;
                 } else {
                     rd++;                          // same ray next iteration: the cached result stays valid
                     phase = PH_T_OUTER_TOP;
                 }
             }
             if (phase == PH_T_OUTER_TOP) {
-                if ((int)rd > P.ray_depth) {
+                if ((int)rd > C.ray_depth) {
                     phase = PH_T_FINISH;
                 } else {
-                    if (gco_obj < 0) gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t);   // :1782
+                    if (gco_obj < 0) gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t);   // :1782
                     if (gco_obj == 1) {
                         w.pos += w.dir * (gco_t + VPT_EPS);
                         gco_obj = -1;
@@ -668,12 +670,12 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                             // (:1806).  Nothing there (the usual case: the ray has left the box for good) ends the path; it is
                             // finished in this very round instead of going round the state list once more (TRACK_DONE sits before
                             // this state).  A sphere ahead goes through OUTER_SECOND with the result cached.
-                            gco_obj = closest_object(P, w.pos, w.dir, w.inv, gco_t);
+                            gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t);
                             if (gco_obj == 0) {
                                 rd++;
                                 phase = PH_T_FINISH;
                             } else {
-                                vd = P.volume_depth + 1;
+                                vd = C.volume_depth + 1;
                                 phase = PH_T_OUTER_SECOND;
                             }
                         } else {
@@ -691,13 +693,12 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             VPT_TICK(ts2);                       // OUTER_SECOND + OUTER_TOP
             if (phase == PH_T_FINISH) {
                 const f3 od = w.dir, oL = L, ob = beta, oe = env_pos;
-                const size_t slot = (size_t)kiter * P.n_pixels + pixel;
+                const size_t slot = (size_t)kiter * C.n_pixels + pixel;
                 // RESOLVED SAMPLES (TraceParams::resolve): what the tail would add to L -- beta x the sky along the exit direction, seen from the
                 // camera origin -- is a dome look-up, done here where ~44 lanes finish together; the sample then leaves as 24 bytes instead of 64.
                 bool resolved = false;
-                const ResolveInTracer* rt = P.resolve;
+                const ResolveInTracer* rt = C.resolve;       // (its fields are fetched here, per batch of finishing paths, not held in the loop's live scalars)
                 if (rt != nullptr) {
-                    asm volatile("" : "+s"(rt));       // (its fields are fetched here, per batch of finishing paths, not hoisted into the loop's live scalars)
                     f3 dv;
                     if (oe.x == rt->cam_origin[0] && oe.y == rt->cam_origin[1] && oe.z == rt->cam_origin[2] && dome_lookup(rt->sky_dome, od, dv)) {
                         const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     }
                 }
                 if (!resolved) {
-                    float4* dst = reinterpret_cast<float4*>(P.records + slot);
+                    float4* dst = reinterpret_cast<float4*>(C.records + slot);
                     dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // tr = fminf(tr, 1) :1854
                     dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
                     dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
@@ -736,8 +737,9 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 
             VPT_TICK(ts3);                       // FINISH
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
-            if (start_tr) phase = tr_begin(P, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
+            if (start_tr) phase = tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
             VPT_TICK(ts4);                       // Tr prologue
+        }
         }
         VPT_TICK(tc3);
     }

@@ -68,11 +68,11 @@ VPT_D bool contains(f3 pmin, f3 pmax, f3 p) {    // AABB.h:141-146
 }
 
 // sphere::intersect + find_discr (geometry/geometry.h:46-70,114-137)
-VPT_D bool sphere_intersect(const TraceParams& P, f3 ray_pos, f3 ray_dir, float& t_min, float& t_max) {
-    f3 orig = ray_pos - ld3(P.sph_center);
+VPT_D bool sphere_intersect(f3 sph_center, float sph_radius, f3 ray_pos, f3 ray_dir, float& t_min, float& t_max) {
+    f3 orig = ray_pos - sph_center;
     float A = ray_dir.x * ray_dir.x + ray_dir.y * ray_dir.y + ray_dir.z * ray_dir.z;
     float B = 2 * (ray_dir.x * orig.x + ray_dir.y * orig.y + ray_dir.z * orig.z);
-    float C = orig.x * orig.x + orig.y * orig.y + orig.z * orig.z - P.sph_radius * P.sph_radius;
+    float C = orig.x * orig.x + orig.y * orig.y + orig.z * orig.z - sph_radius * sph_radius;
     float x1, x2;
     if (B == 0) {
         if (A == 0) return false;
@@ -100,11 +100,15 @@ VPT_D bool sphere_intersect(const TraceParams& P, f3 ray_pos, f3 ray_dir, float&
     return true;
 }
 
+VPT_D bool sphere_intersect(const TraceParams& P, f3 ray_pos, f3 ray_dir, float& t_min, float& t_max) {
+    return sphere_intersect(ld3(P.sph_center), P.sph_radius, ray_pos, ray_dir, t_min, t_max);
+}
+
 // get_closest_object (render_kernel.cu:1118-1135): 0 none, 1 volume box, 2 sphere
-VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min) {
+VPT_D int closest_object(f3 root_lo, f3 root_hi, f3 sph_center, float sph_radius, f3 o, f3 d, f3 inv, float& t_min) {
     float tmin1 = VPT_M_INF, tmax1 = -VPT_M_INF, tmin2 = VPT_M_INF, tmax2 = -VPT_M_INF;
-    bool i1 = box_intersect(ld3(P.root_pmin), ld3(P.root_pmax), o, inv, tmin1, tmax1);
-    bool i2 = sphere_intersect(P, o, d, tmin2, tmax2);
+    bool i1 = box_intersect(root_lo, root_hi, o, inv, tmin1, tmax1);
+    bool i2 = sphere_intersect(sph_center, sph_radius, o, d, tmin2, tmax2);
     if (i1 && !i2) { t_min = tmin1; return 1; }
     if (!i1 && i2) { t_min = tmin2; return 2; }
     if (i1 && i2) {
@@ -112,6 +116,48 @@ VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min)
         if (tmin2 < tmin1) { t_min = tmin2; return 2; }
     }
     return 0;
+}
+
+VPT_D int closest_object(const TraceParams& P, f3 o, f3 d, f3 inv, float& t_min) {
+    return closest_object(ld3(P.root_pmin), ld3(P.root_pmax), ld3(P.sph_center), P.sph_radius, o, d, inv, t_min);
+}
+
+// ---- COLD launch constants ---------------------------------------------------------------------------------------------------------
+// What only the transition states read (sun, sphere, light list, depths, the output pointers).  As fields of the by-value kernel argument they are
+// loaded in the prologue and compete for scalar registers with what the walk step reads on every pass: the register allocator kept 24 of them
+// resident and spilled the world->index matrix of the look-up to VGPR lanes instead (50 v_readlane in the three inlined copies of locate / to_unit of
+// config 2's kernel; profiles/r04_four_waves.txt (n)).  Read through a laundered pointer to the kernel-argument segment (constant address space:
+// scalar loads, a few hundred ns per transition pass, hidden behind the other waves) they are live inside the transition pass only.
+typedef const __attribute__((address_space(4))) TraceParams* KargPtr;
+struct ColdConst {
+    f3 sph_center, sph_color;
+    float sph_radius, sph_roughness;
+    f3 sun_color, sun_dir;
+    float sun_mult, phase_g1, emission_scale;
+    float sky_mult;
+    int ray_depth, volume_depth, num_lights;
+    const DPointLight* lights;
+    uint32_t n_pixels, iter_begin, iter_stride;
+    Record* records;
+    const ResolveInTracer* resolve;
+};
+VPT_D ColdConst load_cold_const() {
+    KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();       // the TraceParams is the kernel's only argument: offset 0 of the segment
+    asm volatile("" : "+s"(k));                                        // (not hoisted out of the pass: that is the point)
+    ColdConst c;
+    c.sph_center = mk3(k->sph_center[0], k->sph_center[1], k->sph_center[2]);
+    c.sph_color = mk3(k->sph_color[0], k->sph_color[1], k->sph_color[2]);
+    c.sph_radius = k->sph_radius; c.sph_roughness = k->sph_roughness;
+    c.sun_color = mk3(k->sun_color[0], k->sun_color[1], k->sun_color[2]);
+    c.sun_dir = mk3(k->sun_dir[0], k->sun_dir[1], k->sun_dir[2]);
+    c.sky_mult = k->sky_mult;
+    c.sun_mult = k->sun_mult; c.phase_g1 = k->phase_g1; c.emission_scale = k->emission_scale;
+    c.ray_depth = k->ray_depth; c.volume_depth = k->volume_depth; c.num_lights = k->num_lights;
+    c.lights = k->lights;
+    c.n_pixels = k->n_pixels; c.iter_begin = k->iter_begin; c.iter_stride = k->iter_stride;
+    c.records = k->records;
+    c.resolve = k->resolve;
+    return c;
 }
 
 // Three-level point location (get_quadrant x3, render_kernel.cu:1102-1115 + :1193-1227).

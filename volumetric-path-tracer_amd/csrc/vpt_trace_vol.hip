@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
     const uint32_t total = *P.queue_count;
     const int lane = __lane_id();
     const WalkConst K = make_walk_const(P);
-    const f3 sun_dir = ld3(P.sun_dir);
     const uint32_t regen_min = P.regen_min;
     const uint32_t trans_min = P.trans_min;
 
@@ -338,7 +337,9 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 if (run_trans) atomicAdd(&P.counters->sched[4], 1ull);
             }
         }
-        while (run_trans && __any(phase >= VH_T_FIRST)) {
+        if (run_trans) {
+        const ColdConst C = load_cold_const();      // the transition states' launch constants: scalar loads per pass (vpt_trace_common.h)
+        while (__any(phase >= VH_T_FIRST)) {
             if (COUNT) {
                 const unsigned long long tm = __ballot(phase >= VH_T_FIRST);
                 if (lane == 0) {
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
             }
             if (phase == VH_T_REPLAY) {
                 // history overflow: walk the integrator's first segment for real
-                const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                const uint32_t iteration = C.iter_begin + kiter * C.iter_stride;
                 const uint32_t cam_draws = (uint32_t)(int)cam_draws_p;
                 rng_init(rng, pixel, iteration * 4096u + cam_draws);
                 draws = cam_draws;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 w.pos = f3(org0) + w.dir * ((float)t_box + VPT_EPS);
                 w.mi = false;
                 w.t = 0.0f; w.geo = false; w.obj2 = false; w.wgt = mk3(1.0f);
-                retry = P.ray_depth - 1;
+                retry = C.ray_depth - 1;
                 phase = VH_W_TRACK;
             }
             if (phase == VH_T_VTRACK_DONE) {
@@ -421,16 +422,16 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                     drew = true;
                     Lsel = mk3(0.0f);
                     if (light_num < 1) {
-                        if (P.sun_mult > .0f) { start_tr = true; tr_dir = sun_dir; tr_done = VH_T_SUN_DONE; phase = VH_W_TR; }
+                        if (C.sun_mult > .0f) { start_tr = true; tr_dir = C.sun_dir; tr_done = VH_T_SUN_DONE; phase = VH_W_TR; }
                         else phase = VH_T_LIGHT_DONE;
                     } else if (light_num >= 1 && light_num < 2) {
-                        if (P.num_lights > 0) {
+                        if (C.num_lights > 0) {
                             budget = 10;                                            // :1459
                             w.Ld = mk3(0.0f);
                             phase = VH_T_PL_NEXT;
                         } else phase = VH_T_LIGHT_DONE;
                     } else {
-                        if (P.sky_mult > .0f) {
+                        if (C.sky_mult > .0f) {
                             w.Ld = mk3(0.0f);
                             phase = VH_T_SKY_A0;
                         } else phase = VH_T_LIGHT_DONE;
@@ -438,17 +439,17 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 }
             } else if (phase == VH_T_SUN_DONE) {
                 // estimate_sun :1478-1516
-                const float cos_theta = dot(f3(pdir), sun_dir);
-                const float pp = henyey_greenstein(cos_theta, P.phase_g1);
-                Lsel = (mk3(w.trw) * pp) * ld3(P.sun_color) * P.sun_mult;
+                const float cos_theta = dot(f3(pdir), C.sun_dir);
+                const float pp = henyey_greenstein(cos_theta, C.phase_g1);
+                Lsel = (mk3(w.trw) * pp) * C.sun_color * C.sun_mult;
                 phase = VH_T_LIGHT_DONE;
             } else if (phase == VH_T_PL_DONE) {
-                if ((int)budget < P.num_lights) {
-                    const DPointLight& lt = P.lights[(int)light_index];             // point_light::Le, light.h:104-121
+                if ((int)budget < C.num_lights) {
+                    const DPointLight& lt = C.lights[(int)light_index];             // point_light::Le, light.h:104-121
                     const f3 lp = ld3(lt.pos), pq = ppos;
                     const f3 wl = normalize(lp - pq);
                     const float cos_theta = dot(f3(pdir), wl);
-                    const float pp = henyey_greenstein(cos_theta, P.phase_g1);
+                    const float pp = henyey_greenstein(cos_theta, C.phase_g1);
                     const float sqr_dist = length(lp * lp - pq * pq);
                     const float falloff = 1 / sqr_dist;
                     w.Ld += ld3(lt.color) * lt.power * mk3(w.trw) * pp * falloff;
@@ -462,11 +463,11 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
             }
             if (phase == VH_T_PL_NEXT && !drew) {
                 // estimate_point_light :1461-1466 (1 draw)
-                int li = (int)floorf(rnd(rng, draws) * P.num_lights);
+                int li = (int)floorf(rnd(rng, draws) * C.num_lights);
                 drew = true;
-                if (li > P.num_lights - 1) li = P.num_lights - 1;                    // rand()==1.0f guard
+                if (li > C.num_lights - 1) li = C.num_lights - 1;                    // rand()==1.0f guard
                 light_index = li;
-                start_tr = true; tr_dir = normalize(ld3(P.lights[li].pos) - f3(ppos)); tr_done = VH_T_PL_DONE; phase = VH_W_TR;
+                start_tr = true; tr_dir = normalize(ld3(C.lights[li].pos) - f3(ppos)); tr_done = VH_T_PL_DONE; phase = VH_W_TR;
             } else if (phase == VH_T_SKY_A0 && !drew) {
                 // estimate_sky :1373-1374: two draws that are never used
                 (void)rnd(rng, draws);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 Li = Lv;
                 phase = VH_T_SKY_C;
                 if (lp > .0f && !is_black(Lv)) {
-                    const float pp = henyey_greenstein(dot(f3(pdir), wv), P.phase_g1);
+                    const float pp = henyey_greenstein(dot(f3(pdir), wv), C.phase_g1);
                     phase_pdf = pp;
                     if (pp > .0f) { start_tr = true; tr_dir = wv; tr_done = VH_T_SKY_B; phase = VH_W_TR; }
                 }
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
             if (phase == VH_T_SKY_C && !drew) {
                 // phase-function sampling :1404-1431 (2 draws)
                 f3 wv = pdir;
-                const float pp = sample_hg_pdf(wv, rng, draws, P.phase_g1);
+                const float pp = sample_hg_pdf(wv, rng, draws, C.phase_g1);
                 wi = wv;
                 drew = true;
                 phase = VH_T_SKY_END;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 phase = VH_T_SKY_END;
             }
             if (phase == VH_T_SKY_END) {
-                Lsel = w.Ld * P.sky_mult;                                           // :1548
+                Lsel = w.Ld * C.sky_mult;                                           // :1548
                 phase = VH_T_LIGHT_DONE;
             }
             if (phase == VH_T_LIGHT_DONE) {
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 w.pos = f3(ppos);
                 w.dir = f3(pdir);
                 w.inv = rcp3(w.dir);
-                if (EMIT && P.emission_scale != 0) {                                // :1285
+                if (EMIT && C.emission_scale != 0) {                                // :1285
                     w.t = 0.0f;
                     w.Ld = mk3(0.0f);
                     phase = VH_W_EMIT;
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 phase = VH_T_SCATTER;
             }
             if (phase == VH_T_SCATTER && !drew) {
-                sample_hg(w.dir, rng, draws, P.phase_g1);                           // :1746 (2 draws)
+                sample_hg(w.dir, rng, draws, C.phase_g1);                           // :1746 (2 draws)
                 drew = true;
                 w.inv = rcp3(w.dir);
                 if (retry == 0) phase = VH_T_FINISH;                                // depth loop exhausted
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
                 const f3 od = normalize(w.dir);                                     // :1750
                 const f3 ob = beta, oL = L;
                 const f3 op = length(ob) > 0.9999f ? f3(org0) : w.pos;              // :1753
-                float4* dst = reinterpret_cast<float4*>(P.records + ((size_t)kiter * P.n_pixels + pixel));
+                float4* dst = reinterpret_cast<float4*>(C.records + ((size_t)kiter * C.n_pixels + pixel));
                 dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // :1755
                 dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
                 dst[2] = make_float4(op.x, op.y, op.z, __uint_as_float(1u));
@@ -581,13 +582,14 @@ __global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(co
             }
 
             if (start_tr) {
-                if (tr_begin(P, K, w, f3(ppos), tr_dir)) {
+                if (tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir)) {
                     tr_next = tr_done;
                     phase = VH_W_TR;
                 } else {
                     phase = tr_done;
                 }
             }
+        }
         }
     }
 }

@@ -386,7 +386,7 @@ VPT_D bool walk_finish(const TraceParams& P, const WalkConst& K, int kind, bool 
 
 // Tr prologue :1153-1167 (shared by sun / point-light / sky / sphere shadow rays): returns true
 // when a walk is needed; otherwise w.trw holds the result (1: misses the box, 0: sphere in the way)
-VPT_D bool tr_begin(const TraceParams& P, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
+VPT_D bool tr_begin(f3 sph_center, float sph_radius, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
     w.pos = from;
     w.dir = tr_dir;
     w.inv = rcp3(tr_dir);
@@ -397,10 +397,13 @@ VPT_D bool tr_begin(const TraceParams& P, const WalkConst& K, Walk& w, f3 from, 
     }
     float geo_dist;
     box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, w.distance);
-    if (sphere_intersect(P, w.pos, w.dir, geo_dist, t_max)) { w.trw = 0.0f; return false; }   // :1160
+    if (sphere_intersect(sph_center, sph_radius, w.pos, w.dir, geo_dist, t_max)) { w.trw = 0.0f; return false; }   // :1160
     w.t = 0.0f;
     w.trw = 1.0f;
     return true;
+}
+VPT_D bool tr_begin(const TraceParams& P, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
+    return tr_begin(ld3(P.sph_center), P.sph_radius, K, w, from, tr_dir);
 }
 // Tr epilogue :1166,:1267
 VPT_D float tr_end(const WalkConst& K, const Walk& w) { return clampf(w.trw * expf(-K.sigma_c * w.distance), .0f, 1.0f); }
