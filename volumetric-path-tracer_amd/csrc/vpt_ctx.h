@@ -15,7 +15,7 @@
 
 namespace vpt {
 hipError_t launch_trace(const TraceParams& P, bool multi, bool color, bool emit, int blocks, hipStream_t stream);
-int trace_vol_blocks_per_cu();
+int trace_vol_blocks_per_cu(bool sky_in_tracer);      // sky_in_tracer: environment_type 0 (the SKYLUT instantiations)
 size_t trace_vol_hist_floats_per_block();                          // > 0: the vol tracer keeps its first-walk density history in HBM (TraceParams::pool_hist)
 int trace_blocks_per_cu();                                         // workgroups per CU the direct tracer is built for (its waves per SIMD)
 #ifdef VPT_WITH_POOL              // study builds only (csrc/variants/vpt_trace_pool.hip, build.py --with-pool): the round-3 pool tracer

@@ -1285,7 +1285,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // without emission grids (render_kernel.cu:1802, :1285)
     // (vol_integrator: estimate_emission returns early only for emission_scale == 0, :1285)
     const bool emit = kp->integrator != 0 ? kp->emission_scale != 0 : kp->emission_scale > 0;
-    const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->use_pool ? 3 : (kp->integrator != 0 ? trace_vol_blocks_per_cu() : trace_blocks_per_cu()));
+    const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->use_pool ? 3 : (kp->integrator != 0 ? trace_vol_blocks_per_cu(kp->environment_type == 0) : trace_blocks_per_cu()));
     const int max_blocks = ctx->num_cus * blocks_per_cu;
 
     for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {

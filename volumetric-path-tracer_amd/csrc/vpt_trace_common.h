@@ -160,6 +160,25 @@ VPT_D ColdConst load_cold_const() {
     return c;
 }
 
+// The single-volume descriptor (TraceParams::vol0) for ONE look-up: ~35 dwords that would otherwise want scalar registers through the whole launch next
+// to the octree's and the walk's constants -- where they all fit the allocator re-reads the descriptor per look-up anyway, where they do not it parks
+// scalars in VGPR lanes (six of the twenty timed instantiations did: 330-470 v_readlane / v_writelane each, tests/test_kernel_resources.py).  Read here,
+// at the look-up, from the kernel-argument segment: the fields a look-up uses arrive in three or four scalar loads.
+VPT_D void load_vol0(DVolume& v) {
+    KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    v.density = k->vol0.density; v.emission = k->vol0.emission; v.color = k->vol0.color;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v.m[i] = k->vol0.m[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.bmin[i] = k->vol0.bmin[i]; v.fdim[i] = k->vol0.fdim[i]; v.dim[i] = k->vol0.dim[i]; v.edim[i] = k->vol0.edim[i]; v.cdim[i] = k->vol0.cdim[i];
+        v.rdim[i] = k->vol0.rdim[i]; v.dimf[i] = k->vol0.dimf[i]; v.edimf[i] = k->vol0.edimf[i]; v.cdimf[i] = k->vol0.cdimf[i];
+    }
+    v.has_color = k->vol0.has_color; v.has_emission = k->vol0.has_emission; v.layout = k->vol0.layout; v.bdim[0] = k->vol0.bdim[0]; v.bdim[1] = k->vol0.bdim[1];
+    v.elayout = k->vol0.elayout; v.addr24 = k->vol0.addr24; v.fast_div = k->vol0.fast_div;
+}
+
 // Three-level point location (get_quadrant x3, render_kernel.cu:1102-1115 + :1193-1227).
 // Child boxes follow divide_bbox (bvh_kernels.cu:150-202): child i covers
 //   x: low half for i in {0,2,4,6}, high half otherwise

@@ -155,16 +155,22 @@ VPT_D f3 sky_at(const TraceParams& P, f3 pos, f3 dir) {
 #ifndef VPT_VOL_WAVES_PER_EU
 #define VPT_VOL_WAVES_PER_EU 4
 #endif
+// ... except the SKYLUT instantiations (environment_type 0: estimate_sky evaluates the Bruneton sky inside the tracer), which want registers, not waves:
+// 256 registers at two waves, 168 + 143 spilled at three, 128 + 240 at four -- tracer 6.5 / 6.9 / 9.9 ms per 8 spp of the dragon at 1080p
+// (tools/vol_sky_probe.py, profiles/r04_four_waves.txt (o)).
+#ifndef VPT_VOL_SKY_WAVES_PER_EU
+#define VPT_VOL_SKY_WAVES_PER_EU 2
+#endif
 #ifndef VPT_VOL_HIST_HBM
 #define VPT_VOL_HIST_HBM 1
 #endif
 #ifndef VPT_VOL_HIST_CAP
 #define VPT_VOL_HIST_CAP (VPT_VOL_HIST_HBM ? 32 : VPT_HIST_CAP)
 #endif
-int trace_vol_blocks_per_cu() { return VPT_VOL_WAVES_PER_EU; }
+int trace_vol_blocks_per_cu(bool sky_in_tracer) { return sky_in_tracer ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WAVES_PER_EU; }
 size_t trace_vol_hist_floats_per_block() { return VPT_VOL_HIST_HBM ? (size_t)VPT_VOL_HIST_CAP * 256u : 0u; }
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool SKYLUT, bool A24>
-__global__ __launch_bounds__(256, VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WAVES_PER_EU) void trace_vol_kernel(const TraceParams P) {
     constexpr int HCAP = VPT_VOL_HIST_CAP;
     __shared__ uint32_t s_occ[20];
 #if VPT_VOL_HIST_HBM

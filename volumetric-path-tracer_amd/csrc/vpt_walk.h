@@ -80,17 +80,25 @@ struct WalkCounts {
 template <bool MULTI, class F>
 VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
     if (!MULTI) {
-        f(P.vol0.m, P.vol0);
+        DVolume v0;
+        load_vol0(v0);
+        f(v0.m, v0);
         return;
     }
-    if (P.single_file) {
+    // (the instance lists' pointers: read where they are used, like the descriptor -- load_vol0)
+    KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    if (k->single_file) {
+        DVolume v0;
+        load_vol0(v0);
         // refined candidate list of the sub-cell (vpt_scene_set_volumes): a subset of the leaf's list in the same order;
         // the instances left out cannot contain the point and would add nothing
         const uint32_t sc = (uint32_t)leaf * (uint32_t)VPT_SUB3 + (uint32_t)cell;
-        const uint32_t b = P.sub_offsets[sc], e = P.sub_offsets[sc + 1u];
+        const uint32_t* sub_offsets = k->sub_offsets;
+        const uint32_t b = sub_offsets[sc], e = sub_offsets[sc + 1u];
         // instances of one file: 48-byte matrix per list entry, the rest from vol0 (SGPRs)
         typedef float __attribute__((ext_vector_type(4))) v4;
-        const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)P.insts;
+        const __attribute__((address_space(1))) v4* ip = (const __attribute__((address_space(1))) v4*)k->insts;
         // insts[] is in leaf-list order (vpt_scene_set_volumes): entry q's matrix sits at q, no index to chase, and the
         // next entry's matrix is requested before the current one is used, so its latency overlaps the transform / fetch
         v4 n0, n1, n2;
@@ -99,12 +107,15 @@ VPT_D void for_each_instance(const TraceParams& P, int leaf, int cell, F&& f) {
             const v4 r0 = n0, r1 = n1, r2 = n2;
             if (q + 1u < e) { const uint32_t vi = (q + 1u) * 4u; n0 = ip[vi]; n1 = ip[vi + 1u]; n2 = ip[vi + 2u]; }
             const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-            f(m, P.vol0);
+            f(m, v0);
         }
     } else {
-        const uint32_t b = P.leaf_offsets[leaf], e = P.leaf_offsets[leaf + 1];
+        const uint32_t* leaf_offsets = k->leaf_offsets;
+        const uint32_t* leaf_indices = k->leaf_indices;
+        const DVolume* volumes = k->volumes;
+        const uint32_t b = leaf_offsets[leaf], e = leaf_offsets[leaf + 1];
         for (uint32_t q = b; q < e; ++q) {
-            const DVolume& v = P.volumes[P.leaf_indices[q]];
+            const DVolume& v = volumes[leaf_indices[q]];
             f(v.m, v);
         }
     }
@@ -330,13 +341,15 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
     if (SPLIT && !MULTI && !is_emit) {
         // request the texels, decide later (walk_finish)
         f3 u;
-        const bool inside = to_unit(P.vol0.m, P.vol0, w.pos, u);
+        DVolume v0;
+        load_vol0(v0);
+        const bool inside = to_unit(v0.m, v0, w.pos, u);
         if (COUNT) c.n_d++;
         if (COUNT) count_fetch(P, 0, inside);
         if (COLOR && COUNT && is_sample && P.vol0.has_color) c.n_c++;          // the reference looks the colour up here (:1662)
         pd.state = 1;
         if (inside) {
-            issue_f32<A24>(P.vol0.density, P.vol0, make_taps(P.vol0.dim, P.vol0.dimf, u, COUNT ? P.tex_fixed8 : 0), pd);
+            issue_f32<A24>(v0.density, v0, make_taps(v0.dim, v0.dimf, u, COUNT ? P.tex_fixed8 : 0), pd);
             pd.state = 2;
         }
         if (COUNT) coherence_stats<A24>(P, w.pos);
