@@ -1,5 +1,5 @@
 #!/bin/bash
-# claim size study (GPU box): one atomic per VPT_STUDY_CHUNK queue entries, worked through in windows of 256
+# claim size study (GPU box; needs a library built with tools/variants/r04_windowed_claims.patch applied, which reads VPT_STUDY_CHUNK): one atomic per VPT_STUDY_CHUNK queue entries, worked through in windows of 256
 cd $GRAFT_REPO_ROOT
 for ch in ${CHUNKS:-256 1024 4096}; do
   echo "== claim $ch"
