@@ -70,8 +70,11 @@ int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, un
  * view): out[0] per-pixel sky patches, [1] never-traced pixel mask (raygen skips those pixels), [2] sky dome(s), [3] dome variants (1 behind
  * a closed lens, 2 k + 1 behind an open one), [4] camera-point scattering table, [5] view-point ground table(s) bound, [6] resolved samples
  * (the tracer adds a finished path's environment term from the dome, sky_fix_kernel serves the rest, the tail streams 16 + 8 bytes per
- * sample: csrc/vpt_device.h, ResolveParams::lean); [7] reserved */
+ * sample: csrc/vpt_device.h, ResolveParams::lean); [7] the never-traced mask was refined per 8x8-pixel tile by the non-empty octree leaves' screen
+ * bounds (ResolveParams::cull_tiles; not in counting renders, which keep the reference-defined skip counts of the rays it removes) */
 int vpt_test_get_cache_state(vpt_ctx *ctx, int out[8]);
+/* pixels the never-traced mask of the LAST render holds (0 when it had none); synchronises the device */
+int vpt_test_count_never_traced(vpt_ctx *ctx, unsigned long long *pixels);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):
  * 0 on success, VPT_E_IO when the chunk is malformed (message in vpt_io_last_error) */
 int vpt_io_test_blosc_decode(const unsigned char *src, size_t n, unsigned char *dst, size_t nbytes_out);

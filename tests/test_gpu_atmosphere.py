@@ -438,6 +438,60 @@ def test_never_traced_pixels_change_nothing(pkg, sky, monkeypatch, view):
     assert sa.samples == w * h * 4
 
 
+@pytest.mark.parametrize("view", ["default", "1080p", "horizon in view", "sphere in view", "inside the box"])
+def test_leaf_level_never_traced_tiles_change_nothing(pkg, sky, monkeypatch, view):
+    """The never-traced mask refined per 8x8-pixel tile by the screen bounds of the NON-EMPTY octree leaves (ResolveParams::cull_tiles): a ray that only
+    ever crosses empty nodes is pushed out of the root without a draw or a look-up (render_kernel.cu:1606-1616) and, with nothing behind, ends exactly
+    as a ray that misses the box -- raygen walks those pushes per sample; a tile no non-empty leaf can be seen through needs none of it.  Against
+    VPT_NO_LEAF_CULL=1 (the mask from the root box's bounds alone): every buffer bit-identical, the same rays queued, and more pixels skipped.
+    (Counting renders do not refine: they report the reference-defined skip counts of exactly those rays.)"""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    w, h = (1920, 1080) if view == "1080p" else (320, 180)
+    sd = pkg.scene.dragon_scene(w, h, "c2")
+    lib = pkg.load_library()
+    if view == "horizon in view":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(40.0, 3.0, 5.0), Float3(0.0, 3.0, 0.0), Float3(0, 1, 0), 70.0, w / h, 0.0)
+    if view == "sphere in view":
+        o = sd.camera.origin
+        sd.sphere.center = Float3(o.x * 0.55, o.y * 0.55 + 1.0, o.z * 0.55 - 2.0)
+        sd.sphere.radius = 1.5
+    if view == "inside the box":
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(0.3, 0.2, 0.1), Float3(5.0, 1.0, 2.0), Float3(0, 1, 0), 60.0, w / h, 0.0)
+    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int * 8)]
+    lib.vpt_test_count_never_traced.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.render(4); hb.sync()
+        st = (C.c_int * 8)()
+        assert lib.vpt_test_get_cache_state(hb.ctx.h, C.byref(st)) == 0
+        n = C.c_ulonglong(0)
+        assert lib.vpt_test_count_never_traced(hb.ctx.h, C.byref(n)) == 0
+        return hb, hb.ctx.stats(), list(st), n.value
+    a, sa, ca, na = run()
+    monkeypatch.setenv("VPT_NO_LEAF_CULL", "1")
+    b, sb, cb, nb = run()
+    for buf in ("accum", "depth", "raw", "display"):
+        np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy(), err_msg=buf)
+    assert sa.queued_rays == sb.queued_rays and sa.queued_rays > 0
+    assert cb[7] == 0
+    assert ca[1] == 1 and ca[7] == 1, ca
+    assert na >= nb > 0, (na, nb)
+    if view in ("default", "1080p", "sphere in view"):
+        assert na > 1.2 * nb, (na, nb)                        # the dragon fills a fraction of its padded box
+    print("never-traced pixels (%s): %d of %d with the leaf tiles, %d from the root box alone" % (view, na, w * h, nb))
+    # ... and a counting render keeps the root-box mask (and with it the skip counts the oracle reports)
+    monkeypatch.delenv("VPT_NO_LEAF_CULL")
+    hc = pkg.scene.HipBinding(sd, device=0)
+    hc.ctx.set_counting(True)
+    hc.render(4); hc.sync()
+    st = (C.c_int * 8)()
+    assert lib.vpt_test_get_cache_state(hc.ctx.h, C.byref(st)) == 0 and st[7] == 0
+    np.testing.assert_array_equal(hc.accum.cpu().numpy(), a.accum.cpu().numpy())
+
+
 @pytest.mark.parametrize("view", ["default", "horizon in view", "sphere in view", "inside the box", "render off", "chunks"])
 def test_resolved_samples_change_nothing(pkg, sky, monkeypatch, view):
     """With the per-view caches in use behind a closed lens the TRACER adds a finished path's environment term (a sky-dome look-up where ~44

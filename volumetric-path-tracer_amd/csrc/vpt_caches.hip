@@ -132,6 +132,47 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 const double ix1 = std::min((double)W, (double)R.cull_rect[2]), iy1 = std::min((double)H, (double)R.cull_rect[3]);
                 const double inside = std::max(0.0, ix1 - ix0) * std::max(0.0, iy1 - iy0);
                 R.cull_enabled = inside <= 0.7 * (double)W * (double)H ? 1 : 0;
+                // ... and per 8x8 tile inside those bounds: the screen bounds of every NON-EMPTY octree leaf, grown by the same 3 pixels
+                // (ResolveParams::cull_tiles).  A leaf's box is the root's halved three times (divide_bbox, bvh_kernels.cu:150-202); evaluated in
+                // binary64 here, within an ulp of the tracer's binary32 planes -- the margin is five orders of magnitude wider.
+                const uint32_t tw = (W + 7u) / 8u, th = (H + 7u) / 8u;
+                std::vector<unsigned char>& tiles = ctx->cull_tiles_host;
+                tiles.assign((size_t)tw * th, 0);
+                bool refined = !ctx->no_leaf_cull && !ctx->counting;      // (a counting render keeps the skip counts of the rays this removes: the reference walks them)
+                for (int path = 0; path < 512 && refined; ++path) {
+                    if (((ctx->occ[(96 + path) >> 5] >> (path & 31)) & 1u) == 0u) continue;              // occ[3..18]: level-3 occupancy (vpt_device.h)
+                    double lo[3] = {blo[0], blo[1], blo[2]}, hi[3] = {bhi[0], bhi[1], bhi[2]};
+                    for (int level = 0; level < 3; ++level) {
+                        const int c = (path >> (6 - 3 * level)) & 7;
+                        const bool high[3] = {(c & 1) != 0, (c & 2) == 0, (c & 4) != 0};                 // child index: x high, y LOW, z high (locate)
+                        for (int a = 0; a < 3; ++a) {
+                            const double mid = (lo[a] + hi[a]) * 0.5;
+                            if (high[a]) lo[a] = mid; else hi[a] = mid;
+                        }
+                    }
+                    double r[4];
+                    if (!vpt_project_box(cam, lo, hi, (double)W, (double)H, r)) { refined = false; break; }
+                    const long x0 = std::max(0L, (long)std::floor((r[0] - m - 1.0) / 8.0)), y0 = std::max(0L, (long)std::floor((r[1] - m - 1.0) / 8.0));
+                    const long x1 = std::min((long)tw - 1, (long)std::floor((r[2] + m) / 8.0)), y1 = std::min((long)th - 1, (long)std::floor((r[3] + m) / 8.0));
+                    for (long ty = y0; ty <= y1; ++ty)
+                        for (long tx = x0; tx <= x1; ++tx) tiles[(size_t)ty * tw + (size_t)tx] = 1;
+                }
+                if (refined) {
+                    uint32_t h0 = 2166136261u, h1 = 0x9747b28cu;
+                    size_t covered = 0;
+                    for (unsigned char t : tiles) { h0 = (h0 ^ t) * 16777619u; h1 = (h1 ^ (t + 1u)) * 0x01000193u + 0x9e3779b9u; covered += t; }
+                    key.cull_tiles_hash[0] = h0 | 1u; key.cull_tiles_hash[1] = h1;
+                    if (ctx->cull_tiles_bytes < tiles.size()) {
+                        CHK(quiesce(ctx, stream));
+                        (void)hipFree(ctx->d_cull_tiles); ctx->d_cull_tiles = nullptr; ctx->cull_tiles_bytes = 0;
+                        HIPCHK(ctx, hipMalloc(&ctx->d_cull_tiles, tiles.size()));
+                        ctx->cull_tiles_bytes = tiles.size();
+                        ctx->sky_patch_built = false;
+                    }
+                    R.cull_tiles = ctx->d_cull_tiles;
+                    R.cull_tiles_w = tw;
+                    R.cull_enabled = (double)covered <= 0.7 * (double)tiles.size() ? 1 : 0;
+                }
             }
         }
         key.cull_enabled = (float)R.cull_enabled; key.render = (float)R.render;
@@ -158,6 +199,8 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
         ctx->view_seen_valid = true;
         const bool use_caches = built_for_this || iter_count >= 2u || view_repeats;
         if (use_caches && !built_for_this) {
+            if (R.cull_tiles != nullptr)       // (the tile map the mask is built from; the host copy lives in the context until the next build)
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d_cull_tiles, ctx->cull_tiles_host.data(), ctx->cull_tiles_host.size(), hipMemcpyHostToDevice, stream));
             HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, ctx->d_nopatch + 1, ctx->d_nopatch, stream));
             if (!ctx->no_sky_dome) {
                 if (ctx->sky_dome_k < 0) {
@@ -261,6 +304,21 @@ int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
     out[4] = R.cam_tab_valid;
     out[5] = R.dir_tab != nullptr;
     out[6] = R.lean;
+    out[7] = R.never_traced != nullptr && R.cull_tiles != nullptr;
+    return VPT_OK;
+}
+
+int vpt_test_count_never_traced(vpt_ctx* ctx, unsigned long long* pixels) {
+    if (!ctx || !pixels) return VPT_E_INVALID;
+    *pixels = 0;
+    if (!ctx->have_last_resolve || ctx->last_resolve.never_traced == nullptr) return VPT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    std::vector<unsigned char> h(ctx->last_resolve.n_pixels);
+    HIPCHK(ctx, hipMemcpy(h.data(), ctx->last_resolve.never_traced, h.size(), hipMemcpyDeviceToHost));
+    unsigned long long n = 0;
+    for (unsigned char v : h) n += v != 0;
+    *pixels = n;
     return VPT_OK;
 }
 

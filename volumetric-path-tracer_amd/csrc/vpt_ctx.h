@@ -63,6 +63,7 @@ struct ViewKey {
     float ground_table;                    // 0: ground hits in full; 1 + tolerance: through the ground tables
     float cull_enabled, render;            // never-traced pixels: on / off, kernel_params.render
     float cull_rect[4], cull_line[3], cull_sph[4];
+    uint32_t cull_tiles_hash[2];           // FNV-1a of the leaf-level tile map (0, 0: none), i.e. of camera x octree occupancy
 };
 
 struct vpt_ctx {
@@ -141,6 +142,7 @@ struct vpt_ctx {
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)
     bool no_heads = false;                 // VPT_NO_HEADS: every sample gets a 64-byte record (tests)
     bool no_cam_table = false;             // VPT_NO_CAM_TABLE: general sky look-ups only (tests)
+    bool no_leaf_cull = false;             // VPT_NO_LEAF_CULL: the never-traced mask from the root box's bounds alone (tests: same image either way)
     bool tex_fixed8 = false;               // VPT_TEX_WEIGHTS=fixed8: diagnostic model of the CUDA texture unit's 1.8 fixed-point weights (vpt_trace_common.h: make_taps)
     bool no_fast_div = false;              // VPT_NO_FAST_DIV: every look-up divides by the grid extent (tests: both forms give the same bits)
     bool no_dir_table = false;             // VPT_NO_DIR_TABLE: every ground hit evaluated in full (tests)
@@ -156,6 +158,9 @@ struct vpt_ctx {
     bool lens_dome_built = false;              // open lens: domes valid for the current camera-point tables
     bool no_sky_dome = false;                  // VPT_NO_SKY_DOME (tests)
     float4* d_sky_patch = nullptr;
+    unsigned char* d_cull_tiles = nullptr;     // ResolveParams::cull_tiles (8x8-pixel tiles some non-empty octree leaf may be seen through)
+    size_t cull_tiles_bytes = 0;
+    std::vector<unsigned char> cull_tiles_host;
     unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
     size_t sky_patch_pixels = 0;           // capacity, in pixels
     bool sky_patch_built = false;

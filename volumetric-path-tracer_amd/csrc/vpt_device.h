@@ -304,6 +304,12 @@ struct ResolveParams {
     // sample's value from the patch.  cull_enabled = 0: a box corner at or behind the camera plane, the origin on a slab plane, ...
     int cull_enabled;
     float cull_rect[4];              // root box: x0, y0, x1, y1
+    // ... refined per 8x8-pixel TILE inside that rectangle (round 4): a tile no NON-EMPTY octree leaf's grown screen bounds touch holds only rays
+    // that cross empty nodes -- sample() pushes them out of the root without a draw or a look-up (:1606-1616) and, with nothing behind, they end
+    // exactly as rays that miss the box (raygen_kernel walks those pushes: 27 % of config 2's box hits).  cull_tiles[ty * cull_tiles_w + tx] != 0:
+    // some leaf may be met.  NULL: no refinement (a leaf corner at or behind the camera plane).
+    const unsigned char* cull_tiles;
+    uint32_t cull_tiles_w;
     float cull_line[3];
     float cull_sph[4];               // reference sphere: centre, radius
     int render;                      // kernel_params.render (a pixel without heads has to know whether its samples are rendered)

@@ -217,6 +217,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
+    ctx->no_leaf_cull = std::getenv("VPT_NO_LEAF_CULL") != nullptr;
     { const char* tw = std::getenv("VPT_TEX_WEIGHTS"); ctx->tex_fixed8 = tw != nullptr && std::strcmp(tw, "fixed8") == 0; }
     if (ctx->tex_fixed8) ctx->counting = true;       // a diagnostic: carried by the counting instantiations of the tracers only (make_taps)
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
@@ -265,6 +266,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_sky_patch);
     (void)hipFree(ctx->d_sky_dome);
     (void)hipFree(ctx->d_never_traced);
+    (void)hipFree(ctx->d_cull_tiles);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);

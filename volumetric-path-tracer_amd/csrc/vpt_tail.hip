@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void sky_patch_kernel(const ResolveParams R, f
     if (never) {
         bool nt = ok && R.cull_enabled != 0;
         const float fx = (float)x, fy = (float)y;
-        if (fx + 1.0f >= R.cull_rect[0] && fx <= R.cull_rect[2] && fy + 1.0f >= R.cull_rect[1] && fy <= R.cull_rect[3]) nt = false;
+        if (fx + 1.0f >= R.cull_rect[0] && fx <= R.cull_rect[2] && fy + 1.0f >= R.cull_rect[1] && fy <= R.cull_rect[3]) {
+            // inside the root box's bounds: traced unless no non-empty leaf's bounds touch the pixel's tile (ResolveParams::cull_tiles)
+            if (R.cull_tiles == nullptr || R.cull_tiles[(y >> 3) * R.cull_tiles_w + (x >> 3)] != 0) nt = false;
+        }
         if (sphere_may_hit(org, dc, diag, R.cull_sph)) nt = false;
         const float la = R.cull_line[0], lb = R.cull_line[1], lc = R.cull_line[2];
         const float ln = la * la + lb * lb;
