@@ -137,9 +137,18 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 // binary64 here, within an ulp of the tracer's binary32 planes -- the margin is five orders of magnitude wider.
                 const uint32_t tw = (W + 7u) / 8u, th = (H + 7u) / 8u;
                 std::vector<unsigned char>& tiles = ctx->cull_tiles_host;
-                tiles.assign((size_t)tw * th, 0);
                 bool refined = !ctx->no_leaf_cull && !ctx->counting;      // (a counting render keeps the skip counts of the rays this removes: the reference walks them)
-                for (int path = 0; path < 512 && refined; ++path) {
+                // the map is a function of the camera, the image size and the octree: a frame loop that changes none of them (one call per iteration,
+                // main.cpp:1822-1829) must not pay ~0.1 ms of host time per call for it
+                float in[9 + 3 + 6 + 2 + 19];
+                std::memcpy(in, frame, sizeof(frame));
+                in[9] = cam->origin.x; in[10] = cam->origin.y; in[11] = cam->origin.z;
+                for (int i = 0; i < 3; ++i) { in[12 + i] = P.root_pmin[i]; in[15 + i] = P.root_pmax[i]; }
+                in[18] = (float)W; in[19] = (float)H;
+                std::memcpy(in + 20, ctx->occ, sizeof(uint32_t) * 19);
+                const bool reuse = refined && ctx->cull_tiles_inputs_valid && std::memcmp(in, ctx->cull_tiles_inputs, sizeof(in)) == 0;
+                if (refined && !reuse) tiles.assign((size_t)tw * th, 0);
+                for (int path = 0; path < 512 && refined && !reuse; ++path) {
                     if (((ctx->occ[(96 + path) >> 5] >> (path & 31)) & 1u) == 0u) continue;              // occ[3..18]: level-3 occupancy (vpt_device.h)
                     double lo[3] = {blo[0], blo[1], blo[2]}, hi[3] = {bhi[0], bhi[1], bhi[2]};
                     for (int level = 0; level < 3; ++level) {
@@ -157,11 +166,18 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                     for (long ty = y0; ty <= y1; ++ty)
                         for (long tx = x0; tx <= x1; ++tx) tiles[(size_t)ty * tw + (size_t)tx] = 1;
                 }
-                if (refined) {
+                if (refined && !reuse) {
                     uint32_t h0 = 2166136261u, h1 = 0x9747b28cu;
                     size_t covered = 0;
                     for (unsigned char t : tiles) { h0 = (h0 ^ t) * 16777619u; h1 = (h1 ^ (t + 1u)) * 0x01000193u + 0x9e3779b9u; covered += t; }
-                    key.cull_tiles_hash[0] = h0 | 1u; key.cull_tiles_hash[1] = h1;
+                    ctx->cull_tiles_hash[0] = h0 | 1u; ctx->cull_tiles_hash[1] = h1; ctx->cull_tiles_covered = covered;
+                    std::memcpy(ctx->cull_tiles_inputs, in, sizeof(in));
+                    ctx->cull_tiles_inputs_valid = true;
+                }
+                if (!refined && !ctx->no_leaf_cull && !ctx->counting) ctx->cull_tiles_inputs_valid = false;       // (a leaf behind the camera plane: nothing to reuse)
+                if (refined) {
+                    const size_t covered = ctx->cull_tiles_covered;
+                    key.cull_tiles_hash[0] = ctx->cull_tiles_hash[0]; key.cull_tiles_hash[1] = ctx->cull_tiles_hash[1];
                     if (ctx->cull_tiles_bytes < tiles.size()) {
                         CHK(quiesce(ctx, stream));
                         (void)hipFree(ctx->d_cull_tiles); ctx->d_cull_tiles = nullptr; ctx->cull_tiles_bytes = 0;

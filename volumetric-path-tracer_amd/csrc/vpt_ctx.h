@@ -161,6 +161,10 @@ struct vpt_ctx {
     unsigned char* d_cull_tiles = nullptr;     // ResolveParams::cull_tiles (8x8-pixel tiles some non-empty octree leaf may be seen through)
     size_t cull_tiles_bytes = 0;
     std::vector<unsigned char> cull_tiles_host;
+    float cull_tiles_inputs[9 + 3 + 6 + 2 + 19] = {};   // what the host map was built from (camera frame + origin, root box, image size, occupancy words)
+    bool cull_tiles_inputs_valid = false;
+    uint32_t cull_tiles_hash[2] = {0, 0};
+    size_t cull_tiles_covered = 0;
     unsigned char* d_never_traced = nullptr;   // per pixel: raygen emits nothing, the tail has the values (ResolveParams::never_traced)
     size_t sky_patch_pixels = 0;           // capacity, in pixels
     bool sky_patch_built = false;
