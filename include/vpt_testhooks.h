@@ -73,6 +73,12 @@ int vpt_test_get_sky_patch_coverage(vpt_ctx *ctx, unsigned long long *pixels, un
  * sample: csrc/vpt_device.h, ResolveParams::lean); [7] the never-traced mask was refined per 8x8-pixel tile by the non-empty octree leaves' screen
  * bounds (ResolveParams::cull_tiles; not in counting renders, which keep the reference-defined skip counts of the rays it removes) */
 int vpt_test_get_cache_state(vpt_ctx *ctx, int out[8]);
+/* the 8x8-pixel tiles ((width + 7) / 8 per row, (height + 7) / 8 rows, one byte each) through which some NON-EMPTY leaf of the octree over
+ * [root_lo, root_hi] may be seen by the closed-lens camera -- every leaf whose bit is set in occ[3..18] (path = 64 c1 + 8 c2 + c3, child index
+ * c = x high | y LOW << 1 | z high << 2: TraceParams::occ), its box projected and grown by `margin` pixels; what the renderer refines its
+ * never-traced mask with (csrc/vpt_caches.hip: build_leaf_tiles).  Host only.  VPT_E_UNSUPPORTED: a leaf corner at or behind the camera plane. */
+int vpt_test_leaf_tiles(const vpt_camera *cam, const float root_lo[3], const float root_hi[3], const unsigned int occ[19], int width, int height,
+                        float margin, unsigned char *tiles);
 /* pixels the never-traced mask of the LAST render holds (0 when it had none); synchronises the device */
 int vpt_test_count_never_traced(vpt_ctx *ctx, unsigned long long *pixels);
 /* one c-blosc chunk (the compressed-buffer framing OpenVDB >= 224 writes) through the reader's own decoder (csrc/vpt_io.hip):

@@ -33,6 +33,36 @@ int quiesce(vpt_ctx* ctx, hipStream_t stream) {
 bool same_tables(const ViewKey& a, const ViewKey& b) { return std::memcmp(&a.tables, &b.tables, sizeof(a.tables)) == 0; }
 bool same_view(const ViewKey& a, const ViewKey& b) { return std::memcmp(&a, &b, sizeof(ViewKey)) == 0; }
 
+// The tiles (8x8 pixels) some NON-EMPTY octree leaf may be seen through: every such leaf's box -- the root's halved three times (divide_bbox,
+// bvh_kernels.cu:150-202; child index: x high, y LOW, z high, as locate has it), in binary64, within an ulp of the tracer's binary32 planes --
+// projected like the root (vpt_project_box) and grown by `margin` pixels.  false: a leaf corner at or behind the camera plane (no bound).
+// occ: the 19 occupancy words of TraceParams::occ ([3..18]: level 3, bit = path).
+bool build_leaf_tiles(const vpt_camera* cam, const double blo[3], const double bhi[3], const uint32_t* occ, uint32_t W, uint32_t H, double margin,
+                      std::vector<unsigned char>& tiles) {
+    const uint32_t tw = (W + 7u) / 8u, th = (H + 7u) / 8u;
+    tiles.assign((size_t)tw * th, 0);
+    for (int path = 0; path < 512; ++path) {
+        if (((occ[(96 + path) >> 5] >> (path & 31)) & 1u) == 0u) continue;
+        double lo[3] = {blo[0], blo[1], blo[2]}, hi[3] = {bhi[0], bhi[1], bhi[2]};
+        for (int level = 0; level < 3; ++level) {
+            const int c = (path >> (6 - 3 * level)) & 7;
+            const bool high[3] = {(c & 1) != 0, (c & 2) == 0, (c & 4) != 0};
+            for (int a = 0; a < 3; ++a) {
+                const double mid = (lo[a] + hi[a]) * 0.5;
+                if (high[a]) lo[a] = mid; else hi[a] = mid;
+            }
+        }
+        double r[4];
+        if (!vpt_project_box(cam, lo, hi, (double)W, (double)H, r)) return false;
+        // a tile [8 t, 8 t + 8] meets [r0 - margin, r2 + margin]: t >= (r0 - margin) / 8 - 1, rounded DOWN once more where it is not an integer
+        const long x0 = std::max(0L, (long)std::floor((r[0] - margin - 1.0) / 8.0)), y0 = std::max(0L, (long)std::floor((r[1] - margin - 1.0) / 8.0));
+        const long x1 = std::min((long)tw - 1, (long)std::floor((r[2] + margin) / 8.0)), y1 = std::min((long)th - 1, (long)std::floor((r[3] + margin) / 8.0));
+        for (long ty = y0; ty <= y1; ++ty)
+            for (long tx = x0; tx <= x1; ++tx) tiles[(size_t)ty * tw + (size_t)tx] = 1;
+    }
+    return true;
+}
+
 }  // namespace
 
 int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_sphere* ref_sphere, const vpt_kernel_params* kp, bool compact,
@@ -133,8 +163,7 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 const double inside = std::max(0.0, ix1 - ix0) * std::max(0.0, iy1 - iy0);
                 R.cull_enabled = inside <= 0.7 * (double)W * (double)H ? 1 : 0;
                 // ... and per 8x8 tile inside those bounds: the screen bounds of every NON-EMPTY octree leaf, grown by the same 3 pixels
-                // (ResolveParams::cull_tiles).  A leaf's box is the root's halved three times (divide_bbox, bvh_kernels.cu:150-202); evaluated in
-                // binary64 here, within an ulp of the tracer's binary32 planes -- the margin is five orders of magnitude wider.
+                // (ResolveParams::cull_tiles, build_leaf_tiles above)
                 const uint32_t tw = (W + 7u) / 8u, th = (H + 7u) / 8u;
                 std::vector<unsigned char>& tiles = ctx->cull_tiles_host;
                 bool refined = !ctx->no_leaf_cull && !ctx->counting;      // (a counting render keeps the skip counts of the rays this removes: the reference walks them)
@@ -147,25 +176,7 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 in[18] = (float)W; in[19] = (float)H;
                 std::memcpy(in + 20, ctx->occ, sizeof(uint32_t) * 19);
                 const bool reuse = refined && ctx->cull_tiles_inputs_valid && std::memcmp(in, ctx->cull_tiles_inputs, sizeof(in)) == 0;
-                if (refined && !reuse) tiles.assign((size_t)tw * th, 0);
-                for (int path = 0; path < 512 && refined && !reuse; ++path) {
-                    if (((ctx->occ[(96 + path) >> 5] >> (path & 31)) & 1u) == 0u) continue;              // occ[3..18]: level-3 occupancy (vpt_device.h)
-                    double lo[3] = {blo[0], blo[1], blo[2]}, hi[3] = {bhi[0], bhi[1], bhi[2]};
-                    for (int level = 0; level < 3; ++level) {
-                        const int c = (path >> (6 - 3 * level)) & 7;
-                        const bool high[3] = {(c & 1) != 0, (c & 2) == 0, (c & 4) != 0};                 // child index: x high, y LOW, z high (locate)
-                        for (int a = 0; a < 3; ++a) {
-                            const double mid = (lo[a] + hi[a]) * 0.5;
-                            if (high[a]) lo[a] = mid; else hi[a] = mid;
-                        }
-                    }
-                    double r[4];
-                    if (!vpt_project_box(cam, lo, hi, (double)W, (double)H, r)) { refined = false; break; }
-                    const long x0 = std::max(0L, (long)std::floor((r[0] - m - 1.0) / 8.0)), y0 = std::max(0L, (long)std::floor((r[1] - m - 1.0) / 8.0));
-                    const long x1 = std::min((long)tw - 1, (long)std::floor((r[2] + m) / 8.0)), y1 = std::min((long)th - 1, (long)std::floor((r[3] + m) / 8.0));
-                    for (long ty = y0; ty <= y1; ++ty)
-                        for (long tx = x0; tx <= x1; ++tx) tiles[(size_t)ty * tw + (size_t)tx] = 1;
-                }
+                if (refined && !reuse) refined = build_leaf_tiles(cam, blo, bhi, ctx->occ, W, H, m, tiles);
                 if (refined && !reuse) {
                     uint32_t h0 = 2166136261u, h1 = 0x9747b28cu;
                     size_t covered = 0;
@@ -321,6 +332,16 @@ int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
     out[5] = R.dir_tab != nullptr;
     out[6] = R.lean;
     out[7] = R.never_traced != nullptr && R.cull_tiles != nullptr;
+    return VPT_OK;
+}
+
+int vpt_test_leaf_tiles(const vpt_camera* cam, const float root_lo[3], const float root_hi[3], const unsigned int occ[19], int width, int height,
+                        float margin, unsigned char* tiles) {
+    if (!cam || !root_lo || !root_hi || !occ || !tiles || width <= 0 || height <= 0) return VPT_E_INVALID;
+    const double lo[3] = {root_lo[0], root_lo[1], root_lo[2]}, hi[3] = {root_hi[0], root_hi[1], root_hi[2]};
+    std::vector<unsigned char> t;
+    if (!build_leaf_tiles(cam, lo, hi, occ, (uint32_t)width, (uint32_t)height, (double)margin, t)) return VPT_E_UNSUPPORTED;
+    std::memcpy(tiles, t.data(), t.size());
     return VPT_OK;
 }
 
