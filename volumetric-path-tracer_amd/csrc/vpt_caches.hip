@@ -176,7 +176,13 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 in[18] = (float)W; in[19] = (float)H;
                 std::memcpy(in + 20, ctx->occ, sizeof(uint32_t) * 19);
                 const bool reuse = refined && ctx->cull_tiles_inputs_valid && std::memcmp(in, ctx->cull_tiles_inputs, sizeof(in)) == 0;
-                if (refined && !reuse) refined = build_leaf_tiles(cam, blo, bhi, ctx->occ, W, H, m, tiles);
+                if (refined && !reuse) {
+                    if (ctx->cull_tiles_copy_pending) {           // (an upload of the previous map may still be queued: it reads this very buffer)
+                        HIPCHK(ctx, hipEventSynchronize(ctx->cull_tiles_copied));
+                        ctx->cull_tiles_copy_pending = false;
+                    }
+                    refined = build_leaf_tiles(cam, blo, bhi, ctx->occ, W, H, m, tiles);
+                }
                 if (refined && !reuse) {
                     uint32_t h0 = 2166136261u, h1 = 0x9747b28cu;
                     size_t covered = 0;
@@ -227,7 +233,12 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
         const bool use_caches = built_for_this || iter_count >= 2u || view_repeats;
         if (use_caches && !built_for_this) {
             if (R.cull_tiles != nullptr)       // (the tile map the mask is built from; the host copy lives in the context until the next build)
+            {
                 HIPCHK(ctx, hipMemcpyAsync(ctx->d_cull_tiles, ctx->cull_tiles_host.data(), ctx->cull_tiles_host.size(), hipMemcpyHostToDevice, stream));
+                if (!ctx->cull_tiles_copied) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cull_tiles_copied, hipEventDisableTiming));
+                HIPCHK(ctx, hipEventRecord(ctx->cull_tiles_copied, stream));
+                ctx->cull_tiles_copy_pending = true;
+            }
             HIPCHK(ctx, launch_sky_patch(R, ctx->d_sky_patch, ctx->d_never_traced, ctx->d_nopatch + 1, ctx->d_nopatch, stream));
             if (!ctx->no_sky_dome) {
                 if (ctx->sky_dome_k < 0) {

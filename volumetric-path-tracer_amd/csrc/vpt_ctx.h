@@ -161,6 +161,8 @@ struct vpt_ctx {
     unsigned char* d_cull_tiles = nullptr;     // ResolveParams::cull_tiles (8x8-pixel tiles some non-empty octree leaf may be seen through)
     size_t cull_tiles_bytes = 0;
     std::vector<unsigned char> cull_tiles_host;
+    hipEvent_t cull_tiles_copied = nullptr;    // recorded behind the map's upload: the host copy is not rewritten before it has been read
+    bool cull_tiles_copy_pending = false;
     float cull_tiles_inputs[9 + 3 + 6 + 2 + 19] = {};   // what the host map was built from (camera frame + origin, root box, image size, occupancy words)
     bool cull_tiles_inputs_valid = false;
     uint32_t cull_tiles_hash[2] = {0, 0};

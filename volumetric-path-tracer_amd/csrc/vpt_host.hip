@@ -267,6 +267,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_sky_dome);
     (void)hipFree(ctx->d_never_traced);
     (void)hipFree(ctx->d_cull_tiles);
+    if (ctx->cull_tiles_copied) (void)hipEventDestroy(ctx->cull_tiles_copied);
     (void)hipFree(ctx->d_vdc);
     (void)hipFree(ctx->d_bn_table);
     (void)hipFree(ctx->d_work_counter);
