@@ -280,13 +280,7 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 std::memset(&rt, 0, sizeof(rt));
                 rt.sky_dome = R.sky_dome; rt.heads = ctx->d_heads; rt.td = ctx->d_td; rt.queue2 = ctx->d_queue2; rt.queue2_tail = ctx->d_work_counter + 4;
                 rt.cam_origin[0] = cam->origin.x; rt.cam_origin[1] = cam->origin.y; rt.cam_origin[2] = cam->origin.z;
-                if (!ctx->d_resolve) HIPCHK(ctx, hipMalloc(&ctx->d_resolve, sizeof(ResolveInTracer)));
-                if (std::memcmp(&rt, &ctx->resolve_host, sizeof(rt)) != 0) {
-                    // (kernels of an earlier render may still read the block: the copy is ordered behind them on the stream)
-                    ctx->resolve_host = rt;
-                    HIPCHK(ctx, hipMemcpyAsync(ctx->d_resolve, &ctx->resolve_host, sizeof(rt), hipMemcpyHostToDevice, stream));
-                }
-                P.resolve = ctx->d_resolve;
+                P.resolve = rt;                     // by value, in the kernel-argument segment (no upload, nothing a later render could overwrite)
             }
         }
     }

@@ -140,7 +140,7 @@ struct Counters {
 #define VPT_SUB3 (VPT_SUB * VPT_SUB * VPT_SUB)
 
 struct ResolveInTracer {
-    const float4* sky_dome;          // ResolveParams::sky_dome
+    const float4* sky_dome;          // ResolveParams::sky_dome; NULL: off (every finished path writes its 64-byte record, the tail adds the environment)
     float4* heads;                   // == TraceParams::heads
     float2* td;                      // [iter_count][n_pixels] {alpha, depth} of the resolved samples
     uint32_t* queue2;                // record slots whose environment term needs the full evaluation
@@ -178,9 +178,11 @@ struct TraceParams {
     // finished path's environment term -- a sky-dome look-up along its exit direction, at the ~44 lanes a transition pass finishes together --
     // and writes the sample as a 16-byte head {value, -1} + 8 bytes {alpha, depth} instead of a 64-byte path record; a path the dome cannot
     // serve (a flagged cell, an origin moved by the sphere bounce) keeps its record and its slot goes into queue2 for sky_fix_kernel.
-    // What that takes sits behind ONE pointer to device memory (the tracer keeps 100 scalars live across its loop as it is; these are
-    // read where a batch of paths finishes, not carried).
-    const struct ResolveInTracer* resolve;   // or NULL: every finished path writes its 64-byte record (the tail adds the environment)
+    // What that takes travels BY VALUE in the kernel-argument segment and is read where a batch of paths finishes (load_resolve, vpt_trace_common.h:
+    // scalar loads through the laundered segment pointer, like ColdConst -- not carried in the loop's live scalars).  Round 5: it sat behind a pointer
+    // to device memory before, uploaded from pageable host memory per view change (a hidden host synchronisation for a moving camera), and the
+    // finishing lanes read its fields with five dependent VECTOR loads.
+    struct ResolveInTracer resolve;
     float* pool_hist;                // pool tracer (vpt_trace_pool.hip): density histories of the fused first walk, [workgroup][entry][ray]
     const float* vdc_tables;         // [2][101]: van der Corput radical inverses, bases 2 and 3
     // camera

@@ -15,6 +15,13 @@ VPT_D float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 VPT_D float flerp(float a, float b, float t) { return ffma(t, b - a, a); }
 VPT_D f3 flerp3(f3 a, f3 b, float t) { return mk3(flerp(a.x, b.x, t), flerp(a.y, b.y, t), flerp(a.z, b.z, t)); }
 VPT_D f3 fscale_add3(f3 a, float s, f3 b) { return mk3(ffma(a.x, s, b.x), ffma(a.y, s, b.y), ffma(a.z, s, b.z)); }
+// CORRECTLY ROUNDED binary32 root / quotient whatever the translation unit's flags (vpt_tail.hip is built with the approximate ones): through
+// binary64, whose 53 bits make the second rounding innocuous for sqrt and / of binary32 operands (2 x 24 + 2 <= 53).  For the GEOMETRY of a ground hit
+// only (vpt_sky.h: sample, SkyRadianceToPoint, GroundFromTable): there one ulp of a root decides which 0.5 m step of the earth's radius a point lands on.
+VPT_D float sqrt_rn(float x) { return (float)__builtin_sqrt((double)x); }
+VPT_D float div_rn(float a, float b) { return (float)((double)a / (double)b); }
+VPT_D float length_rn(f3 v) { return sqrt_rn(dot(v, v)); }
+VPT_D f3 normalize_rn(f3 v) { const float inv = div_rn(1.0f, sqrt_rn(dot(v, v))); return v * inv; }      // helper_math.h:1336, as the strict side forms it
 
 // ---- sky dome (ResolveParams::sky_dome) ------------------------------------------------------------------------------------------
 // direction <-> dome coordinates: v = dir.y in [-1, 1] (rows), u in [0, 4) the L1 azimuth in the xz plane: t = x / (|x| + |z|),

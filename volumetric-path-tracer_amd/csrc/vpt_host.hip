@@ -259,7 +259,6 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_td);
     (void)hipFree(ctx->d_queue2);
     (void)hipFree(ctx->d_nopatch);
-    (void)hipFree(ctx->d_resolve);
     (void)hipFree(ctx->d_head_org);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_pool_hist);

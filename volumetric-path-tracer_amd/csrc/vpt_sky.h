@@ -274,7 +274,7 @@ struct Sky {
     }
     // want_tr: the transmittance is only read for rays inside the sun's disc (sample()); its table look-up is skipped otherwise
     VPT_D f3 SkyRadiance(f3 camera, f3 view_ray, f3 sun_direction, f3& transmittance, int cv, bool want_tr) const {   // :694 (shadow_length = 0)
-        float r = length(camera);
+        float r = length_rn(camera);                       // (the r the table variant `cv` was picked by: sample())
         float rmu = dot(camera, view_ray);
         const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
         if (dtop > 0.0f) {
@@ -300,21 +300,25 @@ struct Sky {
         return sky;
     }
     VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, int cv) const {   // :749 (shadow_length = 0)
+        // GEOMETRY in the reference's own operations, correctly rounded (round 5): the view ray, r, mu and d feed r_p below and the binary32
+        // discriminant (r mu)^2 - r^2 + bottom^2 of the scattering row -- both staircases in which one ulp of a root or a quotient is 0.5 m of
+        // radius = 2.5 km of rho, up to 2 % of the radiance next to the horizon.  With them formed as the strict side forms them the ground
+        // hits of the two sides land on the same steps (per-pixel outliers against the oracle: see profiles/r05_c5_p99.txt).
         const f3 delta = point - camera;
-        float d = length(delta);
-        const f3 view_ray = delta * frcp(d);
-        float r = length(camera);
+        const f3 view_ray = normalize_rn(delta);
+        float d = length_rn(delta);
+        float r = length_rn(camera);
         float rmu = dot(camera, view_ray);
-        const float dtop = -rmu - fsqrt(rmu * rmu - r * r + top() * top());
+        const float dtop = -rmu - sqrt_rn(rmu * rmu - r * r + top() * top());
         if (dtop > 0.0f) {
             camera = camera + view_ray * dtop;
             r = top();
             rmu += dtop;
-            d = length(point - camera);
+            d = length_rn(point - camera);
             cv = -1;
         }
         const float inv_r = frcp(r);
-        const float mu = rmu * inv_r;
+        const float mu = div_rn(rmu, r);
         const float mu_s = dot(camera, sun_direction) * inv_r;
         const float nu = dot(view_ray, sun_direction);
         const bool ground = HitsGround(r, mu);
@@ -416,10 +420,9 @@ struct Sky {
     // false (evaluate in full) for everything else.
     VPT_D bool GroundFromTable(f3 p, float r, float mu_s, f3 pt, f3 sun_direction, int cv, f3& radiance) const {
         const f3 delta = pt - p;
-        const float dist = length(delta);
-        const f3 view_ray = delta * frcp(dist);
-        const float inv_r = frcp(r);
-        const float mu = dot(p, view_ray) * inv_r;
+        const float dist = length_rn(delta);
+        const f3 view_ray = normalize_rn(delta);                                     // (geometry correctly rounded: SkyRadianceToPoint)
+        const float mu = div_rn(dot(p, view_ray), r);
         const float4 vt = view_multi ? R.sky_view->tab[cv] : view_vt0;               // 1 / d_min, 1 / log2(d_max / d_min), x_use, has a table
         const float fx = __builtin_amdgcn_logf(dist * vt.x) * vt.y;
         // (within x_use |mu| is at least 1.6 times the horizon's: the double-precision ground test of :401 holds)
@@ -447,7 +450,7 @@ struct Sky {
         const float p_dot_v = dot(p, ray_dir);
         const float p_dot_p = dot(p, p);
         const float d2 = p_dot_p - p_dot_v * p_dot_v;
-        const float dist = -p_dot_v - fsqrt(earth_center.y * earth_center.y - d2);
+        const float dist = -p_dot_v - sqrt_rn(earth_center.y * earth_center.y - d2);      // (correctly rounded: one ulp of this root moves the ground point 0.5 m along the ray)
         f3 radiance;
         int cv = -1;
         float r_view = 0.0f, mu_s_view = 0.0f;
@@ -459,7 +462,7 @@ struct Sky {
                 mu_s_view = view_mu_s;
             }
         } else if (view_k >= 0) {
-            r_view = length(p);
+            r_view = length_rn(p);                                                    // (its binary32 value picks the table variant)
             mu_s_view = dot(p, sun_direction) * frcp(r_view);
             cv = CamVariant(r_view, mu_s_view);
         }
@@ -469,7 +472,7 @@ struct Sky {
         } else if (dist > 0.0f) {
             if (kind) *kind = 2;
             const f3 pt = ray_pos + ray_dir * dist - earth_center;
-            const float r = length(pt);
+            const float r = length_rn(pt);
             const float inv_r = frcp(r);
             const f3 normal = pt * inv_r;
             const float mu_s = dot(pt, sun_direction) * inv_r;

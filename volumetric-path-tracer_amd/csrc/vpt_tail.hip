@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void sky_dome_kernel(const ResolveParams R, co
         const f3 up0 = normalize(org - ec);
         org = org + up0 * (__uint_as_float(__float_as_uint(view->r) + variant - (uint32_t)kv) - view->r);
         const f3 p = org - ec;
-        const float r = length(p);
+        const float r = length_rn(p);
         variant_ok = sky.CamVariant(r, dot(p, sun_dir) * frcp(r)) == (int)variant;       // (the displaced origin did land on this variant's r)
     }
     const f3 scale = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]) * R.sky_mult;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                             dcv = (env_pos.x == R.cam_origin[0] && env_pos.y == R.cam_origin[1] && env_pos.z == R.cam_origin[2]) ? 0 : -1;
                         } else {
                             const f3 pe = env_pos - mk3(0.0f, -sky.bottom(), 0.0f);
-                            const float re = length(pe);
+                            const float re = length_rn(pe);
                             dcv = sky.CamVariant(re, dot(pe, sun_dir) * frcp(re));
                         }
                     }
@@ -535,7 +535,7 @@ __global__ void sky_view_kernel(const ResolveParams R, SkyView* out, int k) {
     const int v = (int)threadIdx.x;
     const S sky = {R};
     const f3 p = mk3(R.cam_tab_pos[0], R.cam_tab_pos[1] + sky.bottom(), R.cam_tab_pos[2]);       // view point - earth centre
-    const float r0 = length(p);
+    const float r0 = length_rn(p);                       // (correctly rounded, like every r the ground geometry of vpt_sky.h forms)
     if (v == 0) {
         out->r = r0;
         out->mu_s = dot(p, mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2])) * frcp(r0);
@@ -659,7 +659,7 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
         pos = pos + (t1 * __builtin_cosf(th) + t2 * __builtin_sinf(th)) * rho;
     }
     const f3 p = pos - ec;
-    const float r = length(p);
+    const float r = length_rn(p);
     int cv = 0;
     if (LENS) {
         cv = sky.CamVariant(r, dot(p, sun) * frcp(r));

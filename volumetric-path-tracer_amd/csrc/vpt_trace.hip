@@ -697,13 +697,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 // RESOLVED SAMPLES (TraceParams::resolve): what the tail would add to L -- beta x the sky along the exit direction, seen from the
                 // camera origin -- is a dome look-up, done here where ~44 lanes finish together; the sample then leaves as 24 bytes instead of 64.
                 bool resolved = false;
-                const ResolveInTracer* rt = C.resolve;       // (its fields are fetched here, per batch of finishing paths, not held in the loop's live scalars)
-                if (rt != nullptr) {
+                const ResolveInTracer rt = load_resolve();   // (its fields are fetched here, per batch of finishing paths, not held in the loop's live scalars)
+                const bool resolving = rt.sky_dome != nullptr;
+                if (resolving) {
                     f3 dv;
-                    if (oe.x == rt->cam_origin[0] && oe.y == rt->cam_origin[1] && oe.z == rt->cam_origin[2] && dome_lookup(rt->sky_dome, od, dv)) {
+                    if (oe.x == rt.cam_origin[0] && oe.y == rt.cam_origin[1] && oe.z == rt.cam_origin[2] && dome_lookup(rt.sky_dome, od, dv)) {
                         const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
-                        rt->heads[slot] = make_float4(val.x, val.y, val.z, -1.0f);
-                        rt->td[slot] = make_float2(fmin_(w.alpha, 1.0f), depth);
+                        rt.heads[slot] = make_float4(val.x, val.y, val.z, -1.0f);
+                        rt.td[slot] = make_float2(fmin_(w.alpha, 1.0f), depth);
                         resolved = true;
                     }
                 }
@@ -713,14 +714,14 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
                     dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
                     dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
-                    if (rt != nullptr) {
+                    if (resolving) {
                         // the full evaluation is sky_fix_kernel's (vpt_tail.hip): one queue entry per such path, one atomic per wave
                         const unsigned long long qm = __ballot(1);
                         const int ql = __ffsll((long long)qm) - 1;
                         uint32_t qb = 0;
-                        if (lane == ql) qb = atomicAdd(rt->queue2_tail, (uint32_t)__popcll(qm));
+                        if (lane == ql) qb = atomicAdd(rt.queue2_tail, (uint32_t)__popcll(qm));
                         qb = (uint32_t)__shfl((int)qb, ql);
-                        rt->queue2[qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+                        rt.queue2[qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (uint32_t)slot;
                     }
                 }
                 if (COUNT) {

@@ -139,7 +139,6 @@ struct ColdConst {
     const DPointLight* lights;
     uint32_t n_pixels, iter_begin, iter_stride;
     Record* records;
-    const ResolveInTracer* resolve;
 };
 VPT_D ColdConst load_cold_const() {
     KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();       // the TraceParams is the kernel's only argument: offset 0 of the segment
@@ -156,8 +155,18 @@ VPT_D ColdConst load_cold_const() {
     c.lights = k->lights;
     c.n_pixels = k->n_pixels; c.iter_begin = k->iter_begin; c.iter_stride = k->iter_stride;
     c.records = k->records;
-    c.resolve = k->resolve;
     return c;
+}
+// TraceParams::resolve for one batch of finishing paths (PH_T_FINISH): 13 dwords from the kernel-argument segment
+VPT_D ResolveInTracer load_resolve() {
+    KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    ResolveInTracer r;
+    r.sky_dome = k->resolve.sky_dome; r.heads = k->resolve.heads; r.td = k->resolve.td;
+    r.queue2 = k->resolve.queue2; r.queue2_tail = k->resolve.queue2_tail;
+    r.cam_origin[0] = k->resolve.cam_origin[0]; r.cam_origin[1] = k->resolve.cam_origin[1]; r.cam_origin[2] = k->resolve.cam_origin[2];
+    r.pad_ = 0.0f;
+    return r;
 }
 
 // The single-volume descriptor (TraceParams::vol0) for ONE look-up: ~35 dwords that would otherwise want scalar registers through the whole launch next
