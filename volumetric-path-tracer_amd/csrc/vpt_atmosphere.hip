@@ -38,6 +38,8 @@
 #include "../../include/vpt_abi.h"
 #include "vpt_math.h"
 
+void vpt_set_error(vpt_ctx* ctx, const char* fmt, ...);        // vpt_host.hip (C++ linkage, as vpt_ctx.h declares it)
+
 using namespace vpt;
 
 namespace {
@@ -700,9 +702,31 @@ static int precompute_textures(vpt_ctx* ctx, vpt_atmosphere_parameters* p) {
     return VPT_OK;
 }
 
+// `p` is IN/OUT for its nine device buffers and four texture handles (a repeated call refills what it holds): a struct that was never
+// zeroed would have the passes write through garbage pointers.  Every non-NULL buffer must be device memory -- anything else is refused
+// before a byte is written.  (A stale or garbage texture HANDLE is harmless: vpt_texture_destroy refuses what is not a live handle of
+// this context, and the handles are re-created over the buffers either way.)
+static int check_atmosphere_inout(vpt_ctx* ctx, const vpt_atmosphere_parameters* p, const char* who) {
+    const void* bufs[9] = {p->delta_irradience_buffer, p->delta_rayleigh_scattering_buffer, p->delta_mie_scattering_buffer,
+                           p->delta_scattering_density_buffer, p->delta_multiple_scattering_buffer, p->transmittance_buffer,
+                           p->irradiance_buffer, p->scattering_buffer, p->optional_mie_single_scattering_buffer};
+    for (const void* b : bufs) {
+        if (!b) continue;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, b) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            vpt_set_error(ctx, "%s: the atmosphere struct holds a buffer pointer that is not device memory -- zero the struct before the first call "
+                               "(its nine buffers and four texture handles are IN/OUT: a repeated call refills them)", who);
+            return VPT_E_INVALID;
+        }
+    }
+    return VPT_OK;
+}
+
 int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int num_scattering_orders, void* stream_v) {
     if (!ctx || !p) return VPT_E_INVALID;
     if (p->use_luminance == 2) return VPT_E_INVALID;         // PRECOMPUTED needs the model's spectra per pass: vpt_atmosphere_precompute_model
+    { const int rc0 = check_atmosphere_inout(ctx, p, "vpt_atmosphere_precompute"); if (rc0 != VPT_OK) return rc0; }
     if (num_scattering_orders < 1) num_scattering_orders = 4;
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
     vpt_invalidate_sky_tables(ctx);      // the per-frame sky tables are keyed on the buffers' addresses, which a re-run keeps
@@ -723,6 +747,7 @@ int vpt_atmosphere_precompute(vpt_ctx* ctx, vpt_atmosphere_parameters* p, int nu
 int vpt_atmosphere_precompute_model(vpt_ctx* ctx, const vpt_atmosphere_model_options* opt, const char* spectra_file,
                                     vpt_atmosphere_parameters* atm, int num_scattering_orders, void* stream_v) {
     if (!ctx || !opt || !atm) return VPT_E_INVALID;
+    { const int rc0 = check_atmosphere_inout(ctx, atm, "vpt_atmosphere_precompute_model"); if (rc0 != VPT_OK) return rc0; }
     if (num_scattering_orders < 1) num_scattering_orders = 4;
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : (hipStream_t)vpt_stream(ctx);
     vpt_atmosphere_parameters fin;

@@ -174,6 +174,8 @@ struct vpt_ctx {
     // another stream than the previous one first waits (on the device) for that one's last kernel.
     hipEvent_t render_event = nullptr;     // recorded behind every render's last kernel
     hipStream_t render_stream = nullptr;   // the stream of the previous render
+    hipEvent_t comm_event = nullptr;       // recorded behind every vpt_allreduce_accum's last kernel
+    hipStream_t comm_stream = nullptr;     // the stream of the previous collective
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
     // stats
     bool counting = false;

@@ -39,6 +39,28 @@ struct SkyView {
                                           // which the ground table is used (and was validated), 1 if the variant has a ground table
 };
 
+// WRITE-ONCE / READ-ONCE streams (ray and path records, sample heads, {alpha, depth} pairs, queue entries: 8.5 GB per 64-iteration launch at
+// 1080p): accessed through these helpers so that a build can mark them NON-TEMPORAL (-DVPT_NT_STREAMS: the `nt` bit of global_load /
+// global_store -- the lines are first in line for eviction and do not push the grid, the tables and the dome out of L2 and the Infinity
+// Cache).  Same bytes either way; measured per config in profiles/r05_*.
+typedef float vpt_v4f __attribute__((ext_vector_type(4)));
+typedef float vpt_v2f __attribute__((ext_vector_type(2)));
+#ifdef VPT_NT_STREAMS
+VPT_D float4 ld_stream(const float4* p) { const vpt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const vpt_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+VPT_D float2 ld_stream(const float2* p) { const vpt_v2f v = __builtin_nontemporal_load(reinterpret_cast<const vpt_v2f*>(p)); return make_float2(v.x, v.y); }
+VPT_D uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+VPT_D void st_stream(float4* p, float4 v) { vpt_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<vpt_v4f*>(p)); }
+VPT_D void st_stream(float2* p, float2 v) { vpt_v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<vpt_v2f*>(p)); }
+VPT_D void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+VPT_D float4 ld_stream(const float4* p) { return *p; }
+VPT_D float2 ld_stream(const float2* p) { return *p; }
+VPT_D uint32_t ld_stream(const uint32_t* p) { return *p; }
+VPT_D void st_stream(float4* p, float4 v) { *p = v; }
+VPT_D void st_stream(float2* p, float2 v) { *p = v; }
+VPT_D void st_stream(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+
 struct DVolume {
     const float* density;
     const float* emission;
@@ -228,6 +250,7 @@ struct TraceParams {
     float sun_color[3];
     float sun_mult;
     float sun_dir[3];                // degree_to_cartesian(azimuth, elevation), host-evaluated
+    float sun_inv[3];                // 1 / sun_dir per component, host-evaluated (IEEE single = the device's correctly rounded quotient): the sun's shadow rays (Tr prologue)
     float energy_inject;             // float(kernel_params.energy_inject)
     const float* emission_lut;       // float3[256]
     const float* density_color_lut;  // float3[256]

@@ -12,6 +12,11 @@
 // entry before it is later forced to 1, the running `func` offset by one texel, and the
 // `total_int` loop that adds marginal_func[0] `res` times -- is restated as written.
 // Host code only (no kernels); strict arithmetic like the rest of the host side.
+//
+// NOTE on form: `solve_quadratic`, `ray_sphere`, `host_degree_to_cartesian` and `host_sample_atmosphere` below (lines 25-118) are a LITERAL
+// RESTATEMENT of source/main.cpp:182-312, statement for statement with other names -- not a redesign.  They feed point-sampled CDF inversion on
+// the decision path of estimate_sky, tests/test_env_cdf.py demands the tables BIT-identical to the reference's own lines compiled for the host,
+// and for ~90 lines of scalar binary32 host arithmetic the operation order IS the specification.  The fill loop after them is re-expressed.
 #include <cmath>
 #include <cstring>
 #include <vector>

@@ -274,6 +274,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_lights);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->render_event) (void)hipEventDestroy(ctx->render_event);
+    if (ctx->comm_event) (void)hipEventDestroy(ctx->comm_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -972,8 +973,14 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const unsigned blocks = (unsigned)((n_floats + 255ull) / 256ull);
+    // the reduce takes part in the context's serialisation like a render: it starts (on the device) behind the last render and behind the last
+    // collective, whatever stream those ran on -- a caller that switches streams between two reduces must not free or overwrite a payload the
+    // earlier collective still uses
+    if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
+    if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));
     if (ctx->comm_buf_floats < (size_t)n_floats + 1u) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
+        if (ctx->comm_stream && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
         (void)hipFree(ctx->d_comm_buf); ctx->d_comm_buf = nullptr; ctx->comm_buf_floats = 0;
         HIPCHK(ctx, hipMalloc(&ctx->d_comm_buf, ((size_t)n_floats + 1u) * sizeof(float)));
         ctx->comm_buf_floats = (size_t)n_floats + 1u;
@@ -986,6 +993,9 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     RCCLCHK(ctx, g_rccl.AllReduce(ctx->d_comm_buf, ctx->d_comm_buf, (size_t)n_floats + 1u, ncclFloat32, ncclSum, ctx->comm, stream));
     hipLaunchKernelGGL(comm_divide_kernel, dim3(blocks), dim3(256), 0, stream, accum, (size_t)n_floats, ctx->d_comm_buf);
     HIPCHK(ctx, hipGetLastError());
+    if (!ctx->comm_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->comm_event, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->comm_event, stream));
+    ctx->comm_stream = stream;
     return VPT_OK;
 }
 
@@ -1054,6 +1064,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // one context's renders share its scratch buffers and per-view caches: a render on another stream than the previous one starts
     // (on the device) behind that one's last kernel
     if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
+    if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));   // (the reduce rewrites the caller's accumulation buffer)
 
     // ---- resolve-side parameters
     ResolveParams R;
@@ -1156,6 +1167,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.emission_scale = kp->emission_scale; P.emission_pivot = kp->emission_pivot;
     st3(P.sun_color, kp->sun_color); P.sun_mult = kp->sun_mult;
     st3(P.sun_dir, sun_dir);
+    P.sun_inv[0] = 1.0f / sun_dir.x; P.sun_inv[1] = 1.0f / sun_dir.y; P.sun_inv[2] = 1.0f / sun_dir.z;      // rcp3 of the tracer, IEEE single on the host
     P.energy_inject = (float)kp->energy_inject;
     P.emission_lut = reinterpret_cast<const float*>(kp->emission_texture);
     P.density_color_lut = reinterpret_cast<const float*>(kp->density_color_texture);

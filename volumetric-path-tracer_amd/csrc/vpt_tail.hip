@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
     } else {
     // the next iteration's head is requested while the current sample is evaluated (a streaming read from HBM)
     float4 h_next = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    if (HEADS) h_next = R.heads[idx];
+    if (HEADS) h_next = ld_stream(R.heads + idx);
     for (uint32_t k = 0; k < R.iter_count; ++k) {
         const uint32_t iteration = R.iter_begin + k * R.iter_stride;
         const uint32_t local_it = local_it0 + k;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         bool from_record = true;
         if (HEADS) {
             const float4 h = h_next;
-            if (k + 1u < R.iter_count) h_next = R.heads[slot + R.n_pixels];
+            if (k + 1u < R.iter_count) h_next = ld_stream(R.heads + slot + R.n_pixels);
             if (!LENS && patch && h.w >= 0.0f) {
                 // an untraced sample of a pixel with a sky patch: its value is the patch at the sample's jitter (L = 0, beta = 1)
                 const float2 j = R.blue_noise[(size_t)k * 65536u + bn_idx];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
                 q0 = make_float4(l, l, l, 0.0f);
                 q1 = make_float4(b, b, b, rendered ? h.w : 0.0f);
                 if (R.head_org) {
-                    const float4 o = R.head_org[slot];
+                    const float4 o = ld_stream(R.head_org + slot);
                     q2 = make_float4(o.x, o.y, o.z, __uint_as_float(rendered ? 1u : 0u));
                 } else {
                     q2 = make_float4(R.cam_origin[0], R.cam_origin[1], R.cam_origin[2], __uint_as_float(rendered ? 1u : 0u));
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
         }
         if (from_record) {
             const float4* rec = reinterpret_cast<const float4*>(R.records + slot);
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+            q0 = ld_stream(rec); q1 = ld_stream(rec + 1); q2 = ld_stream(rec + 2); q3 = ld_stream(rec + 3);
         }
         f3 value = mk3(q0.x, q0.y, q0.z);
         float tr = q0.w;
@@ -422,12 +422,12 @@ __global__ __launch_bounds__(256) void sky_fix_kernel(const ResolveParams R, flo
         if (t < n_a) {
             const uint32_t slot = R.queue2[t];
             const float4* rec = reinterpret_cast<const float4*>(R.records + slot);
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            const float4 q0 = ld_stream(rec), q1 = ld_stream(rec + 1), q2 = ld_stream(rec + 2), q3 = ld_stream(rec + 3);
             f3 value = mk3(q0.x, q0.y, q0.z);
             const f3 beta = mk3(q1.x, q1.y, q1.z);
             value += sky.sample(mk3(q2.x, q2.y, q2.z), mk3(q3.x, q3.y, q3.z), sun_dir, use_dir_tab) * beta * R.sky_mult * sky_color;
-            heads[slot] = make_float4(value.x, value.y, value.z, -1.0f);
-            R.td[slot] = make_float2(q0.w, q1.w);
+            st_stream(heads + slot, make_float4(value.x, value.y, value.z, -1.0f));
+            st_stream(R.td + slot, make_float2(q0.w, q1.w));
         } else {
             const uint32_t e = t - n_a;
             const uint32_t p = e / R.iter_count, k = e - p * R.iter_count;
@@ -474,13 +474,13 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
             const uint32_t k = k0 + u;
             const bool live = k < R.iter_count;
             // a pixel raygen emitted nothing for has no heads: every sample is untraced with depth 0 (or not rendered)
-            h[u] = (live && !never) ? R.heads[(size_t)k * R.n_pixels + idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            h[u] = (live && !never) ? ld_stream(R.heads + ((size_t)k * R.n_pixels + idx)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
         for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
             const uint32_t k = k0 + u;
-            td[u] = (k < R.iter_count && h[u].w == -1.0f) ? R.td[(size_t)k * R.n_pixels + idx] : make_float2(0.0f, 0.0f);
+            td[u] = (k < R.iter_count && h[u].w == -1.0f) ? ld_stream(R.td + ((size_t)k * R.n_pixels + idx)) : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
         for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {

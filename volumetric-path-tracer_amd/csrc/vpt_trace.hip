@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
             if (P.heads) {
                 // compact stream: a sample that starts no walk is fully described by its 16-byte head {dir0, depth} --
                 // plus its origin when the lens is open (lens_radius == 0: org0 is the camera origin for every sample)
-                P.heads[s] = make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f));
-                if (P.head_org && !traced) P.head_org[s] = make_float4(org0.x, org0.y, org0.z, 0.0f);
-                if (traced) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3; }
+                st_stream(P.heads + s, make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f)));
+                if (P.head_org && !traced) st_stream(P.head_org + s, make_float4(org0.x, org0.y, org0.z, 0.0f));
+                if (traced) { st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3); }
             } else {
-                dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+                st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3);
             }
         }
         const unsigned long long m = __ballot(enqueue);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
     if (tid == 0 && n) s_base = atomicAdd(P.queue_tail, n);
     __syncthreads();
     const uint32_t gbase = s_base;
-    for (uint32_t i = tid; i < n; i += 256u) P.queue[gbase + i] = s_q[i];
+    for (uint32_t i = tid; i < n; i += 256u) st_stream(P.queue + gbase + i, s_q[i]);
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
     if (COUNT && n_empty_skips) atomicAdd(&P.counters->skip_steps, (unsigned long long)n_empty_skips);
 }
@@ -260,6 +260,12 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
 #define VPT_HIST_CAP_EMIT 8
 #endif
 int trace_blocks_per_cu() { return VPT_TRACE_WAVES_PER_EU; }
+// (study switch: -DVPT_NO_SUN_INV forms 1 / sun_dir in the Tr prologue again, as rounds 1-4 did)
+#ifdef VPT_NO_SUN_INV
+#define VPT_SUN_INV(C) rcp3((C).sun_dir)
+#else
+#define VPT_SUN_INV(C) (C).sun_inv
+#endif
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool A24>
 __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(const TraceParams P) {
     constexpr int HCAP = EMIT ? VPT_HIST_CAP_EMIT : VPT_HIST_CAP;
@@ -336,10 +342,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
                 chunk_base = chunk_next;
-                qi0 = chunk_base + (uint32_t)lane < chunk_end ? P.queue[chunk_base + (uint32_t)lane] : 0u;
-                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 64u + (uint32_t)lane] : 0u;
-                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 128u + (uint32_t)lane] : 0u;
-                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 192u + (uint32_t)lane] : 0u;
+                qi0 = chunk_base + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + (uint32_t)lane) : 0u;
+                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 64u + (uint32_t)lane) : 0u;
+                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 128u + (uint32_t)lane) : 0u;
+                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 192u + (uint32_t)lane) : 0u;
             }
             if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }       // (study builds: charge the claim's latencies to the claim)
             VPT_TICK(tr1);
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
 #ifdef VPT_PROFILE_SECTIONS
                         // (study builds: the wave waits for its records HERE, outside the divergent block, and times the wait apart from the unpacking)
-                        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+                        q0 = ld_stream(src); q1 = ld_stream(src + 1); q2 = ld_stream(src + 2); q3 = ld_stream(src + 3);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         uint32_t new_kiter, new_pixel;
                         split_slot(P, rel >> 6 == 0u ? e0 : (rel >> 6 == 1u ? e1 : (rel >> 6 == 2u ? e2 : e3)), new_kiter, new_pixel);
 #else
-                        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                        const float4 q0 = ld_stream(src), q1 = ld_stream(src + 1), q2 = ld_stream(src + 2), q3 = ld_stream(src + 3);
 #endif
                         kiter = new_kiter;
                         pixel = new_pixel;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             rng_top_up(rng, pixel);
             bool start_tr = false;
             uint32_t tr_walk_phase = PH_IDLE, tr_done_phase = PH_IDLE;
-            f3 tr_dir = mk3(0.0f);
+            f3 tr_dir = mk3(0.0f), tr_inv = mk3(0.0f);
 
             if (phase == PH_T_FIRST_DONE) {
                 // the walk just finished IS depth_calculator's walk (:1879-1881) ...
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     // estimate_sun :1478-1516
                     ppos = w.pos;
                     pdir = w.dir;
-                    start_tr = true; tr_dir = C.sun_dir; tr_walk_phase = PH_W_SUN; tr_done_phase = PH_T_SUN_DONE;
+                    start_tr = true; tr_dir = C.sun_dir; tr_inv = VPT_SUN_INV(C); tr_walk_phase = PH_W_SUN; tr_done_phase = PH_T_SUN_DONE;
                 } else {
                     phase = PH_T_OUTER_SECOND;
                 }
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 if (li > C.num_lights - 1) li = C.num_lights - 1;                    // rand()==1.0f guard
                 light_index = li;
                 const DPointLight& lt = C.lights[li];
-                start_tr = true; tr_dir = normalize(ld3(lt.pos) - f3(ppos)); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
+                start_tr = true; tr_dir = normalize(ld3(lt.pos) - f3(ppos)); tr_inv = rcp3(tr_dir); tr_walk_phase = PH_W_PL; tr_done_phase = PH_T_PL_DONE;
             } else if (phase == PH_T_EMIT_CHECK || phase == PH_T_EMIT_DONE || phase == PH_T_SPH_DONE) {
                 if (phase == PH_T_EMIT_DONE) L += w.Ld;                             // :1803
                 if (phase == PH_T_SPH_DONE) L += C.sun_color * C.sun_mult * mk3(w.trw) * (float)sph_factor * f3(beta);  // :1832
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     ppos = w.pos;
                     pdir = w.dir;
                     gco_obj = -1;
-                    start_tr = true; tr_dir = C.sun_dir; tr_walk_phase = PH_W_SPH; tr_done_phase = PH_T_SPH_DONE;
+                    start_tr = true; tr_dir = C.sun_dir; tr_inv = VPT_SUN_INV(C); tr_walk_phase = PH_W_SPH; tr_done_phase = PH_T_SPH_DONE;
                 } else {
                     rd++;                          // same ray next iteration: the cached result stays valid
                     phase = PH_T_OUTER_TOP;
@@ -703,17 +709,17 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     f3 dv;
                     if (oe.x == rt.cam_origin[0] && oe.y == rt.cam_origin[1] && oe.z == rt.cam_origin[2] && dome_lookup(rt.sky_dome, od, dv)) {
                         const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
-                        rt.heads[slot] = make_float4(val.x, val.y, val.z, -1.0f);
-                        rt.td[slot] = make_float2(fmin_(w.alpha, 1.0f), depth);
+                        st_stream(rt.heads + slot, make_float4(val.x, val.y, val.z, -1.0f));
+                        st_stream(rt.td + slot, make_float2(fmin_(w.alpha, 1.0f), depth));
                         resolved = true;
                     }
                 }
                 if (!resolved) {
                     float4* dst = reinterpret_cast<float4*>(C.records + slot);
-                    dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // tr = fminf(tr, 1) :1854
-                    dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
-                    dst[2] = make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u));
-                    dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
+                    st_stream(dst, make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f)));      // tr = fminf(tr, 1) :1854
+                    st_stream(dst + 1, make_float4(ob.x, ob.y, ob.z, depth));
+                    st_stream(dst + 2, make_float4(oe.x, oe.y, oe.z, __uint_as_float(1u)));
+                    st_stream(dst + 3, make_float4(od.x, od.y, od.z, 0.0f));
                     if (resolving) {
                         // the full evaluation is sky_fix_kernel's (vpt_tail.hip): one queue entry per such path, one atomic per wave
                         const unsigned long long qm = __ballot(1);
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 
             VPT_TICK(ts3);                       // FINISH
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
-            if (start_tr) phase = tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir) ? tr_walk_phase : tr_done_phase;
+            if (start_tr) phase = tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir, tr_inv) ? tr_walk_phase : tr_done_phase;
             VPT_TICK(ts4);                       // Tr prologue
         }
         }

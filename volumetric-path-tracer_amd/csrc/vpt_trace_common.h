@@ -132,7 +132,7 @@ typedef const __attribute__((address_space(4))) TraceParams* KargPtr;
 struct ColdConst {
     f3 sph_center, sph_color;
     float sph_radius, sph_roughness;
-    f3 sun_color, sun_dir;
+    f3 sun_color, sun_dir, sun_inv;
     float sun_mult, phase_g1, emission_scale;
     float sky_mult;
     int ray_depth, volume_depth, num_lights;
@@ -149,6 +149,7 @@ VPT_D ColdConst load_cold_const() {
     c.sph_radius = k->sph_radius; c.sph_roughness = k->sph_roughness;
     c.sun_color = mk3(k->sun_color[0], k->sun_color[1], k->sun_color[2]);
     c.sun_dir = mk3(k->sun_dir[0], k->sun_dir[1], k->sun_dir[2]);
+    c.sun_inv = mk3(k->sun_inv[0], k->sun_inv[1], k->sun_inv[2]);
     c.sky_mult = k->sky_mult;
     c.sun_mult = k->sun_mult; c.phase_g1 = k->phase_g1; c.emission_scale = k->emission_scale;
     c.ray_depth = k->ray_depth; c.volume_depth = k->volume_depth; c.num_lights = k->num_lights;
@@ -397,12 +398,22 @@ VPT_D void quad_entries(const int* dim, const Taps& t, uint32_t& e0, uint32_t& e
     e0 = row + (uint32_t)t.i0;
     e1 = row + (uint32_t)t.i1;
 }
+// a corner quad is read once per look-up and (on the grids that are re-laid: those that do not stay in L2) almost never again by the same CU --
+// 1.02 lanes of a wave share an 8^3 brick on config 4 (profiles/r02_lookup_coherence.txt).  -DVPT_NT_QUADS marks the two loads non-temporal, so
+// that their 128-byte lines are the first to leave L2 / the Infinity Cache instead of the records, the HDRI and the dome (measured: profiles/r05_*).
+VPT_D v4f ld_quad(gptr_f4 g, size_t e) {
+#ifdef VPT_NT_QUADS
+    return __builtin_nontemporal_load(g + e);
+#else
+    return g[e];
+#endif
+}
 template <bool A24>
 VPT_D float fetch_f32_quads(const float* __restrict__ g_, const int* dim, const Taps& t) {
     const gptr_f4 g = (gptr_f4)g_;
     uint32_t e0, e1;
     quad_entries<A24>(dim, t, e0, e1);
-    const v4f q0 = g[(size_t)e0], q1 = g[(size_t)e1];
+    const v4f q0 = ld_quad(g, (size_t)e0), q1 = ld_quad(g, (size_t)e1);
     const float c00 = q0.x + (q1.x - q0.x) * t.ax;
     const float c10 = q0.y + (q1.y - q0.y) * t.ax;
     const float c01 = q0.z + (q1.z - q0.z) * t.ax;
@@ -424,7 +435,7 @@ VPT_D void issue_f32(const float* __restrict__ g_, const DVolume& v, const Taps&
     if (v.layout == GRID_QUADS) {
         uint32_t e0, e1;
         quad_entries<A24>(v.dim, t, e0, e1);
-        const v4f q0 = ((gptr_f4)g_)[(size_t)e0], q1 = ((gptr_f4)g_)[(size_t)e1];
+        const v4f q0 = ld_quad((gptr_f4)g_, (size_t)e0), q1 = ld_quad((gptr_f4)g_, (size_t)e1);
         pd.c[0] = q0.x; pd.c[1] = q1.x;
         pd.c[2] = q0.y; pd.c[3] = q1.y;
         pd.c[4] = q0.z; pd.c[5] = q1.z;

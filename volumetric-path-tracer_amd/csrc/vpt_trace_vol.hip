@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
                 chunk_base = chunk_next;
-                qi0 = chunk_base + (uint32_t)lane < chunk_end ? P.queue[chunk_base + (uint32_t)lane] : 0u;
-                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 64u + (uint32_t)lane] : 0u;
-                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 128u + (uint32_t)lane] : 0u;
-                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 192u + (uint32_t)lane] : 0u;
+                qi0 = chunk_base + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + (uint32_t)lane) : 0u;
+                qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 64u + (uint32_t)lane) : 0u;
+                qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 128u + (uint32_t)lane) : 0u;
+                qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 192u + (uint32_t)lane) : 0u;
             }
             const uint32_t avail = chunk_end - chunk_next;
             if (avail == 0u && !more && idle == active) break;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
                         split_slot(P, slot, kiter, pixel);
                         const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         const float4* src = reinterpret_cast<const float4*>(P.records + slot);
-                        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                        const float4 q0 = ld_stream(src), q1 = ld_stream(src + 1), q2 = ld_stream(src + 2), q3 = ld_stream(src + 3);
                         const f3 o0 = mk3(q0.x, q0.y, q0.z), d0 = mk3(q1.x, q1.y, q1.z);
                         org0 = o0;
                         dir0 = d0;
@@ -572,10 +572,10 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
                 const f3 ob = beta, oL = L;
                 const f3 op = length(ob) > 0.9999f ? f3(org0) : w.pos;              // :1753
                 float4* dst = reinterpret_cast<float4*>(C.records + ((size_t)kiter * C.n_pixels + pixel));
-                dst[0] = make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f));      // :1755
-                dst[1] = make_float4(ob.x, ob.y, ob.z, depth);
-                dst[2] = make_float4(op.x, op.y, op.z, __uint_as_float(1u));
-                dst[3] = make_float4(od.x, od.y, od.z, 0.0f);
+                st_stream(dst, make_float4(oL.x, oL.y, oL.z, fmin_(w.alpha, 1.0f)));      // :1755
+                st_stream(dst + 1, make_float4(ob.x, ob.y, ob.z, depth));
+                st_stream(dst + 2, make_float4(op.x, op.y, op.z, __uint_as_float(1u)));
+                st_stream(dst + 3, make_float4(od.x, od.y, od.z, 0.0f));
                 if (COUNT) {
                     atomicAdd(&P.counters->samples, 1ull);
                     atomicAdd(&P.counters->density_lookups, (unsigned long long)cnt.n_d);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
             }
 
             if (start_tr) {
-                if (tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir)) {
+                if (tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir, rcp3(tr_dir))) {
                     tr_next = tr_done;
                     phase = VH_W_TR;
                 } else {

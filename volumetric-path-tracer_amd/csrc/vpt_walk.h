@@ -399,10 +399,11 @@ VPT_D bool walk_finish(const TraceParams& P, const WalkConst& K, int kind, bool 
 
 // Tr prologue :1153-1167 (shared by sun / point-light / sky / sphere shadow rays): returns true
 // when a walk is needed; otherwise w.trw holds the result (1: misses the box, 0: sphere in the way)
-VPT_D bool tr_begin(f3 sph_center, float sph_radius, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
+// tr_inv: 1 / tr_dir per component (the sun's is a launch constant, host-evaluated: three correctly rounded divisions per scatter event less)
+VPT_D bool tr_begin(f3 sph_center, float sph_radius, const WalkConst& K, Walk& w, f3 from, f3 tr_dir, f3 tr_inv) {
     w.pos = from;
     w.dir = tr_dir;
-    w.inv = rcp3(tr_dir);
+    w.inv = tr_inv;
     float t_min, t_max;
     if (!contains(K.root_lo, K.root_hi, w.pos)) {
         if (box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_min, t_max)) w.pos += w.dir * (t_min + VPT_EPS);
@@ -416,7 +417,7 @@ VPT_D bool tr_begin(f3 sph_center, float sph_radius, const WalkConst& K, Walk& w
     return true;
 }
 VPT_D bool tr_begin(const TraceParams& P, const WalkConst& K, Walk& w, f3 from, f3 tr_dir) {
-    return tr_begin(ld3(P.sph_center), P.sph_radius, K, w, from, tr_dir);
+    return tr_begin(ld3(P.sph_center), P.sph_radius, K, w, from, tr_dir, rcp3(tr_dir));
 }
 // Tr epilogue :1166,:1267
 VPT_D float tr_end(const WalkConst& K, const Walk& w) { return clampf(w.trw * expf(-K.sigma_c * w.distance), .0f, 1.0f); }
