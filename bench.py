@@ -67,6 +67,17 @@ def make_scene(pkg, cfg, W, H, spp, grid_scale, dev, local_rank):
     return sd, workload, data, W, H
 
 
+def flips_block(lib, hb):
+    """share of the ground table's check rays whose binary32 ground point the full path finds one step (0.5 m) above the ground: the reference's own
+    ray-to-ray noise, gated apart from the table's deviation (csrc/vpt_tail.hip: sky_dir_table_rays_kernel)"""
+    import ctypes as C
+    f = (C.c_float * 2)()
+    lib.vpt_test_get_dir_table_flips.argtypes = [C.c_void_p, C.POINTER(C.c_float * 2)]
+    if lib.vpt_test_get_dir_table_flips(hb.ctx.h, C.byref(f)) != 0:
+        return None
+    return {"fraction_centre_variant": float(f[0]), "largest_fraction_all_variants": float(f[1]), "accepted_fraction": 0.05}
+
+
 def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator, lean=False):
     """cs: stats of a counted pass, st: HIP-event times of the last timed step; lean: the tracer resolved its finished paths itself
     (24 bytes out per ray instead of a 64-byte path record, csrc/vpt_device.h ResolveParams::lean).
@@ -95,9 +106,13 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
     trace_s = st.trace_ms * 1e-3
     achieved_kernel = b_kernel * samples_per_step / trace_s / 1e9 if trace_s > 0 else 0.0
     achieved = b_ref * samples_per_step / step_s / 1e9
+    # BASELINE.md's formula charges bytes for look-ups the reference evaluates and DISCARDS (config 5: 13 colour look-ups per sample, :1662 vs :1673):
+    # where that puts the figure above the peak it is not a fraction of anything -- `frac` is null, `frac_void` says why, the raw ratio is kept under
+    # a name that does not claim to be one, and the config's roofline figure is `frac_kernel_issued_fetches` (bytes this tracer must move / its time)
+    void = achieved > HBM_PEAK_GBS
     r = {
-        "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3) if not void else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5) if not void else None, "frac_void": bool(void), "traffic": None,
         "definition": "BASELINE.md 3 verbatim: (32 N_d + 128 N_c + 32 N_e + 88) B per pixel-sample with the reference-defined look-up counts x samples/s of the whole step",
         "frac_kernel_issued_fetches": round(achieved_kernel / HBM_PEAK_GBS, 5),
         "achieved_kernel_issued_fetches": round(achieved_kernel, 3),
@@ -115,6 +130,11 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
         "resolved_samples": bool(lean),
         "note": "kernel times: HIP events on the context's stream around every launch of the LAST timed step",
     }
+    if void:
+        r["reference_count_bytes_over_peak"] = round(achieved / HBM_PEAK_GBS, 3)
+        r["frac_void_reason"] = ("BASELINE.md 3's bytes per sample count every look-up the reference evaluates, used or not (render_kernel.cu:1662 vs :1673): "
+                                 "x samples/s they exceed the 8 TB/s peak, so the formula bounds nothing here; this config's roofline figure is frac_kernel_issued_fetches")
+        r["frac_promoted"] = {"name": "frac_kernel_issued_fetches", "value": r["frac_kernel_issued_fetches"]}
     # measured HBM traffic of the dominant kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
     # command, corrected per MI355X_MICROARCH.md; tools/profile_bench.sh + tools/make_traffic_json.py write the file)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -161,6 +181,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-per-frame", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-config parity leg of other_configs")
+    ap.add_argument("--no-c4-oracle", action="store_true", help="config 4's parity leg: the layout A/B only (no 3.5 GB host copy, no oracle lattice)")
+    ap.add_argument("--no-c1", action="store_true", help="skip the config-1 block (reference kernel on ONE host thread, 512x512x16spp)")
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
     args = ap.parse_args()
@@ -214,17 +236,17 @@ def main():
 
     cfg = args.config
     job_spp = args.spp or DEFAULT_SPP.get(cfg, 64)
-    if args.scaling == "strong" and world > 1:
-        # the job's iterations striped over the ranks: rank r renders iterations r, r + G, ... (one more on the first spp % G ranks);
-        # the all-reduce weights every rank's mean with its own count
-        spp = len(range(rank, job_spp, world))
-    else:
-        spp = job_spp
 
-    def measure(cfg, spp, steps, warmup, W, H, with_extras):
+    def rank_spp(scaling):
+        # strong: the job's iterations striped over the ranks: rank r renders iterations r, r + G, ... (one more on the first spp % G ranks);
+        # the all-reduce weights every rank's mean with its own count.  weak: every rank renders the job's spp
+        return len(range(rank, job_spp, world)) if (scaling == "strong" and world > 1) else job_spp
+
+    def measure(cfg, spp, steps, warmup, W, H, with_extras, scaling=None):
         """one workload: returns the dict of the JSON line (rank 0) or None"""
-        job_iters = spp * world if (world == 1 or args.scaling == "weak") else job_spp       # iterations of the whole job per step
-        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or args.scaling == "weak" else job_spp, args.grid_scale, dev, local_rank)
+        scaling = scaling or args.scaling
+        job_iters = spp * world if (world == 1 or scaling == "weak") else job_spp       # iterations of the whole job per step
+        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or scaling == "weak" else job_spp, args.grid_scale, dev, local_rank)
         # scene set-up as a rank pays it at start (outside the timed region): texture uploads / adoption, the re-lay of big grids
         # into corner quads (config 4: 3.5 GB -> 14 GB on the GPU), the host octree and its candidate lists, buffer allocation
         torch.cuda.synchronize(dev)
@@ -310,12 +332,17 @@ def main():
                 tb = time.perf_counter()
                 hb.render(spp, iteration=0)
                 hb.sync()
-                roofline["cache_build_ms_per_view"] = round(max(0.0, (time.perf_counter() - tb) - step_s) * 1e3, 3)
+                cold_s = time.perf_counter() - tb
+                roofline["cache_build_ms_per_view"] = round(max(0.0, cold_s - step_s) * 1e3, 3)
+                # the headline's timed steps render a still view whose per-view caches were built in the warm-up; a COLD frame (new view: caches
+                # rebuilt inside the step) is this
+                roofline["cold_view_ms_per_step"] = round(max(cold_s, step_s) * 1e3, 3)
+                roofline["cold_view_msamples_per_s"] = round(W * H * spp / max(cold_s, step_s) / 1e6, 3)
                 roofline["caches_in_use"] = dict(zip(("sky_patch", "never_traced", "sky_dome", "dome_variants", "cam_table", "dir_table", "resolved_samples"), [int(x) for x in list(cstate)[:7]]))
             out = {
                 "metric": "Msamples/s (W*H*spp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
                 "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": data,
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": data,
                 "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp, "spp_job": job_iters,
                            "parallelism": "iteration-striped x%d + 1 RCCL all-reduce under the C ABI" % world if world > 1 else "1 GPU",
                            # what carried the reduce: the rank count read back from the context's RCCL communicator, or the
@@ -341,8 +368,9 @@ def main():
                         "interpolation_error_at_cell_centres": float(err.value), "interpolation_error_accepted_below": 5e-4,
                         "variants_in_use": int(chk[5]),
                         "vs_full_path_along_real_rays": {"rays_centre_variant": int(chk[2]), "max_relative_difference": float(chk[1]), "accepted_below": 2e-2,
-                                                         "fraction_above_1e-3": (float(chk[3]) / float(chk[2])) if chk[2] else None, "accepted_fraction": 0.02,
-                                                         "all_variants_max": float(chk[6]), "all_variants_largest_fraction_above_1e-3": float(chk[7])}}
+                                                         "fraction_unflipped_above_1e-3": (float(chk[3]) / float(chk[2])) if chk[2] else None, "accepted_fraction": 0.005,
+                                                         "all_variants_max": float(chk[6]), "all_variants_largest_fraction_unflipped_above_1e-3": float(chk[7]),
+                                                         "flipped_rays": flips_block(lib, hb)}}
                 pa, pb = C.c_ulonglong(0), C.c_ulonglong(0)
                 lib.vpt_test_get_sky_patch_coverage.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
                 if lib.vpt_test_get_sky_patch_coverage(hb.ctx.h, C.byref(pa), C.byref(pb)) == 0:
@@ -406,14 +434,28 @@ def main():
             same_counts = all(getattr(sa, c) == getattr(sb, c) for c in counts)
             same_bits = bool(torch.equal(hb.accum, hd.accum) and torch.equal(hb.depth, hd.depth))
             hd.ctx.close()
+            del hd
+            torch.cuda.empty_cache()
             hb.ctx.set_counting(False)
-            return {"kind": "layout", "iterations": 2, "counts_equal_dense_layout": same_counts, "buffers_bit_identical_dense_layout": same_bits,
-                    "note": "re-laid (corner-quad) density grid vs VPT_GRID_LAYOUT=dense on the same device grid; against the oracle: "
-                            "tests/test_gpu_fullsize.py::test_config4_cloud_benchmark_size_grid_1080p"}
+            layout = {"iterations": 2, "counts_equal_dense_layout": same_counts, "buffers_bit_identical_dense_layout": same_bits,
+                      "note": "re-laid (corner-quad) density grid vs VPT_GRID_LAYOUT=dense on the same device grid"}
+            # ... and against the ORACLE at this size like configs 3 and 5 (round 5): a host copy of the device grid (3.5 GB at spec), two record chunks on a
+            # lattice of the frame.  --no-c4-oracle keeps the layout comparison only.
+            if args.no_c4_oracle:
+                return dict(layout, kind="layout")
+            import copy
+            sd_host = copy.copy(sd)
+            sd_host.volumes = [(v[0], v[1].detach().cpu().numpy() if not isinstance(v[1], np.ndarray) else v[1], v[2], v[3]) for v in sd.volumes]
+            res = oracle_lattice(cfg, hb, sd_host, bn0, W, H, ipl)
+            res["layout"] = layout
+            return res
+        return oracle_lattice(cfg, hb, sd, bn0, W, H, ipl)
+
+    def oracle_lattice(cfg, hb, sd, bn0, W, H, ipl):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding
-        step = {"c3": 17, "c5": 131}.get(cfg, 17)
-        iters = 2 * ipl
+        step = {"c3": 17, "c5": 131, "c4": 67}.get(cfg, 17)
+        iters = 2 * ipl if cfg != "c4" else ipl + 8      # two record chunks either way (a launch boundary); config 4's vol_integrator walks cost the CPU ~5x per sample
         cores = os.cpu_count() or 1
         ob = oracle_binding.OracleBinding(sd)
         tc = time.perf_counter()
@@ -430,6 +472,41 @@ def main():
         return {"kind": "oracle", "iterations": iters, "record_chunks": 2, "pixel_step": step, "pixels": int(got.shape[0]), "rel_l2": rel,
                 "depth_pixels_differing": int((dgot != dref).sum()), "tolerance": 1e-3, "cpu_seconds": round(dtc, 1),
                 "note": "HIP accum / depth after %d iterations (2 record chunks) vs the oracle on every %dth pixel of the %dx%d frame" % (iters, step, W, H)}
+
+    def c1_single_thread():
+        """BASELINE config 1 as SURVEY 8d specifies it: dragon.vdb, 512 x 512, 16 spp, ONE point light, no atmosphere -- the reference's own kernel
+        (oracle/_ref; the oracle where that library is absent: same image bit for bit) on ONE host thread, the whole config, next to the HIP path on the
+        very same 16 iterations and the parity of the two."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding
+        import ref_binding
+        Wc, Hc, sppc = 512, 512, 16
+        sd1 = pkg.scene.dragon_scene(Wc, Hc, "c1")
+        use_ref = ref_binding.have_ref()
+        ob = ref_binding.RefBinding(sd1) if use_ref else oracle_binding.OracleBinding(sd1)
+        tc = time.perf_counter()
+        ob.render(sppc, nthreads=1)
+        dtc = time.perf_counter() - tc
+        h1 = pkg.scene.HipBinding(sd1, device=local_rank)
+        h1.render(sppc, iteration=0)
+        h1.sync()
+        got, ref = h1.accum.cpu().numpy().astype(np.float64), ob.accum.astype(np.float64)
+        rel = float(np.sqrt(((got - ref) ** 2).sum()) / max(1e-30, np.sqrt((ref ** 2).sum())))
+        ddiff = int((h1.depth.cpu().numpy() != ob.depth).sum())
+        bn1 = h1.blue_noise.clone()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            h1.render(sppc)
+        h1.sync()
+        dth = (time.perf_counter() - t1) / 20
+        h1.ctx.close()
+        return {"workload": "dragon.vdb %dx%dx%dspp, one point light, no atmosphere (BASELINE config 1)" % (Wc, Hc, sppc),
+                "cpu": {"value": round(Wc * Hc * sppc / dtc / 1e6, 4), "unit": "Msamples/s", "cores": 1, "seconds": round(dtc, 2),
+                        "kind": "reference" if use_ref else "port",
+                        "what": "the reference's render_kernel.cu built for the host (oracle/_ref), 1 thread, all 16 iterations" if use_ref else "oracle, 1 thread, all 16 iterations"},
+                "hip": {"value": round(Wc * Hc * sppc / dth / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 4)},
+                "parity_rel_l2": rel, "parity_depth_pixels_differing": ddiff, "tolerance": 1e-3}
 
     def cpu_baseline(hb, sd, bn0, W, H, spp):
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)
@@ -463,7 +540,19 @@ def main():
                 "parity_depth_pixels_differing": int((dgot != dref).sum()),
                 "parity_note": "HIP accum / depth buffers vs this CPU render after the same %d iterations at full size (tolerance 1e-3 rel. L2)" % args.cpu_iters}
 
-    out = measure(cfg, spp, args.steps, args.warmup, args.width, args.height, True)
+    out = measure(cfg, rank_spp(args.scaling), args.steps, args.warmup, args.width, args.height, True)
+    # BOTH scalings travel in the one line (round 5): `value` / `scaling` are the mode asked for (weak by default: what the driver's N = 1, 2, 4, 8
+    # runs compare), `weak` and `strong` hold the job's rate either way -- strong is north_star's own sentence: ONE frame's sample batches split over
+    # the GPUs and reduced once.  At N = 1 the two are the same job.
+    other = "strong" if args.scaling == "weak" else "weak"
+    if world > 1:
+        o2 = measure(cfg, rank_spp(other), args.steps, args.warmup, args.width, args.height, False, scaling=other)
+    else:
+        o2 = out
+    if rank == 0 and out is not None and o2 is not None:
+        for name, o in ((args.scaling, out), (other, o2)):
+            out[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                         "spp_per_gpu": o["config"]["spp_per_gpu"], "spp_job": o["config"]["spp_job"], "n_gpus": world}
     if not multi and not args.no_other_configs and cfg == "c2":
         others = []
         for oc in ("c3", "c4", "c5"):
@@ -473,6 +562,8 @@ def main():
                                "warmup": o["warmup"], "data": o["data"], "roofline": o["roofline"], "parity": o.get("parity")})
         if out is not None:
             out["other_configs"] = others
+    if not multi and rank == 0 and out is not None and cfg == "c2" and not args.no_c1 and not args.no_cpu_baseline:
+        out["c1_cpu_single_thread"] = c1_single_thread()
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if multi:

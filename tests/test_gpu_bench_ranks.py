@@ -25,11 +25,15 @@ def test_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["config"]["spp_per_gpu"] == 4
+    # both scalings travel in the one line (round 5): the job's rate with every rank rendering the 4 iterations, and with the 4 split over the 2 ranks
+    assert d["weak"]["value"] == d["value"] and d["weak"]["spp_per_gpu"] == 4 and d["weak"]["spp_job"] == 8
+    assert d["strong"]["value"] > 0 and d["strong"]["spp_per_gpu"] == 2 and d["strong"]["spp_job"] == 4 and d["strong"]["n_gpus"] == 2
     # fixed total work: the job's 4 iterations split over the 2 ranks
     r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["spp_per_gpu"] == 2 and d["value"] > 0
+    assert d["strong"]["value"] == d["value"] and d["weak"]["spp_per_gpu"] == 4 and d["weak"]["value"] > 0
 
 
 def test_eight_ranks_strong_scaling_dry_run():

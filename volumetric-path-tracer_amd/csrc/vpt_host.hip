@@ -827,6 +827,23 @@ int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {
     return VPT_OK;
 }
 
+int vpt_test_get_dir_table_flips(vpt_ctx* ctx, float out[2]) {
+    if (!ctx || !out) return VPT_E_INVALID;
+    out[0] = out[1] = 0.0f;
+    if (!ctx->dir_tab_built) return VPT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    unsigned long long w[SKY_DIR_ERR_WORDS] = {0};
+    HIPCHK(ctx, hipMemcpy(w, ctx->d_dir_err, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[2] != 0ull) out[0] = (float)((double)w[6] / (double)w[2]);        // (the verdict kernel copies the centre variant's figures to err[1..3], err[6])
+    for (int v = 0; v < 2 * SKY_VIEW_MAX_K + 1; ++v) {
+        const unsigned long long* e = w + 8 + 4 * v;
+        if (e[1] == 0ull) continue;
+        out[1] = std::max(out[1], (float)((double)e[3] / (double)e[1]));
+    }
+    return VPT_OK;
+}
+
 int vpt_test_sky_samples(vpt_ctx* ctx, int n, const float* origins, const float* dirs, int use_table, float* out) {
     if (!ctx || n <= 0 || !dirs || !out) return VPT_E_INVALID;
     if (!ctx->have_last_resolve || !ctx->last_resolve.has_atmosphere || !ctx->last_resolve.cam_tab_valid) {

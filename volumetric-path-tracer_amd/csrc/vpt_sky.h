@@ -299,7 +299,9 @@ struct Sky {
         if (lum()) sky *= v(AF_SKY_K);
         return sky;
     }
-    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, int cv) const {   // :749 (shadow_length = 0)
+    // flipped (optional): the binary32 ground point did NOT land on the ground -- its radius, as :781 forms it, is a step (0.5 m) above `bottom`,
+    // i.e. 2.5 km of the tables' rho: the reference's own ray-to-ray noise of a ground hit (~2 % of the rays, ~5e-3 of the radiance each)
+    VPT_D f3 SkyRadianceToPoint(f3 camera, f3 point, f3 sun_direction, f3& transmittance, int cv, bool* flipped = nullptr) const {   // :749 (shadow_length = 0)
         // GEOMETRY in the reference's own operations, correctly rounded (round 5): the view ray, r, mu and d feed r_p below and the binary32
         // discriminant (r mu)^2 - r^2 + bottom^2 of the scattering row -- both staircases in which one ulp of a root or a quotient is 0.5 m of
         // radius = 2.5 km of rho, up to 2 % of the radiance next to the horizon.  With them formed as the strict side forms them the ground
@@ -323,6 +325,7 @@ struct Sky {
         const float nu = dot(view_ray, sun_direction);
         const bool ground = HitsGround(r, mu);
         const float r_d = ClampRadius(RadiusAt(r, mu, d));
+        if (flipped) *flipped = r_d > bottom();
         transmittance = Transmittance(r, mu, d, r_d, ground);
         f3 single_mie;
         f3 scattering = cv >= 0 ? CombinedScatteringCam(r, mu, nu, ground, single_mie, cv) : CombinedScattering(r, mu, mu_s, nu, ground, single_mie);
@@ -444,7 +447,7 @@ struct Sky {
     // sample_atmosphere :839-895.  use_dir_tab: ground hits seen from the table's view point come from the ground table
     // kind (optional): which evaluation the direction took -- 0 sky, 1 ground through the table, 2 ground in full (the one whose
     // binary32 ground point makes it noisy from ray to ray: the per-pixel sky patches keep away from it)
-    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction, bool use_dir_tab = false, int* kind = nullptr) const {
+    VPT_D f3 sample(f3 ray_pos, f3 ray_dir, f3 sun_direction, bool use_dir_tab = false, int* kind = nullptr, bool* flipped = nullptr) const {
         const f3 earth_center = mk3(.0f, -bottom(), .0f);
         const f3 p = ray_pos - earth_center;
         const float p_dot_v = dot(p, ray_dir);
@@ -481,7 +484,7 @@ struct Sky {
             if (lum()) { sky_irr *= v(AF_SKY_K); sun_irr *= v(AF_SUN_K); }
             radiance = v(AF_GROUND) * (1.0f / VPT_PI) * (sun_irr + sky_irr);
             f3 tr;
-            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr, cv);
+            const f3 in_scatter = SkyRadianceToPoint(p, pt, sun_direction, tr, cv, flipped);
             radiance = radiance * tr + in_scatter;
             // lerp(radiance_sky, ground_radiance, ground_alpha = 1) (:881) is ground_radiance to one
             // rounding: the sky-only branch below is not evaluated for ground hits

@@ -624,12 +624,11 @@ __global__ void sky_dir_table_check_kernel(const ResolveParams R, const SkyView*
 // open lens, horizontally within the lens radius) -- is evaluated
 // twice through sample_atmosphere: in full (the reference's arithmetic: binary32 ground point, its radius as the reference finds
 // it) and through the table; the two tone-curved radiances the tail would add to L are compared.  Per variant v, at err[8 + 4 v]:
-// largest relative difference (high word) and its cell, rays compared, rays off by more than 1e-3, rays off by more than VPT_DIR_TAB_P99.  The interpolation check above
-// cannot see what this one sees: the rays whose binary32 ground point lies one step (0.5 m) above the ground (vpt_sky.h,
-// GroundFromTable) -- more of them from the off-centre origins of an open lens.
-#ifndef VPT_DIR_TAB_P99
-#define VPT_DIR_TAB_P99 2e-3f
-#endif
+// largest relative difference (high word) and its cell, rays compared, UNFLIPPED rays off by more than 1e-3, FLIPPED rays.  A ray is "flipped" when
+// the full path finds its binary32 ground point one step (0.5 m) above the ground (vpt_sky.h: SkyRadianceToPoint) -- the reference's own ray-to-ray
+// noise, 2.5 km of the tables' rho, ~5e-3 of the radiance: a table is a smooth function and returns such a ray's unflipped value by construction, so the
+// two populations are gated apart (round 5: with the ground geometry formed as the strict side forms it, ~2 % of the rays flip, where the approximate
+// roots of rounds 1-4 flipped 0.5 % of them on one side only and the single "share above 1e-3" gate sat at its limit).
 template <bool LENS>
 __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* view, unsigned long long* err) {
     typedef Sky<ResolveParams> S;
@@ -680,10 +679,11 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     const float cphi = fdiv(nu - mu * mu_s, sv * ss);
     valid = valid && fabsf(cphi) <= 1.0f;                                                      // else: no view ray has this (mu, nu)
     float dev = 0.0f;
+    bool flip = false;
     if (valid) {
         const f3 e1 = (sun - up * mu_s) * frcp(ss), e2 = cross(up, e1);
         const f3 dir = normalize(up * mu + (e1 * cphi + e2 * fsqrt(fmax_(1.0f - cphi * cphi, 0.0f))) * sv);
-        const f3 full = sky.sample(pos, dir, sun, false), tab = sky.sample(pos, dir, sun, true);
+        const f3 full = sky.sample(pos, dir, sun, false, nullptr, &flip), tab = sky.sample(pos, dir, sun, true);
         dev = fmax_(fmax_(fabsf(tab.x - full.x), fabsf(tab.y - full.y)), fabsf(tab.z - full.z)) / fmax_(fmax_(fmax_(full.x, full.y), full.z), 1e-30f);
     }
     const uint32_t bits = dev == dev ? __float_as_uint(dev) : 0x7fc00000u;                      // NaN compares false everywhere: let it through as a huge error
@@ -692,8 +692,8 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
     for (int v = 0; v <= 2 * k; ++v) {
         const unsigned long long m = __ballot(valid && cv == v);
         if (m == 0ull) continue;
-        const unsigned long long above = __ballot(valid && cv == v && !(dev <= 1e-3f));
-        const unsigned long long above2 = __ballot(valid && cv == v && !(dev <= VPT_DIR_TAB_P99));
+        const unsigned long long above = __ballot(valid && cv == v && !flip && !(dev <= 1e-3f));
+        const unsigned long long above2 = __ballot(valid && cv == v && flip);
         unsigned long long key = (valid && cv == v) ? (((unsigned long long)bits << 32) | c) : 0ull;
         for (int s = 32; s >= 1; s >>= 1) {
             const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), s) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, s);
@@ -708,23 +708,21 @@ __global__ void sky_dir_table_rays_kernel(const ResolveParams R, const SkyView* 
         }
     }
 }
-// The verdicts the tail reads.  Per variant: against real rays through the full path no ray is off by more than 2 % and at most
-// 2 % of them by more than 1e-3 (the image tolerance is 1e-3 rel. L2) -- a variant that fails loses its table (SkyView::tab[v].w = 0:
-// its ground hits are evaluated in full).  err[4] = 1 when the interpolant follows its nodes (err[0] <= tol) and a variant is left;
-// err[1..3] = the centre variant's figures (vpt_test_get_dir_table_check), err[5] = variants in use.
+// The verdicts the tail reads.  Per variant: against real rays through the full path no ray is off by more than 2 %, at most 0.5 % of them are
+// UNFLIPPED rays off by more than 1e-3 (the image tolerance is 1e-3 rel. L2) and at most 5 % are flipped ones (see above: their mean is what a smooth
+// cache returns, 1e-4 of the radiance) -- a variant that fails loses its table (SkyView::tab[v].w = 0: its ground hits are evaluated in full).  err[4] = 1 when the interpolant follows its nodes (err[0] <= tol) and a variant is left;
+// err[1..3], err[6] = the centre variant's figures (vpt_test_get_dir_table_check / _flips), err[5] = variants in use.
 __global__ void sky_dir_table_verdict_kernel(unsigned long long* err, SkyView* view, float tol) {
     const int k = view->k;
     unsigned long long in_use = 0;
     for (int v = 0; v <= 2 * k; ++v) {
         const unsigned long long* e = err + 8 + 4 * v;
         const float worst = __uint_as_float((uint32_t)(e[0] >> 32));
-        // ... and its 99th percentile within VPT_DIR_TAB_P99 (2e-3: the per-pixel bound the full-size tests hold every config to): behind an
-        // open lens the off-centre variants meet the ground point's binary32 radius flip more often than the centre one
-        const bool ok = view->tab[v].w != 0.0f && e[1] > 0ull && worst <= 2e-2f && e[2] * 50ull <= e[1] && e[3] * 100ull <= e[1];
+        const bool ok = view->tab[v].w != 0.0f && e[1] > 0ull && worst <= 2e-2f && e[2] * 200ull <= e[1] && e[3] * 20ull <= e[1];
         if (!ok) view->tab[v].w = 0.0f;
         in_use += ok ? 1ull : 0ull;
     }
-    err[1] = err[8 + 4 * k]; err[2] = err[8 + 4 * k + 1]; err[3] = err[8 + 4 * k + 2];
+    err[1] = err[8 + 4 * k]; err[2] = err[8 + 4 * k + 1]; err[3] = err[8 + 4 * k + 2]; err[6] = err[8 + 4 * k + 3];
     err[5] = in_use;
     err[4] = (__uint_as_float((uint32_t)(err[0] >> 32)) <= tol && in_use != 0ull) ? 1ull : 0ull;
 }
