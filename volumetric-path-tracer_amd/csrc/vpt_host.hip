@@ -222,6 +222,14 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (ctx->tex_fixed8) ctx->counting = true;       // a diagnostic: carried by the counting instantiations of the tracers only (make_taps)
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->no_async_tail = std::getenv("VPT_NO_ASYNC_TAIL") != nullptr;
+    if (!ctx->no_async_tail) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_traced[i], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tailed[i], hipEventDisableTiming));
+        }
+    }
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
     HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
@@ -240,7 +248,16 @@ void vpt_destroy(vpt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
+    if (ctx->render_stream && ctx->render_stream != ctx->stream) (void)hipStreamSynchronize(ctx->render_stream);
     (void)vpt_comm_destroy(ctx);
+    (void)hipFree(ctx->alt.records); (void)hipFree(ctx->alt.queue); (void)hipFree(ctx->alt.heads); (void)hipFree(ctx->alt.head_org);
+    (void)hipFree(ctx->alt.td); (void)hipFree(ctx->alt.queue2); (void)hipFree(ctx->alt.bn_table); (void)hipFree(ctx->alt.wc);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_traced[i]) (void)hipEventDestroy(ctx->ev_traced[i]);
+        if (ctx->ev_tailed[i]) (void)hipEventDestroy(ctx->ev_tailed[i]);
+    }
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     (void)hipFree(ctx->d_comm_buf);
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
@@ -279,6 +296,26 @@ void vpt_destroy(vpt_ctx* ctx) {
     delete ctx;
 }
 
+// orders `stream` behind the tail a previous render left out on the tail stream (vpt_ctx.h)
+int vpt_join_tail(vpt_ctx* ctx, hipStream_t stream) {
+    if (!ctx->tail_unjoined) return VPT_OK;
+    HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[ctx->last_set], 0));
+    ctx->tail_unjoined = false;
+    return VPT_OK;
+}
+// frees and reallocations of what kernels of this context may still read: every stream it has work on, idle
+static int quiesce_all(vpt_ctx* ctx, hipStream_t stream) {
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));
+    if (ctx->tail_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tail_stream));
+    ctx->tail_unjoined = false;
+    ctx->tail_pending[0] = ctx->tail_pending[1] = false;
+    return VPT_OK;
+}
+
+// The context's own stream.  NOTE: a render issued with stream = NULL leaves its last tail on a second, internal stream (vpt_ctx.h): its results
+// are complete after vpt_sync (or once any later vpt_* call that touches them has been ordered behind it) -- not when THIS stream drains.  A host that
+// orders its own work against this handle calls vpt_sync first, or renders on a stream of its own (such a render joins before it returns).
 void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int vpt_sync(vpt_ctx* ctx) {
@@ -341,6 +378,7 @@ int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
     TexEntry& t = ctx->textures[tex - 1];
     if (t.owned) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->tail_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tail_stream));      // (a tail still out may read this table)
         HIPCHK(ctx, hipFree(t.owned));
     }
     t.live = false;
@@ -700,7 +738,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
     out->samples = ctx->last_samples;
     {
         uint32_t wc[9] = {0};
-        HIPCHK(ctx, hipMemcpy(wc, ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(wc, ctx->last_wc ? ctx->last_wc : ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
         out->queued_rays = wc[8];
     }
     if (ctx->counting) {
@@ -995,6 +1033,7 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     // earlier collective still uses
     if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
     if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));
+    { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }      // (the last render's tail writes the buffer this reduces)
     if (ctx->comm_buf_floats < (size_t)n_floats + 1u) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
         if (ctx->comm_stream && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
@@ -1082,6 +1121,11 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // (on the device) behind that one's last kernel
     if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
     if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));   // (the reduce rewrites the caller's accumulation buffer)
+    // A batch runs its tails on the context's tail stream (vpt_ctx.h); the per-frame call and counting renders keep everything on `stream`.  A tail the
+    // previous render left out is joined here unless this render continues the pipeline on the same stream (its own tails queue behind it in order, its
+    // raygen waits per buffer set, a cache rebuild joins in vpt_view_caches_prepare).
+    const bool pipelined = ctx->tail_stream != nullptr && !ctx->counting && !ctx->use_pool && iter_count >= 2u;
+    if (ctx->tail_unjoined && (!pipelined || stream != ctx->tail_origin)) { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }
 
     // ---- resolve-side parameters
     ResolveParams R;
@@ -1221,8 +1265,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                        std::memcmp(ctx->lights_cache.data(), lights->light_ptr, n * sizeof(DPointLight)) != 0;
         if (changed) {
             if (ctx->lights_capacity < n) {
-                HIPCHK(ctx, hipStreamSynchronize(stream));
-                if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
+                { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
                 (void)hipFree(ctx->d_lights);
                 HIPCHK(ctx, hipMalloc(&ctx->d_lights, n * sizeof(DPointLight)));
                 ctx->lights_capacity = n;
@@ -1243,8 +1286,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (chunk > iter_count) chunk = iter_count;
     if (ctx->batch_iters > 0) chunk = std::min<size_t>(std::min<size_t>((size_t)ctx->batch_iters, iter_count), 64);     // (ResolveParams::rcp_n, split_slot: <= 64 per launch)
     if (ctx->records_capacity < chunk * per_iter) {
-        HIPCHK(ctx, hipStreamSynchronize(stream));
-        if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
+        { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
         (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
@@ -1260,8 +1302,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         ctx->records_capacity = chunk * per_iter;
     }
     if (ctx->bn_capacity < chunk) {
-        HIPCHK(ctx, hipStreamSynchronize(stream));
-        if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
+        { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_bn_table); ctx->d_bn_table = nullptr;
         HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, chunk * 65536 * sizeof(float2)));
         ctx->bn_capacity = chunk;
@@ -1275,8 +1316,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.head_org = nullptr;
     if (compact && cam->lens_radius != 0.0f) {
         if (ctx->head_org_capacity < ctx->records_capacity) {
-            HIPCHK(ctx, hipStreamSynchronize(stream));
-            if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));   // (the previous render may have run elsewhere)
+            { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
             (void)hipFree(ctx->d_head_org); ctx->d_head_org = nullptr; ctx->head_org_capacity = 0;
             HIPCHK(ctx, hipMalloc(&ctx->d_head_org, ctx->records_capacity * sizeof(float4)));
             ctx->head_org_capacity = ctx->records_capacity;
@@ -1319,10 +1359,60 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->use_pool ? 3 : (kp->integrator != 0 ? trace_vol_blocks_per_cu(kp->environment_type == 0) : trace_blocks_per_cu()));
     const int max_blocks = ctx->num_cus * blocks_per_cu;
 
+    // the two sets of per-chunk buffers (vpt_ctx.h): set 0 = the context's d_* fields, as P and R hold them now; set 1 = `alt`
+    vpt_ctx::ChunkBufs set0;
+    set0.records = ctx->d_records; set0.queue = ctx->d_queue; set0.heads = ctx->d_heads; set0.head_org = ctx->d_head_org; set0.td = ctx->d_td;
+    set0.queue2 = ctx->d_queue2; set0.bn_table = ctx->d_bn_table; set0.wc = ctx->d_work_counter;
+    auto point_at = [&](const vpt_ctx::ChunkBufs& B) {
+        P.records = B.records; R.records = B.records;
+        if (P.heads) { P.heads = B.heads; R.heads = B.heads; }
+        if (P.head_org) { P.head_org = B.head_org; R.head_org = B.head_org; }
+        P.queue = B.queue; P.queue_tail = B.wc + 8; P.queue_count = B.wc + 8; P.work_counter = B.wc;
+        P.blue_noise = B.bn_table;
+        if (R.blue_noise) R.blue_noise = B.bn_table;
+        if (R.lean) {
+            R.td = B.td; R.queue2 = B.queue2; R.queue2_count = B.wc + 4;
+            P.resolve.heads = B.heads; P.resolve.td = B.td; P.resolve.queue2 = B.queue2; P.resolve.queue2_tail = B.wc + 4;
+        }
+    };
+    int last_p = 0;
     for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {
         const unsigned int n = (unsigned int)std::min<size_t>(chunk, iter_count - done);
         const unsigned int it0 = kp->iteration + done * iter_stride;
         const bool last = done + n >= iter_count;
+        const int p = pipelined ? (int)(ctx->chunk_parity++ & 1u) : 0;
+        if (p == 1) {
+            // set 1 mirrors set 0's capacities; (re)allocated with every stream of the context idle
+            const bool lens_org = P.head_org != nullptr;
+            if (ctx->alt_records_capacity < ctx->records_capacity || ctx->alt_bn_capacity < ctx->bn_capacity || (lens_org && ctx->alt_head_org_capacity < ctx->head_org_capacity) ||
+                (R.lean && ctx->alt_td_capacity < ctx->td_capacity)) {
+                { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
+                vpt_ctx::ChunkBufs& A = ctx->alt;
+                (void)hipFree(A.records); (void)hipFree(A.queue); (void)hipFree(A.heads); (void)hipFree(A.head_org); (void)hipFree(A.td); (void)hipFree(A.queue2); (void)hipFree(A.bn_table);
+                A.records = nullptr; A.queue = nullptr; A.heads = nullptr; A.head_org = nullptr; A.td = nullptr; A.queue2 = nullptr; A.bn_table = nullptr;
+                ctx->alt_records_capacity = ctx->alt_bn_capacity = ctx->alt_head_org_capacity = ctx->alt_td_capacity = 0;
+                hipError_t e = hipMalloc(&A.records, ctx->records_capacity * sizeof(Record));
+                if (e == hipSuccess) e = hipMalloc(&A.queue, ctx->records_capacity * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMalloc(&A.heads, ctx->records_capacity * sizeof(float4));
+                if (e == hipSuccess) e = hipMalloc(&A.bn_table, ctx->bn_capacity * 65536 * sizeof(float2));
+                if (e == hipSuccess && ctx->head_org_capacity) e = hipMalloc(&A.head_org, ctx->head_org_capacity * sizeof(float4));
+                if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.td, ctx->td_capacity * sizeof(float2));
+                if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.queue2, ctx->td_capacity * sizeof(uint32_t));
+                if (e == hipSuccess && !A.wc) e = hipMalloc(&A.wc, 16 * sizeof(uint32_t));
+                if (e != hipSuccess) {
+                    set_error(ctx, "vpt_render: hipMalloc of the second set of per-chunk buffers failed: %s (VPT_NO_ASYNC_TAIL=1 renders with one set)", hipGetErrorString(e));
+                    return VPT_E_NOMEM;
+                }
+                ctx->alt_records_capacity = ctx->records_capacity; ctx->alt_bn_capacity = ctx->bn_capacity;
+                ctx->alt_head_org_capacity = ctx->head_org_capacity; ctx->alt_td_capacity = ctx->td_capacity;
+            }
+        }
+        point_at(p ? ctx->alt : set0);
+        // this set is rewritten from here on: behind the tail that last read it
+        if (ctx->tail_pending[p]) {
+            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[p], 0));
+            ctx->tail_pending[p] = false;
+        }
         P.iter_begin = it0; P.iter_count = n;
         R.iter_begin = it0; R.iter_count = n;
         for (unsigned int k = 0; k < 64u; ++k) {
@@ -1331,19 +1421,20 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         }
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 16 * sizeof(uint32_t), stream));
-        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), ctx->d_bn_table, n, iter_stride,
+        HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
+        ctx->last_wc = P.work_counter;
+        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), const_cast<float2*>(P.blue_noise), n, iter_stride,
                                       (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull), stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
         if (blocks < 1) blocks = 1;
         // HIP events on the launch stream around every stage (one span per kernel)
-        int ev[5], rc;
-        for (int i = 0; i < 5; i += 2) {
+        int ev[6], rc;
+        for (int i = 0; i < 6; i += 2) {
             int a, b;
             if ((rc = get_events(ctx, &a, &b)) != 0) return rc;
             ev[i] = a;
-            if (i + 1 < 5) ev[i + 1] = b;
+            ev[i + 1] = b;
         }
         P.chunk = total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK;
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
@@ -1357,7 +1448,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             if (trace_vol_hist_floats_per_block() != 0u) {
                 const size_t need = trace_vol_hist_floats_per_block() * (size_t)max_blocks;
                 if (ctx->pool_hist_floats < need) {
-                    HIPCHK(ctx, hipStreamSynchronize(stream));
+                    { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
                     (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = 0;
                     HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, need * sizeof(float)));
                     ctx->pool_hist_floats = need;
@@ -1378,11 +1469,41 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
-        if (R.lean) HIPCHK(ctx, launch_tail_stream(R, stream));  // sky_fix_kernel over what the dome did not serve, then the streaming tail
-        else HIPCHK(ctx, launch_tail_resolve(R, stream));        // environment tail + resolve, fused
+        // sky_fix_kernel (what the dome did not serve: reads path records and the queue the tracer filled) stays on the tracer's stream ...
+        if (R.lean) HIPCHK(ctx, launch_sky_fix(R, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));
-        for (int k = 0; k < 3; ++k) ctx->spans.push_back({ev[k], ev[k + 1], k});
+        // ... the running means (streaming tail / environment tail + resolve) go to the tail stream: under the next chunk's raygen
+        hipStream_t ts = stream;
+        if (pipelined) {
+            ts = ctx->tail_stream;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_traced[p], stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_traced[p], 0));
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[4]], ts));
+        if (R.lean) HIPCHK(ctx, launch_tail_stream(R, ts));
+        else HIPCHK(ctx, launch_tail_resolve(R, ts));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[5]], ts));
+        if (pipelined) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_tailed[p], ts));
+            ctx->tail_pending[p] = true;
+            last_p = p;
+        }
+        ctx->spans.push_back({ev[0], ev[1], 0});
+        ctx->spans.push_back({ev[1], ev[2], 1});
+        ctx->spans.push_back({ev[2], ev[3], 2});
+        ctx->spans.push_back({ev[4], ev[5], 2});
         ctx->last_samples += total;
+    }
+    if (pipelined) {
+        ctx->last_set = last_p;
+        if (stream == ctx->stream) {
+            // the context's own stream: the last tail stays out, the next render's raygen overlaps it (vpt_sync, or whatever touches the results, joins)
+            ctx->tail_unjoined = true;
+            ctx->tail_origin = stream;
+        } else {
+            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[last_p], 0));      // a caller's stream: its completion is the render's
+            ctx->tail_unjoined = false;
+        }
     }
     if (!ctx->render_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->render_event, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(ctx->render_event, stream));
@@ -1401,6 +1522,7 @@ int vpt_resolve_display(vpt_ctx* ctx, const vpt_kernel_params* kp, void* stream_
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const unsigned long long n = (unsigned long long)kp->resolution.x * kp->resolution.y;
     if (n == 0 || n > 0xffffffffull) return VPT_E_INVALID;
+    { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }
     HIPCHK(ctx, launch_display(reinterpret_cast<const float*>(kp->accum_buffer), kp->display_buffer, reinterpret_cast<float*>(kp->raw_buffer), (uint32_t)n,
                                kp->exposure_scale, stream));
     return VPT_OK;

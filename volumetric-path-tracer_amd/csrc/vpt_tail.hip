@@ -507,8 +507,11 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
     }
     rm.store(R, idx);
 }
-hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream) {
+hipError_t launch_sky_fix(const ResolveParams& R, hipStream_t stream) {
     hipLaunchKernelGGL(sky_fix_kernel, dim3(512), dim3(256), 0, stream, R, const_cast<float4*>(R.heads));
+    return hipGetLastError();
+}
+hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream) {
     hipLaunchKernelGGL(tail_stream_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
     return hipGetLastError();
 }
