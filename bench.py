@@ -71,11 +71,12 @@ def flips_block(lib, hb):
     """share of the ground table's check rays whose binary32 ground point the full path finds one step (0.5 m) above the ground: the reference's own
     ray-to-ray noise, gated apart from the table's deviation (csrc/vpt_tail.hip: sky_dir_table_rays_kernel)"""
     import ctypes as C
-    f = (C.c_float * 2)()
-    lib.vpt_test_get_dir_table_flips.argtypes = [C.c_void_p, C.POINTER(C.c_float * 2)]
+    f = (C.c_float * 4)()
+    lib.vpt_test_get_dir_table_flips.argtypes = [C.c_void_p, C.POINTER(C.c_float * 4)]
     if lib.vpt_test_get_dir_table_flips(hb.ctx.h, C.byref(f)) != 0:
         return None
-    return {"fraction_centre_variant": float(f[0]), "largest_fraction_all_variants": float(f[1]), "accepted_fraction": 0.05}
+    return {"fraction_centre_variant": float(f[0]), "largest_fraction_all_variants": float(f[1]),
+            "mean_cost_centre_variant": float(f[2]), "largest_mean_cost_all_variants": float(f[3]), "accepted_mean_cost": 3e-4}
 
 
 def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator, lean=False):
@@ -491,7 +492,14 @@ def main():
         h1.render(sppc, iteration=0)
         h1.sync()
         got, ref = h1.accum.cpu().numpy().astype(np.float64), ob.accum.astype(np.float64)
-        rel = float(np.sqrt(((got - ref) ** 2).sum()) / max(1e-30, np.sqrt((ref ** 2).sum())))
+        # the point light's falloff is 1 / length(lp * lp - pp * pp) (light.h:104-121 as written): a handful of samples land where that vanishes and
+        # come out at 1e30 and more on BOTH sides -- an image-wide L2 is then the last bits of those fireflies.  The figure is taken over the pixels
+        # below the 99.9th percentile of the reference's brightness; the rest are counted and compared RELATIVELY, pixel by pixel.
+        lum = ref.max(1)
+        keep = lum <= np.quantile(lum, 0.999)
+        rel = float(np.sqrt(((got[keep] - ref[keep]) ** 2).sum()) / max(1e-30, np.sqrt((ref[keep] ** 2).sum())))
+        ff = ~keep
+        ff_rel = float((np.abs(got[ff] - ref[ff]).max(1) / np.maximum(lum[ff], 1e-30)).max()) if ff.any() else 0.0
         ddiff = int((h1.depth.cpu().numpy() != ob.depth).sum())
         bn1 = h1.blue_noise.clone()
         torch.cuda.synchronize(dev)
@@ -506,7 +514,9 @@ def main():
                         "kind": "reference" if use_ref else "port",
                         "what": "the reference's render_kernel.cu built for the host (oracle/_ref), 1 thread, all 16 iterations" if use_ref else "oracle, 1 thread, all 16 iterations"},
                 "hip": {"value": round(Wc * Hc * sppc / dth / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 4)},
-                "parity_rel_l2": rel, "parity_depth_pixels_differing": ddiff, "tolerance": 1e-3}
+                "parity_rel_l2": rel, "parity_depth_pixels_differing": ddiff, "tolerance": 1e-3,
+                "parity_note": "relative L2 over the pixels below the 99.9th percentile of the reference's brightness; the %d brighter ones (fireflies of the point light's "
+                               "falloff, up to %.1e) agree to %.1e of their own value" % (int(ff.sum()), float(lum.max()), ff_rel)}
 
     def cpu_baseline(hb, sd, bn0, W, H, spp):
         host_grids = all(isinstance(v[1], np.ndarray) for v in sd.volumes)

@@ -45,13 +45,14 @@ int vpt_test_get_dir_table_error(vpt_ctx *ctx, int *built, float *err, unsigned 
  * between the table path and the FULL path (the reference's arithmetic) of sample_atmosphere along real view rays from the
  * camera origin, one per reachable cell centre; out[2] = rays compared; out[3] = rays that differ by more than 1e-3;
  * out[4] = 1 when the tail uses the tables (out[0] <= tolerance and at least one variant passed: worst ray <= 2e-2, at most 0.5 % of
- * its rays unflipped and off by more than 1e-3, at most 5 % flipped -- a variant that fails loses its table); out[5] = variants in use (1 behind a closed lens, up to
+ * its rays unflipped and off by more than 1e-3, the flipped ones costing at most 3e-4 on average -- a variant that fails loses its table); out[5] = variants in use (1 behind a closed lens, up to
  * 2 k + 1 behind an open one); out[6], out[7] = the worst ray and the largest share of rays above 1e-3 over ALL checked variants */
 int vpt_test_get_dir_table_check(vpt_ctx *ctx, float out[8]);
 /* round 5: the check above counts in out[3] / out[7] only UNFLIPPED rays (gate: at most 0.5 % of a variant's rays); a ray is FLIPPED when the full
  * path finds its binary32 ground point one step (0.5 m) above the ground -- the reference's own ray-to-ray noise, which a smooth table cannot and
- * should not follow.  out[0] = share of flipped rays of the centre variant, out[1] = the largest share over all checked variants (gate: 5 %) */
-int vpt_test_get_dir_table_flips(vpt_ctx *ctx, float out[2]);
+ * should not follow.  out[0] = share of flipped rays of the centre variant, out[1] = the largest share over all checked variants; out[2], out[3] = what
+ * they cost a smooth cache on average -- the flipped rays' summed deviation over ALL rays -- for the centre variant / the largest over all (gate: 3e-4) */
+int vpt_test_get_dir_table_flips(vpt_ctx *ctx, float out[4]);
 /* sample_atmosphere (render_kernel.cu:839-895) as the environment tail of the last render evaluates it, along n unit directions
  * dirs[3n] -> out[3n], from origins[3n] (scene coordinates) or, origins == NULL, from that render's view point; use_table: ground
  * hits through the view-point ground tables (when the last render had them within tolerance), else in full */

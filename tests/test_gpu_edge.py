@@ -285,3 +285,101 @@ def test_image_plane_quotients_by_checked_reciprocal(pkg, monkeypatch, size):
         assert a.accum.abs().max() > 0
         for buf in ("accum", "depth", "raw", "display", "blue_noise"):
             np.testing.assert_array_equal(getattr(a, buf).cpu().numpy(), getattr(b, buf).cpu().numpy())
+
+
+# ---- round 5: host-side scheduling that must change no bit -----------------------------------------------------------------------------
+
+def _frame_scene(pkg, kind):
+    import ctypes as C
+    if kind == "dragon sun+sky":
+        sd = pkg.scene.dragon_scene(256, 144, "c2")
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    elif kind == "dragon sun only":
+        sd = pkg.scene.dragon_scene(256, 144, "sun")
+    elif kind == "fireball sun+sky":
+        sd = pkg.scene.fireball_scene(192, 108, n=48, sky=True)
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    elif kind == "instances open lens":
+        sd = pkg.scene.instanced_scene(256, 144, n=32, grid=3, aperture=2.0, sky=True)
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    else:
+        sd = pkg.scene.cloud_scene(192, 108, shape=(48, 40, 56), env=(128, 64), integrator=1)
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    return sd
+
+
+@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "instances open lens", "cloud vol_integrator"])
+def test_frame_ahead_changes_nothing(pkg, monkeypatch, kind):
+    """FRAME-AHEAD (csrc/vpt_ctx.h): from the second identical one-iteration call on, vpt_render traces the rays of the next 2, 4, 8, 16 iterations in
+    one raygen + tracer launch and the following calls run only their tail.  Against VPT_NO_FRAME_AHEAD=1 (one launch per frame, as rounds 1-4):
+    EVERY buffer after EVERY frame is bit-identical -- accumulation, cost, depth, raw, display and the caller's blue-noise state -- through the growth
+    of the batches, a camera move in the middle of a batch (what was traced ahead is discarded), and a return to the first camera."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    sd = _frame_scene(pkg, kind)
+    lib = pkg.load_library()
+    frames, move_at, back_at = 23, 9, 14
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        cam0 = type(hb.sd.camera).from_buffer_copy(hb.sd.camera)
+        out = []
+        for f in range(frames):
+            if f == move_at:
+                o = hb.sd.camera.origin
+                lib.vpt_camera_update(C.byref(hb.sd.camera), Float3(o.x * 0.9, o.y * 1.05, o.z * 0.95), Float3(0.0, 0.0, 0.0), Float3(0, 1, 0), 40.0,
+                                      sd.width / sd.height, float(2.0 * hb.sd.camera.lens_radius))
+            if f == back_at:
+                C.memmove(C.byref(hb.sd.camera), C.byref(cam0), C.sizeof(cam0))
+            hb.render_frame()
+            hb.sync()
+            out.append({b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")})
+        C.memmove(C.byref(hb.sd.camera), C.byref(cam0), C.sizeof(cam0))
+        hb.ctx.close()
+        return out
+    a = run()
+    monkeypatch.setenv("VPT_NO_FRAME_AHEAD", "1")
+    b = run()
+    assert np.isfinite(a[-1]["accum"]).all() and a[-1]["accum"].max() > 0
+    for f in range(frames):
+        for k in a[f]:
+            np.testing.assert_array_equal(a[f][k], b[f][k], err_msg="frame %d, %s" % (f, k))
+
+
+@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "instances open lens", "cloud vol_integrator"])
+def test_tails_on_their_own_stream_change_nothing(pkg, monkeypatch, kind):
+    """VPT_ASYNC_TAIL=1 (a study switch: measured without gain, profiles/r05_async_tail.txt): the running means of a chunk run on the context's tail
+    stream, under the next chunk's raygen, out of a second set of per-chunk buffers (csrc/vpt_ctx.h).  Against the default (every kernel on the one
+    stream): every buffer bit-identical -- over several batches back to back
+    WITHOUT a host sync in between (the last tail of one render overlaps the next render's raygen), chunked batches (launch boundaries inside a
+    render: both buffer sets in one call), a one-iteration frame and a view change between batches (the caches are rebuilt behind the tail that reads them)."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    sd = _frame_scene(pkg, kind)
+    lib = pkg.load_library()
+    monkeypatch.setenv("VPT_BATCH_ITERS", "3")
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        cam0 = type(hb.sd.camera).from_buffer_copy(hb.sd.camera)
+        hb.render(7)                      # 3 + 3 + 1: three chunks
+        hb.render(3)
+        hb.render(2)
+        hb.render_frame()
+        hb.render(4)
+        o = hb.sd.camera.origin
+        lib.vpt_camera_update(C.byref(hb.sd.camera), Float3(o.x * 0.9, o.y * 1.05, o.z * 0.95), Float3(0.0, 0.0, 0.0), Float3(0, 1, 0), 40.0,
+                              sd.width / sd.height, float(2.0 * hb.sd.camera.lens_radius))
+        hb.render(5)
+        hb.render(2)
+        hb.sync()
+        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+        C.memmove(C.byref(hb.sd.camera), C.byref(cam0), C.sizeof(cam0))
+        hb.ctx.close()
+        return out
+    a = run()
+    monkeypatch.setenv("VPT_ASYNC_TAIL", "1")
+    b = run()
+    assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -330,6 +330,8 @@ int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
     ctx->dir_tab_built = false;
     ctx->sky_patch_built = false;
     ctx->lens_dome_built = false;
+    ctx->ahead.key_valid = false;            // (rays traced ahead looked at the old tables)
+    ctx->ahead.n = 0;
     return VPT_OK;
 }
 

@@ -76,6 +76,7 @@ struct vpt_ctx {
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
     uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
+    uint32_t raygen_small_iters = 8; // VPT_RAYGEN_SMALL_ITERS: launches of fewer iterations run raygen over 16-row tiles (TraceParams::raygen_small_iters)
     // pool tracer (csrc/variants/vpt_trace_pool.hip, study builds with -DVPT_WITH_POOL only): direct_integrator with the rays in an LDS pool per CU
     bool use_pool = false;         // VPT_TRACER=pool in such a build: measured slower than the lane-bound tracer, kept as the evidence and for A/B runs
     int pool_waves = 12;           // VPT_POOL_WAVES: waves of the one workgroup per CU (8..12)
@@ -177,7 +178,7 @@ struct vpt_ctx {
     hipStream_t render_stream = nullptr;   // the stream of the previous render
     hipEvent_t comm_event = nullptr;       // recorded behind every vpt_allreduce_accum's last kernel
     hipStream_t comm_stream = nullptr;     // the stream of the previous collective
-    // THE TAIL RUNS ON ITS OWN STREAM (round 5): the running means of a chunk (tail_stream_kernel / tail_resolve_kernel: streaming, latency-bound) overlap
+    // THE TAIL ON ITS OWN STREAM (round 5; a STUDY switch, VPT_ASYNC_TAIL=1 -- measured without gain, see vpt_create): the running means of a chunk (tail_stream_kernel / tail_resolve_kernel: streaming, latency-bound) overlap
     // the next chunk's raygen (VALU-bound) instead of queueing in front of it.  Everything the tail reads per chunk exists twice (records, queue,
     // heads, origins, {alpha, depth}, queue2, jitter table, work counters: the context's d_* fields are set 0, `alt` is set 1; allocated when first used),
     // chunks alternate between the sets, a set is rewritten only behind the tail that last read it (ev_tailed), tails run in order on `tail_stream` (the
@@ -197,7 +198,25 @@ struct vpt_ctx {
     bool tail_unjoined = false;            // the last render's final tail is out on tail_stream and nothing has been ordered behind it yet
     hipStream_t tail_origin = nullptr;     // ... and that render's stream
     const uint32_t* last_wc = nullptr;     // work counters of the last chunk launched (vpt_get_stats: queued rays)
-    bool no_async_tail = false;            // VPT_NO_ASYNC_TAIL: every kernel of a render on the one stream, as rounds 1-4 (tests, A/B)
+    bool no_async_tail = true;             // the default: every kernel of a render on the one stream, as rounds 1-4; VPT_ASYNC_TAIL=1 clears it
+    // FRAME-AHEAD (round 5): the reference's host loop is ONE launch + device sync per iteration (main.cpp:1822-1829), and a one-iteration launch of the
+    // persistent tracer lasts as long as its longest paths whatever the machine could do meanwhile (0.19 of the frame's 0.35 ms at 1080p).  A still camera
+    // repeats the same call with iteration + 1: from the second such call on, a call traces the rays of the NEXT iterations as well (2, 4, 8, ... up to
+    // max_k per call, one raygen + tracer launch at the batch's occupancy) but accumulates only its own; the following calls find their rays traced and
+    // run only their tail.  Every sample is the same Philox-keyed function of (pixel, iteration) either way and the running means take the iterations in
+    // the same order: every buffer after every frame is bit-identical to the frame-by-frame sequence (tests/test_gpu_edge.py).  A call that does not
+    // continue the sequence (another camera, light, parameter, buffer, stream; a batch; a scene or texture change) discards what was traced ahead: the
+    // cost of a camera move is the <= max_k iterations of rays traced for nothing, once.
+    struct FrameAhead {
+        bool off = false;                  // VPT_NO_FRAME_AHEAD
+        unsigned max_k = 16;               // VPT_FRAME_AHEAD_MAX
+        bool key_valid = false;
+        std::vector<unsigned char> key;    // what a one-iteration call is a function of, its iteration index excluded (bytes of the argument structs)
+        unsigned last_it = 0;              // iteration of the previous call
+        unsigned streak = 0;               // consecutive calls with the same key and iteration = previous + 1
+        unsigned it0 = 0, n = 0, next = 0; // rays of iterations it0 .. it0 + n - 1 are traced (buffer set 0); slices [next, n) still wait for their tail
+        float* d_bn = nullptr;             // private copy of the caller's blue-noise state the batch's jitter tables are generated from
+    } ahead;
     bool counters_dirty = true;            // d_counters holds counts of an earlier counted render
     // stats
     bool counting = false;

@@ -30,7 +30,8 @@ enum { SKY_VIEW_MAX_K = 4 };
 #define VPT_SKY_DOME_NV 1024
 #endif
 enum { SKY_DOME_NU = VPT_SKY_DOME_NU, SKY_DOME_NV = VPT_SKY_DOME_NV };          // sky dome nodes (ResolveParams::sky_dome): float4 each
-enum { SKY_DIR_ERR_WORDS = 8 + 4 * (2 * SKY_VIEW_MAX_K + 1) };   // u64 words of the ground table's build-time check (vpt_tail.hip: launch_sky_dir_table)
+enum { SKY_DIR_ERR_STRIDE = 6 };      // u64 words per table variant: worst ray (key), rays, unflipped rays above 1e-3, flipped rays, their summed deviation (2^-24 units), spare
+enum { SKY_DIR_ERR_WORDS = 8 + SKY_DIR_ERR_STRIDE * (2 * SKY_VIEW_MAX_K + 1) };   // u64 words of the ground table's build-time check (vpt_tail.hip: launch_sky_dir_table)
 struct SkyView {
     float r, mu_s;         // of the camera origin, with the tail's own arithmetic
     int k;                 // variants: r + (-k .. k) binary32 steps
@@ -184,6 +185,7 @@ struct TraceParams {
     uint32_t regen_min;              // refill when at least this many lanes of a wave are idle
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
     uint32_t chunk;                  // queue entries a wave claims per global atomic: VPT_CHUNK, half of it for launches of a few iterations
+    uint32_t raygen_small_iters;     // launches of fewer iterations run raygen over 16-row tiles (four times the blocks)
     uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor

@@ -222,7 +222,13 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (ctx->tex_fixed8) ctx->counting = true;       // a diagnostic: carried by the counting instantiations of the tracers only (make_taps)
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->no_async_tail = std::getenv("VPT_NO_ASYNC_TAIL") != nullptr;
+    if (const char* e = std::getenv("VPT_RAYGEN_SMALL_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) ctx->raygen_small_iters = (uint32_t)v; }
+    ctx->ahead.off = std::getenv("VPT_NO_FRAME_AHEAD") != nullptr;
+    if (const char* e = std::getenv("VPT_FRAME_AHEAD_MAX")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->ahead.max_k = (unsigned)v; }
+    // MEASURED AND NOT ADOPTED (profiles/r05_async_tail.txt): the overlap buys nothing -- raygen and the tail slow each other down by what they overlap
+    // (config 2: 5.758 vs 5.759 ms per step) and on configs 4 / 5 the tail spills under the TRACER and costs it waves (97.4 -> 110.7 ms, 140.5 -> 143.9 ms).
+    // Off unless VPT_ASYNC_TAIL=1 (the bit-identity test runs it).
+    ctx->no_async_tail = std::getenv("VPT_ASYNC_TAIL") == nullptr || std::getenv("VPT_NO_ASYNC_TAIL") != nullptr;
     if (!ctx->no_async_tail) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
@@ -251,6 +257,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->render_stream && ctx->render_stream != ctx->stream) (void)hipStreamSynchronize(ctx->render_stream);
     (void)vpt_comm_destroy(ctx);
+    (void)hipFree(ctx->ahead.d_bn);
     (void)hipFree(ctx->alt.records); (void)hipFree(ctx->alt.queue); (void)hipFree(ctx->alt.heads); (void)hipFree(ctx->alt.head_org);
     (void)hipFree(ctx->alt.td); (void)hipFree(ctx->alt.queue2); (void)hipFree(ctx->alt.bn_table); (void)hipFree(ctx->alt.wc);
     for (int i = 0; i < 2; ++i) {
@@ -462,6 +469,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     // the previous scene's device arrays are released below: until this call succeeds there is no scene to render
     ctx->scene_ready = false;
     ctx->any_color = ctx->any_emission = false;
+    ctx->ahead.key_valid = false; ctx->ahead.n = 0;            // (rays traced ahead walked the previous scene)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (void* b : ctx->bricked) (void)hipFree(b);
     ctx->bricked.clear();
@@ -720,6 +728,7 @@ int vpt_scene_get_octree_stats(vpt_ctx* ctx, int out_nonempty[3]) {
 int vpt_set_counting(vpt_ctx* ctx, int enable) {
     if (!ctx) return VPT_E_INVALID;
     ctx->counting = enable != 0 || ctx->tex_fixed8;          // (the fixed8 diagnostic lives in the counting instantiations)
+    ctx->ahead.key_valid = false; ctx->ahead.n = 0;
     return VPT_OK;
 }
 
@@ -852,7 +861,7 @@ int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {
     // over the variants that had a table to check: worst ray, and the largest share of rays off by more than 1e-3
     float worst = 0.0f, share = 0.0f;
     for (int v = 0; v < 2 * SKY_VIEW_MAX_K + 1; ++v) {
-        const unsigned long long* e = w + 8 + 4 * v;
+        const unsigned long long* e = w + 8 + SKY_DIR_ERR_STRIDE * v;
         if (e[1] == 0ull) continue;
         const uint32_t bb = (uint32_t)(e[0] >> 32);
         float f;
@@ -865,19 +874,23 @@ int vpt_test_get_dir_table_check(vpt_ctx* ctx, float out[8]) {
     return VPT_OK;
 }
 
-int vpt_test_get_dir_table_flips(vpt_ctx* ctx, float out[2]) {
+int vpt_test_get_dir_table_flips(vpt_ctx* ctx, float out[4]) {
     if (!ctx || !out) return VPT_E_INVALID;
-    out[0] = out[1] = 0.0f;
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
     if (!ctx->dir_tab_built) return VPT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
     unsigned long long w[SKY_DIR_ERR_WORDS] = {0};
     HIPCHK(ctx, hipMemcpy(w, ctx->d_dir_err, sizeof(w), hipMemcpyDeviceToHost));
-    if (w[2] != 0ull) out[0] = (float)((double)w[6] / (double)w[2]);        // (the verdict kernel copies the centre variant's figures to err[1..3], err[6])
+    if (w[2] != 0ull) {          // (the verdict kernel copies the centre variant's figures to err[1..3], err[6], err[7])
+        out[0] = (float)((double)w[6] / (double)w[2]);
+        out[2] = (float)((double)w[7] / 16777216.0 / (double)w[2]);
+    }
     for (int v = 0; v < 2 * SKY_VIEW_MAX_K + 1; ++v) {
-        const unsigned long long* e = w + 8 + 4 * v;
+        const unsigned long long* e = w + 8 + SKY_DIR_ERR_STRIDE * v;
         if (e[1] == 0ull) continue;
         out[1] = std::max(out[1], (float)((double)e[3] / (double)e[1]));
+        out[3] = std::max(out[3], (float)((double)e[4] / 16777216.0 / (double)e[1]));
     }
     return VPT_OK;
 }
@@ -1127,6 +1140,44 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     const bool pipelined = ctx->tail_stream != nullptr && !ctx->counting && !ctx->use_pool && iter_count >= 2u;
     if (ctx->tail_unjoined && (!pipelined || stream != ctx->tail_origin)) { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }
 
+    // ---- frame-ahead (vpt_ctx.h: FrameAhead): does this one-iteration call continue a still sequence, and are its rays traced already?
+    const bool fa_ok = !ctx->ahead.off && iter_count == 1u && iter_stride == 1u && !ctx->counting && !ctx->use_pool && ctx->batch_iters == 0;
+    bool fa_hit = false;
+    unsigned fa_n = 1;
+    if (fa_ok) {
+        std::vector<unsigned char> key;
+        auto put = [&](const void* ptr, size_t bytes) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + bytes); };
+        put(cam, sizeof(*cam)); put(ref_sphere, sizeof(*ref_sphere));
+        const unsigned char has_atm = atmosphere ? 1 : 0;
+        put(&has_atm, 1);
+        if (atmosphere) put(atmosphere, sizeof(*atmosphere));
+        vpt_kernel_params kp0 = *kp;
+        kp0.iteration = 0;
+        put(&kp0, sizeof(kp0));
+        put(&stream, sizeof(stream));
+        put(&lights->num_lights, sizeof(lights->num_lights));
+        if (lights->num_lights > 0) put(lights->light_ptr, (size_t)lights->num_lights * sizeof(vpt_point_light));
+        const bool same = ctx->ahead.key_valid && key == ctx->ahead.key;
+        fa_hit = same && ctx->ahead.next < ctx->ahead.n && kp->iteration == ctx->ahead.it0 + ctx->ahead.next;
+        if (!fa_hit) {
+            const bool consecutive = same && kp->iteration == ctx->ahead.last_it + 1u;
+            ctx->ahead.streak = consecutive ? ctx->ahead.streak + 1u : 0u;
+            ctx->ahead.n = 0;                                   // whatever was traced ahead is void
+            if (ctx->ahead.streak >= 1u) fa_n = std::min(ctx->ahead.max_k, 1u << std::min(ctx->ahead.streak, 6u));
+            const unsigned long long rule = std::max<unsigned long long>(1ull, ((unsigned long long)16 << 30) / ((unsigned long long)n_pixels * sizeof(Record)));
+            fa_n = (unsigned)std::min<unsigned long long>(fa_n, std::min<unsigned long long>(rule, 64ull));
+            while (fa_n > 1u && (unsigned long long)kp->iteration + fa_n >= (1ull << 20)) fa_n >>= 1;
+        }
+        ctx->ahead.key.swap(key);
+        ctx->ahead.key_valid = true;
+        ctx->ahead.last_it = kp->iteration;
+    } else {
+        ctx->ahead.key_valid = false;
+        ctx->ahead.n = 0;
+        ctx->ahead.streak = 0;
+    }
+    const unsigned fa_iters = fa_ok ? (fa_hit ? ctx->ahead.n : fa_n) : 0u;      // iterations of records the buffers must hold for it
+
     // ---- resolve-side parameters
     ResolveParams R;
     std::memset(&R, 0, sizeof(R));
@@ -1189,6 +1240,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     P.max_interactions = kp->max_interactions;
     P.render = kp->render ? 1 : 0;
     P.regen_min = kp->integrator != 0 ? ctx->regen_min_vol : ctx->regen_min;
+    P.raygen_small_iters = ctx->raygen_small_iters;
     P.trans_min = kp->integrator != 0 ? ctx->trans_min_vol : ctx->trans_min;
     P.work_counter = ctx->d_work_counter;
     P.counters = ctx->counting ? ctx->d_counters : nullptr;
@@ -1285,27 +1337,28 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (chunk > 64) chunk = 64;
     if (chunk > iter_count) chunk = iter_count;
     if (ctx->batch_iters > 0) chunk = std::min<size_t>(std::min<size_t>((size_t)ctx->batch_iters, iter_count), 64);     // (ResolveParams::rcp_n, split_slot: <= 64 per launch)
-    if (ctx->records_capacity < chunk * per_iter) {
+    const size_t cap_iters = std::max<size_t>(chunk, fa_iters);
+    if (ctx->records_capacity < cap_iters * per_iter) {
         { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
         (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
         (void)hipFree(ctx->d_td); ctx->d_td = nullptr; ctx->td_capacity = 0;
         (void)hipFree(ctx->d_queue2); ctx->d_queue2 = nullptr;
-        hipError_t e = hipMalloc(&ctx->d_records, chunk * per_iter * sizeof(Record));
-        if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, chunk * per_iter * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&ctx->d_heads, chunk * per_iter * sizeof(float4));
+        hipError_t e = hipMalloc(&ctx->d_records, cap_iters * per_iter * sizeof(Record));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, cap_iters * per_iter * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_heads, cap_iters * per_iter * sizeof(float4));
         if (e != hipSuccess) {
-            set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", chunk * per_iter * sizeof(Record), hipGetErrorString(e));
+            set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", cap_iters * per_iter * sizeof(Record), hipGetErrorString(e));
             return VPT_E_NOMEM;
         }
-        ctx->records_capacity = chunk * per_iter;
+        ctx->records_capacity = cap_iters * per_iter;
     }
-    if (ctx->bn_capacity < chunk) {
+    if (ctx->bn_capacity < cap_iters) {
         { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_bn_table); ctx->d_bn_table = nullptr;
-        HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, chunk * 65536 * sizeof(float2)));
-        ctx->bn_capacity = chunk;
+        HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, cap_iters * 65536 * sizeof(float2)));
+        ctx->bn_capacity = cap_iters;
     }
     P.records = ctx->d_records;
     // compact sample heads: a sample whose primary ray starts no walk needs its direction and depth only -- plus its
@@ -1358,6 +1411,108 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     const bool emit = kp->integrator != 0 ? kp->emission_scale != 0 : kp->emission_scale > 0;
     const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->use_pool ? 3 : (kp->integrator != 0 ? trace_vol_blocks_per_cu(kp->environment_type == 0) : trace_blocks_per_cu()));
     const int max_blocks = ctx->num_cus * blocks_per_cu;
+
+    // raygen's queue -> the persistent tracer of this scene (direct / vol_integrator instantiation)
+    auto launch_tracer = [&](unsigned long long total, int blocks) -> int {
+        // the root-only point location is for instantiations that ignore the leaf index (MULTI = false): the direct tracer
+        // with one volume, the vol tracer's non-generic variant
+        const bool kernel_multi = kp->integrator != 0 ? (multi || color || emit) : multi;
+        if (kernel_multi) P.octree_full_single = 0;
+        if (kp->integrator != 0) {
+            if (trace_vol_hist_floats_per_block() != 0u) {
+                const size_t need = trace_vol_hist_floats_per_block() * (size_t)max_blocks;
+                if (ctx->pool_hist_floats < need) {
+                    { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
+                    (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, need * sizeof(float)));
+                    ctx->pool_hist_floats = need;
+                }
+                P.pool_hist = ctx->d_pool_hist;
+            }
+            HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
+#ifdef VPT_WITH_POOL
+        } else if (ctx->use_pool && trace_pool_supports(P)) {
+            // one workgroup per CU, each with its own pool of rays in LDS
+            if (ctx->pool_hist_floats < trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus) { (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus; HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * ctx->pool_hist_floats)); }
+            P.pool_hist = ctx->d_pool_hist;
+            P.trans_min = ctx->pool_min_lanes;
+            const int pool_blocks = (int)std::min<unsigned long long>((total + 831) / 832, (unsigned long long)ctx->num_cus);
+            HIPCHK(ctx, launch_trace_pool(P, multi, color, emit, std::max(pool_blocks, 1), 64 * ctx->pool_waves, stream));
+#endif
+        } else {
+            HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
+        }
+        return VPT_OK;
+    };
+
+    // ---- frame-ahead (vpt_ctx.h: FrameAhead): a one-iteration call of a still sequence.  Buffer set 0, everything on `stream`.
+    if (fa_ok && (fa_hit || fa_n > 1u)) {
+        if (ctx->tail_pending[0]) {                          // (a batch's tail may have read set 0 last)
+            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[0], 0));
+            ctx->tail_pending[0] = false;
+        }
+        const uint32_t live = (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull);
+        float* const bn_caller = reinterpret_cast<float*>(kp->blue_noise_buffer);
+        int rc;
+        if (!fa_hit) {
+            // trace the rays of iterations it0 .. it0 + n - 1 in ONE raygen + tracer launch; the jitter tables come from a private copy of the
+            // caller's blue-noise state (the caller's own buffer advances one step per call, below, as one launch per call leaves it)
+            const unsigned n = fa_n, it0 = kp->iteration;
+            if (!ctx->ahead.d_bn) HIPCHK(ctx, hipMalloc(&ctx->ahead.d_bn, 65536 * 3 * sizeof(float)));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->ahead.d_bn, bn_caller, 65536 * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
+            ctx->last_wc = P.work_counter;
+            HIPCHK(ctx, launch_blue_noise(ctx->ahead.d_bn, ctx->d_bn_table, n, 1u, live, stream));
+            P.iter_begin = it0; P.iter_count = n;
+            R.iter_begin = it0; R.iter_count = n;
+            const unsigned long long total = (unsigned long long)n_pixels * n;
+            int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
+            if (blocks < 1) blocks = 1;
+            P.chunk = total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK;
+            int e0, e1, e2, e3;
+            if ((rc = get_events(ctx, &e0, &e1)) != 0 || (rc = get_events(ctx, &e2, &e3)) != 0) return rc;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
+            HIPCHK(ctx, launch_raygen(P, stream));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e1], stream));
+            if ((rc = launch_tracer(total, blocks)) != VPT_OK) return rc;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e2], stream));
+            if (R.lean) HIPCHK(ctx, launch_sky_fix(R, stream));          // (over the whole batch: its heads are final before any slice's tail)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e3], stream));
+            ctx->spans.push_back({e0, e1, 0});
+            ctx->spans.push_back({e1, e2, 1});
+            ctx->spans.push_back({e2, e3, 2});
+            ctx->ahead.it0 = it0; ctx->ahead.n = n; ctx->ahead.next = 0;
+        }
+        // this call's iteration: slice k of what is traced -- its tail, exactly as a one-iteration launch runs it
+        const unsigned k = ctx->ahead.next;
+        HIPCHK(ctx, launch_blue_noise(bn_caller, nullptr, 1u, 1u, live, stream));
+        ResolveParams Rk = R;
+        Rk.iter_begin = kp->iteration; Rk.iter_count = 1;
+        for (unsigned int q = 0; q < 64u; ++q) Rk.rcp_n[q] = 0.0;
+        { const float nf = (float)(kp->iteration + 1u); Rk.rcp_n[0] = nf < 134217728.0f ? 1.0 / (double)nf : 0.0; }
+        const size_t off = (size_t)k * n_pixels;
+        Rk.records = R.records + off;
+        if (Rk.heads) Rk.heads = R.heads + off;
+        if (Rk.head_org) Rk.head_org = R.head_org + off;
+        if (Rk.td) Rk.td = R.td + off;
+        if (Rk.blue_noise) Rk.blue_noise = R.blue_noise + (size_t)k * 65536u;
+        Rk.display = kp->display_buffer;
+        Rk.raw = reinterpret_cast<float*>(kp->raw_buffer);
+        int ea, eb;
+        if ((rc = get_events(ctx, &ea, &eb)) != 0) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ea], stream));
+        if (Rk.lean) HIPCHK(ctx, launch_tail_stream(Rk, stream));
+        else HIPCHK(ctx, launch_tail_resolve(Rk, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[eb], stream));
+        ctx->spans.push_back({ea, eb, 2});
+        ctx->ahead.next = k + 1u;
+        ctx->last_samples = n_pixels;
+        ctx->last_resolve = Rk;
+        if (!ctx->render_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->render_event, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->render_event, stream));
+        ctx->render_stream = stream;
+        return VPT_OK;
+    }
 
     // the two sets of per-chunk buffers (vpt_ctx.h): set 0 = the context's d_* fields, as P and R hold them now; set 1 = `alt`
     vpt_ctx::ChunkBufs set0;
@@ -1440,34 +1595,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
-        // the root-only point location is for instantiations that ignore the leaf index (MULTI = false): the direct tracer
-        // with one volume, the vol tracer's non-generic variant
-        const bool kernel_multi = kp->integrator != 0 ? (multi || color || emit) : multi;
-        if (kernel_multi) P.octree_full_single = 0;
-        if (kp->integrator != 0) {
-            if (trace_vol_hist_floats_per_block() != 0u) {
-                const size_t need = trace_vol_hist_floats_per_block() * (size_t)max_blocks;
-                if (ctx->pool_hist_floats < need) {
-                    { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
-                    (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = 0;
-                    HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, need * sizeof(float)));
-                    ctx->pool_hist_floats = need;
-                }
-                P.pool_hist = ctx->d_pool_hist;
-            }
-            HIPCHK(ctx, launch_trace_vol(P, multi, color, emit, blocks, stream));
-#ifdef VPT_WITH_POOL
-        } else if (ctx->use_pool && trace_pool_supports(P)) {
-            // one workgroup per CU, each with its own pool of rays in LDS
-            if (ctx->pool_hist_floats < trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus) { (void)hipFree(ctx->d_pool_hist); ctx->d_pool_hist = nullptr; ctx->pool_hist_floats = trace_pool_hist_floats_per_block() * (size_t)ctx->num_cus; HIPCHK(ctx, hipMalloc(&ctx->d_pool_hist, sizeof(float) * ctx->pool_hist_floats)); }
-            P.pool_hist = ctx->d_pool_hist;
-            P.trans_min = ctx->pool_min_lanes;
-            const int pool_blocks = (int)std::min<unsigned long long>((total + 831) / 832, (unsigned long long)ctx->num_cus);
-            HIPCHK(ctx, launch_trace_pool(P, multi, color, emit, std::max(pool_blocks, 1), 64 * ctx->pool_waves, stream));
-#endif
-        } else {
-            HIPCHK(ctx, launch_trace(P, multi, color, emit, blocks, stream));
-        }
+        { const int rt_ = launch_tracer(total, blocks); if (rt_ != VPT_OK) return rt_; }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
         // sky_fix_kernel (what the dome did not serve: reads path records and the queue the tracer filled) stays on the tracer's stream ...
         if (R.lean) HIPCHK(ctx, launch_sky_fix(R, stream));
