@@ -259,9 +259,6 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
 #ifndef VPT_HIST_CAP_EMIT
 #define VPT_HIST_CAP_EMIT 8
 #endif
-#ifndef VPT_TRANS_MIN_DRAIN
-#define VPT_TRANS_MIN_DRAIN 64             // lanes that must wait before the transitions run once a wave's queue is empty (64: as in steady state; measured: profiles/r05_short_launches.txt)
-#endif
 int trace_blocks_per_cu() { return VPT_TRACE_WAVES_PER_EU; }
 // (study switch: -DVPT_NO_SUN_INV forms 1 / sun_dir in the Tr prologue again, as rounds 1-4 did)
 #ifdef VPT_NO_SUN_INV
@@ -481,12 +478,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         // Transition code runs with few lanes, so it is batched like the refill: entered only when
         // >= trans_min lanes wait for it or nothing else can make progress.
         const unsigned long long tmask = __ballot(phase >= PH_T_FIRST);
-        // DRAIN: once the queue is empty for this wave (nothing left to claim, its chunk used up) no refill will ever fill the lanes a transition batch
-        // waits for -- batching then only delays the paths that are left, and a short launch lasts as long as its longest path.  From there on the
-        // transitions run as soon as VPT_TRANS_MIN_DRAIN lanes wait (a schedule, not a value: the Philox counter defines the sample).
-        const bool draining = !more && chunk_next == chunk_end;
-        const uint32_t tmin = draining ? min(trans_min, (uint32_t)VPT_TRANS_MIN_DRAIN) : trans_min;
-        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= tmin || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
+        // (a lower threshold once the wave's queue is empty -- 1, 8, 16 lanes -- changes nothing measurable, not even on a one-iteration launch: profiles/r05_short_launches.txt)
+        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
         if (COUNT) {
             const unsigned long long wm = __ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST), im = __ballot(phase == PH_IDLE);
             if (lane == 0) {

@@ -32,9 +32,6 @@
 #include "vpt_sky.h"
 #include "vpt_walk.h"
 
-#ifndef VPT_TRANS_MIN_DRAIN
-#define VPT_TRANS_MIN_DRAIN 64             // (vpt_trace.hip)
-#endif
 namespace vpt {
 
 enum : uint32_t {
@@ -335,9 +332,7 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
 
         // ==== transitions ===================================================================
         const unsigned long long tmask = __ballot(phase >= VH_T_FIRST);
-        const bool draining = !more && chunk_next == chunk_end;                  // (see vpt_trace.hip)
-        const uint32_t tmin = draining ? min(trans_min, (uint32_t)VPT_TRANS_MIN_DRAIN) : trans_min;
-        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= tmin || !__any(phase >= VH_W_FIRST && phase <= VH_W_LAST));
+        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= VH_W_FIRST && phase <= VH_W_LAST));
         if (COUNT) {                     // schedule statistics (vpt_test_get_schedule), as in trace_kernel
             const unsigned long long wm = __ballot(phase >= VH_W_FIRST && phase <= VH_W_LAST), im = __ballot(phase == VH_IDLE);
             if (lane == 0) {
