@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-per-frame", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-config parity leg of other_configs")
     ap.add_argument("--no-c4-oracle", action="store_true", help="config 4's parity leg: the layout A/B only (no 3.5 GB host copy, no oracle lattice)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="independent frames a rank keeps in flight (contexts dealt round robin); 0 = 3 for strong-scaling "
+                    "steps of <= 12 iterations per rank, else 1.  With N = 1 a value > 1 makes every step a fresh frame")
     ap.add_argument("--no-c1", action="store_true", help="skip the config-1 block (reference kernel on ONE host thread, 512x512x16spp)")
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
@@ -260,30 +262,45 @@ def main():
         bn0 = hb.blue_noise.clone()
         torch.cuda.synchronize(dev)
         use_comm = multi and backend == "nccl"
+        # FRAMES IN FLIGHT (round 5): a strong-scaling step is ONE independent frame (a fresh render of this rank's stripe + the one all-reduce), and a
+        # k-iteration launch of the persistent tracer pays ~0.25 ms of start-up and drain whatever k is -- 8 iterations per rank run at 68 % of
+        # the batch rate.  Consecutive frames are independent, so a rank keeps F of them in flight: F contexts (own stream, own buffers, own
+        # communicator), steps dealt round robin; frame f + 1's kernels run under frame f's drain and reduce.  Measured on one GPU
+        # (profiles/r05_frames_in_flight.txt): 8 iterations per frame 1.093 -> 0.879 ms with F = 3; no gain from 16 iterations up, a loss at 64.
+        in_flight = args.frames_in_flight or (3 if (world > 1 and scaling == "strong" and 0 < spp <= 12) else 1)
+        fresh_frames = multi or in_flight > 1             # every step a fresh frame (else: the progressive render carries on)
+        hbs = [hb] + [pkg.scene.HipBinding(sd, device=local_rank) for _ in range(in_flight - 1)]
         if use_comm:
-            pkg.dist.init_comm(hb.ctx)                   # RCCL communicator of this context (id carried by torch.distributed)
-        # everything a step enqueues goes to the context's own stream; torch ops on it through an ExternalStream view
-        cstream = torch.cuda.ExternalStream(hb.ctx.stream, device=dev)
+            for h in hbs:
+                pkg.dist.init_comm(h.ctx)                # RCCL communicator of this context (id carried by torch.distributed)
+        # everything a step enqueues goes to its context's own stream; torch ops on it through an ExternalStream view
+        cstreams = [torch.cuda.ExternalStream(h.ctx.stream, device=dev) for h in hbs]
+        step_no = [0]
 
         def one_step():
-            if not multi:
+            h = hbs[step_no[0] % in_flight]
+            cs_ = cstreams[step_no[0] % in_flight]
+            step_no[0] += 1
+            if not fresh_frames:
                 # the next `spp` iterations of the progressive render (iteration indices, blue-noise table and running means
                 # carry on from the previous step, as consecutive frames of the reference do): no host round trip between steps
-                hb.render(spp)
+                h.render(spp)
                 return
             # a step of the N-rank job: this rank's stripe of a fresh render, then the one all-reduce.  All of it is enqueued
             # on the context's stream in order -- the next step's kernels queue behind the reduce, no host fence in between.
-            with torch.cuda.stream(cstream):
-                hb.blue_noise.copy_(bn0)
+            with torch.cuda.stream(cs_):
+                h.blue_noise.copy_(bn0)
             if bn_pre:
-                hb.ctx.blue_noise_advance(hb.blue_noise, bn_pre, sd.width * sd.height)
+                h.ctx.blue_noise_advance(h.blue_noise, bn_pre, sd.width * sd.height)
             if spp:                                         # (a rank beyond the job's iterations renders nothing and carries weight 0)
-                hb.render(spp, iter_stride=stride, iteration=first_it)
+                h.render(spp, iter_stride=stride, iteration=first_it)
+            if not multi:
+                return
             if use_comm:
-                pkg.dist.combine_means(hb.accum, spp, ctx=hb.ctx)
+                pkg.dist.combine_means(h.accum, spp, ctx=h.ctx)
             else:
-                hb.sync()                                   # host-staged fallback (gloo): ctx stream -> torch's stream
-                pkg.dist.combine_means(hb.accum, spp)
+                h.sync()                                    # host-staged fallback (gloo): ctx stream -> torch's stream
+                pkg.dist.combine_means(h.accum, spp)
                 torch.cuda.synchronize(dev)
 
         def fence():
@@ -350,6 +367,7 @@ def main():
                            # host-staged torch.distributed fallback (VPT_BENCH_BACKEND=gloo: ranks sharing one GPU)
                            "collective": ({"backend": "rccl (vpt_allreduce_accum)", "comm_ranks": int(hb.ctx.comm_nranks)} if use_comm else
                                           {"backend": backend + " (torch.distributed, host-staged)", "comm_ranks": world}) if multi else None,
+                           "frames_in_flight": in_flight,
                            "arithmetic": "strict (no FMA contraction, fixed-sequence log/sin/cos)",
                            "scene_setup_s": round(t_setup, 3)},
                 "roofline": roofline,
@@ -387,8 +405,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(hb, sd, bn0, W, H, spp)
         if multi:
             dist.barrier()
-        hb.ctx.close()
-        del hb
+        for h in hbs:
+            h.ctx.close()
+        del hb, hbs
         torch.cuda.empty_cache()
         return out
 
@@ -562,7 +581,8 @@ def main():
     if rank == 0 and out is not None and o2 is not None:
         for name, o in ((args.scaling, out), (other, o2)):
             out[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
-                         "spp_per_gpu": o["config"]["spp_per_gpu"], "spp_job": o["config"]["spp_job"], "n_gpus": world}
+                         "spp_per_gpu": o["config"]["spp_per_gpu"], "spp_job": o["config"]["spp_job"], "n_gpus": world,
+                         "frames_in_flight": o["config"]["frames_in_flight"]}
     if not multi and not args.no_other_configs and cfg == "c2":
         others = []
         for oc in ("c3", "c4", "c5"):

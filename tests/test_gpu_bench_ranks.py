@@ -28,6 +28,8 @@ def test_two_ranks_on_one_gpu():
     # both scalings travel in the one line (round 5): the job's rate with every rank rendering the 4 iterations, and with the 4 split over the 2 ranks
     assert d["weak"]["value"] == d["value"] and d["weak"]["spp_per_gpu"] == 4 and d["weak"]["spp_job"] == 8
     assert d["strong"]["value"] > 0 and d["strong"]["spp_per_gpu"] == 2 and d["strong"]["spp_job"] == 4 and d["strong"]["n_gpus"] == 2
+    # a strong-scaling step of a few iterations per rank is one independent frame: three of them in flight per rank (three contexts dealt round robin)
+    assert d["strong"]["frames_in_flight"] == 3 and d["weak"]["frames_in_flight"] == 1
     # fixed total work: the job's 4 iterations split over the 2 ranks
     r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
