@@ -425,9 +425,29 @@ def main():
             hb.sync()
         dt = time.perf_counter() - tf
         st = hb.ctx.stats()
-        return {"value": round(W * H * args.frames / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(dt / args.frames * 1e3, 4),
-                "frames": args.frames, "kernels_ms_last_frame": {"raygen": round(st.raygen_ms, 4), "trace": round(st.trace_ms, 4), "tail_resolve": round(st.tail_ms, 4)},
-                "call": "vpt_render (iter_count 1) + vpt_sync per frame, as source/main.cpp:1822-1829"}
+        out = {"value": round(W * H * args.frames / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(dt / args.frames * 1e3, 4),
+               "frames": args.frames, "kernels_ms_last_frame": {"raygen": round(st.raygen_ms, 4), "trace": round(st.trace_ms, 4), "tail_resolve": round(st.tail_ms, 4)},
+               "call": "vpt_render (iter_count 1) + vpt_sync per frame, as source/main.cpp:1822-1829",
+               "frame_ahead": "on (the product's default): from the second identical call on a call traces the rays of the next 2..16 iterations in one launch, the following calls "
+                              "run only their tail; every buffer after every frame bit-identical to frame by frame (tests/test_gpu_edge.py)"}
+        # ... and the same loop with one launch per frame (VPT_NO_FRAME_AHEAD=1, as rounds 1-4): a second context, the switch is read when a context is created
+        if "VPT_NO_FRAME_AHEAD" not in os.environ:
+            os.environ["VPT_NO_FRAME_AHEAD"] = "1"
+            try:
+                h2 = pkg.scene.HipBinding(sd, device=local_rank)
+            finally:
+                del os.environ["VPT_NO_FRAME_AHEAD"]
+            for _ in range(4):
+                h2.render_frame(); h2.sync()
+            tf = time.perf_counter()
+            for _ in range(args.frames):
+                h2.render_frame(); h2.sync()
+            dt2 = time.perf_counter() - tf
+            s2 = h2.ctx.stats()
+            h2.ctx.close()
+            out["frame_by_frame"] = {"value": round(W * H * args.frames / dt2 / 1e6, 3), "ms_per_frame": round(dt2 / args.frames * 1e3, 4),
+                                     "kernels_ms_last_frame": {"raygen": round(s2.raygen_ms, 4), "trace": round(s2.trace_ms, 4), "tail_resolve": round(s2.tail_ms, 4)}}
+        return out
 
     def config_parity(cfg, hb, sd, bn0, W, H, spp):
         """parity evidence of configs 3-5 AT THE SIZE THAT IS TIMED, carried in the bench line:

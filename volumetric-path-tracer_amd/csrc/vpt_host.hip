@@ -320,9 +320,9 @@ static int quiesce_all(vpt_ctx* ctx, hipStream_t stream) {
     return VPT_OK;
 }
 
-// The context's own stream.  NOTE: a render issued with stream = NULL leaves its last tail on a second, internal stream (vpt_ctx.h): its results
-// are complete after vpt_sync (or once any later vpt_* call that touches them has been ordered behind it) -- not when THIS stream drains.  A host that
-// orders its own work against this handle calls vpt_sync first, or renders on a stream of its own (such a render joins before it returns).
+// The context's own stream: everything a render enqueues runs on it, in order.  (Only under the study switch VPT_ASYNC_TAIL=1 -- off by default, measured
+// without gain -- does a render issued with stream = NULL leave its last tail on a second, internal stream (vpt_ctx.h): its results are then complete
+// after vpt_sync, or once a later vpt_* call that touches them has been ordered behind it.)
 void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int vpt_sync(vpt_ctx* ctx) {
