@@ -522,6 +522,9 @@ def main():
         import ref_binding
         Wc, Hc, sppc = 512, 512, 16
         sd1 = pkg.scene.dragon_scene(Wc, Hc, "c1")
+        # "no atmosphere" = sun_mult = sky_mult = 0: the reference's kernel still CALLS sample_atmosphere (:1840) and multiplies by zero, so the
+        # compiled reference needs finite tables (without them NaN x 0 trips its NaN guard and the image is black); the HIP path gets the same tables
+        pkg.atmosphere.attach_default_atmosphere(sd1, device=local_rank)
         use_ref = ref_binding.have_ref()
         ob = ref_binding.RefBinding(sd1) if use_ref else oracle_binding.OracleBinding(sd1)
         tc = time.perf_counter()

@@ -76,7 +76,7 @@ struct vpt_ctx {
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
     uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
-    uint32_t raygen_small_iters = 8; // VPT_RAYGEN_SMALL_ITERS: launches of fewer iterations run raygen over 16-row tiles (TraceParams::raygen_small_iters)
+    uint32_t raygen_small_iters = 17; // VPT_RAYGEN_SMALL_ITERS: launches of fewer iterations run raygen over 16-row tiles (four times the blocks: 8 iterations 1.102 -> 1.045 ms, 16: 1.669 -> 1.611, 64: no difference; profiles/r05_batch_curve.txt)
     // pool tracer (csrc/variants/vpt_trace_pool.hip, study builds with -DVPT_WITH_POOL only): direct_integrator with the rays in an LDS pool per CU
     bool use_pool = false;         // VPT_TRACER=pool in such a build: measured slower than the lane-bound tracer, kept as the evidence and for A/B runs
     int pool_waves = 12;           // VPT_POOL_WAVES: waves of the one workgroup per CU (8..12)

@@ -769,7 +769,7 @@ static hipError_t launch_variant(const TraceParams& P, int blocks, hipStream_t s
 }
 
 hipError_t launch_raygen(const TraceParams& P, hipStream_t stream) {
-    const bool small = P.iter_count < P.raygen_small_iters;      // (8 unless VPT_RAYGEN_SMALL_ITERS says otherwise)
+    const bool small = P.iter_count < P.raygen_small_iters;      // (17 unless VPT_RAYGEN_SMALL_ITERS says otherwise)
     const uint32_t rows = small ? 16u : 64u;
     const dim3 grid(((P.width + 63u) / 64u) * ((P.height + rows - 1u) / rows) * P.iter_count), block(64, 4, 1);
     if (small) {
