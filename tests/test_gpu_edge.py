@@ -383,40 +383,3 @@ def test_tails_on_their_own_stream_change_nothing(pkg, monkeypatch, kind):
     assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-
-
-@pytest.mark.parametrize("size", [(160, 90), (384, 216)])
-def test_jitter_by_recurrence_changes_nothing(pkg, monkeypatch, size):
-    """The streaming tail re-derives its pixel's jitters from the chunk's start state with the blue-noise table's own recurrence (csrc/vpt_tail.hip:
-    tail_stream_kernel) instead of reading the table back.  Against VPT_NO_JITTER_RECURRENCE=1: every buffer bit-identical -- an image below 65 536 pixels
-    (only the first W*H entries of the table advance, render_kernel.cu:2320) and one above, batches that continue one another, chunked batches (a launch
-    boundary: each chunk starts from its own state), an iteration stride of 3 (a rank's stripe of a multi-GPU job) and a blue-noise state outside [0, 1]
-    in a few entries (outside the contract: those lanes keep the table)."""
-    w, h = size
-    sd = pkg.scene.dragon_scene(w, h, "c2")
-    pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-    sd.blue_noise = sd.blue_noise.copy()
-    sd.blue_noise[5] = (-0.25, 1.5, 0.5)
-    sd.blue_noise[77] = (1.0, 0.0, 2.0)
-    monkeypatch.setenv("VPT_BATCH_ITERS", "5")
-
-    def run():
-        hb = pkg.scene.HipBinding(sd, device=0)
-        hb.render(4)
-        hb.render(7)                                 # 5 + 2
-        hb.render(6, iter_stride=3, iteration=11)
-        hb.sync()
-        import ctypes as C
-        lib = pkg.load_library()
-        state = (C.c_int * 8)()
-        lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-        assert lib.vpt_test_get_cache_state(hb.ctx.h, state) == 0 and state[0] and state[6], list(state)      # patches + the streaming tail
-        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
-        hb.ctx.close()
-        return out
-    a = run()
-    monkeypatch.setenv("VPT_NO_JITTER_RECURRENCE", "1")
-    b = run()
-    assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
-    for k in a:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

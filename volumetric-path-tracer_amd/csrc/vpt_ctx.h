@@ -37,7 +37,7 @@ hipError_t launch_sky_patch(const ResolveParams& R, float4* out, unsigned char* 
 hipError_t launch_sky_dome(const ResolveParams& R, const SkyView* view, float4* out, int k, hipStream_t stream);
 size_t sky_dome_bytes(int k);
 hipError_t launch_display(const float* accum, unsigned int* display, float* raw, uint32_t n, float exposure_scale, hipStream_t stream);
-hipError_t launch_blue_noise(float* bn, float2* table, float2* start, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
+hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream);
 }  // namespace vpt
 
 
@@ -116,7 +116,6 @@ struct vpt_ctx {
     size_t td_capacity = 0;
     uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td
     uint32_t* d_nopatch = nullptr;         // [0]: count, [1..]: pixels without a usable sky patch (ResolveParams::nopatch_list), with d_sky_patch
-    bool no_jitter_recurrence = false;     // VPT_NO_JITTER_RECURRENCE: the streaming tail reads the jitter tables back (tests: same bits either way)
     bool no_lean_tail = false;             // VPT_NO_LEAN_TAIL: finished paths keep their 64-byte records and the tail adds the environment (A/B, tests)
     float4* d_head_org = nullptr;          // ray origins of the heads (thin lens: lens_radius != 0), allocated on first use
     size_t head_org_capacity = 0;
@@ -190,7 +189,6 @@ struct vpt_ctx {
     struct ChunkBufs {
         vpt::Record* records = nullptr; uint32_t* queue = nullptr; float4* heads = nullptr; float4* head_org = nullptr; float2* td = nullptr;
         uint32_t* queue2 = nullptr; float2* bn_table = nullptr; uint32_t* wc = nullptr;
-        float2* bn_start = nullptr;       // the 65536 entries behind the set's jitter tables (ResolveParams::bn_start)
     } alt;
     size_t alt_records_capacity = 0, alt_head_org_capacity = 0, alt_td_capacity = 0, alt_bn_capacity = 0;
     hipEvent_t ev_traced[2] = {nullptr, nullptr}, ev_tailed[2] = {nullptr, nullptr};

@@ -22,8 +22,6 @@
 namespace vpt {
 
 enum { GRID_DENSE = 0, GRID_BRICKS = 1, GRID_QUADS = 2 };
-// the golden-ratio step of the blue-noise advance (render_kernel.cu:2320-2325): (1.0f + sqrtf(5.0f)) / 2.0f in binary32, as the reference's expression rounds
-#define VPT_BN_PHI 0x1.9e377ap+0f
 
 // view point of the environment tail's per-frame tables (vpt_sky.h), device-resident
 enum { SKY_VIEW_MAX_K = 4 };
@@ -310,9 +308,6 @@ struct ResolveParams {
     // a ground hit evaluated in full, the sun's disc is more than a cell away.  A sample whose direction falls into a flagged cell
     // costs four float4 reads and nine FMAs instead of sample_atmosphere; the others are evaluated as before.  VALUE-ONLY.
     const float4* sky_dome;          // [SKY_DOME_NV][SKY_DOME_NU] {value.rgb, cell flag}, or NULL
-    const float2* bn_start;          // [65536] or NULL: the chunk's jitter state at its first iteration, unclamped (blue_noise_kernel): tail_stream_kernel re-derives
-                                     // blue_noise[k][i] from it by the table's own recurrence instead of reading the table back (1 GB per 64-iteration launch at 1080p)
-    uint32_t bn_live;                // entries below it advance (min(W*H, 65536): `if (idx < 256*256)` runs for idx < W*H only)
     const float2* blue_noise;        // [iter_count][65536]: the chunk's jitter tables (what raygen read), for the patch
     // RESOLVED SAMPLES (TraceParams::resolve): with the per-view caches in use behind a closed lens the tail proper (tail_stream_kernel) evaluates
     // no sky at all -- a sample is a head {dir0, depth >= 0} (untraced: the pixel's patch at its jitter), {-, -, -, -2} (not rendered) or

@@ -216,7 +216,6 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
-    ctx->no_jitter_recurrence = std::getenv("VPT_NO_JITTER_RECURRENCE") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     ctx->no_leaf_cull = std::getenv("VPT_NO_LEAF_CULL") != nullptr;
     { const char* tw = std::getenv("VPT_TEX_WEIGHTS"); ctx->tex_fixed8 = tw != nullptr && std::strcmp(tw, "fixed8") == 0; }
@@ -1184,7 +1183,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     std::memset(&R, 0, sizeof(R));
     R.width = W; R.height = H; R.n_pixels = n_pixels;
     R.iter_stride = iter_stride;
-    R.bn_live = (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull);
     R.max_interactions = kp->max_interactions;
     R.accum = reinterpret_cast<float*>(kp->accum_buffer);
     R.cost = reinterpret_cast<float*>(kp->cost_buffer);
@@ -1359,7 +1357,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (ctx->bn_capacity < cap_iters) {
         { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_bn_table); ctx->d_bn_table = nullptr;
-        HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, (cap_iters + 1) * 65536 * sizeof(float2)));      // (+ the chunk's start state behind the tables: ResolveParams::bn_start)
+        HIPCHK(ctx, hipMalloc(&ctx->d_bn_table, cap_iters * 65536 * sizeof(float2)));
         ctx->bn_capacity = cap_iters;
     }
     P.records = ctx->d_records;
@@ -1464,7 +1462,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             HIPCHK(ctx, hipMemcpyAsync(ctx->ahead.d_bn, bn_caller, 65536 * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
             HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
             ctx->last_wc = P.work_counter;
-            HIPCHK(ctx, launch_blue_noise(ctx->ahead.d_bn, ctx->d_bn_table, nullptr, n, 1u, live, stream));
+            HIPCHK(ctx, launch_blue_noise(ctx->ahead.d_bn, ctx->d_bn_table, n, 1u, live, stream));
             P.iter_begin = it0; P.iter_count = n;
             R.iter_begin = it0; R.iter_count = n;
             const unsigned long long total = (unsigned long long)n_pixels * n;
@@ -1487,7 +1485,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         }
         // this call's iteration: slice k of what is traced -- its tail, exactly as a one-iteration launch runs it
         const unsigned k = ctx->ahead.next;
-        HIPCHK(ctx, launch_blue_noise(bn_caller, nullptr, nullptr, 1u, 1u, live, stream));
+        HIPCHK(ctx, launch_blue_noise(bn_caller, nullptr, 1u, 1u, live, stream));
         ResolveParams Rk = R;
         Rk.iter_begin = kp->iteration; Rk.iter_count = 1;
         for (unsigned int q = 0; q < 64u; ++q) Rk.rcp_n[q] = 0.0;
@@ -1498,7 +1496,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (Rk.head_org) Rk.head_org = R.head_org + off;
         if (Rk.td) Rk.td = R.td + off;
         if (Rk.blue_noise) Rk.blue_noise = R.blue_noise + (size_t)k * 65536u;
-        Rk.bn_start = nullptr;                                   // (a slice reads its one iteration's jitters from the table)
         Rk.display = kp->display_buffer;
         Rk.raw = reinterpret_cast<float*>(kp->raw_buffer);
         int ea, eb;
@@ -1521,7 +1518,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     vpt_ctx::ChunkBufs set0;
     set0.records = ctx->d_records; set0.queue = ctx->d_queue; set0.heads = ctx->d_heads; set0.head_org = ctx->d_head_org; set0.td = ctx->d_td;
     set0.queue2 = ctx->d_queue2; set0.bn_table = ctx->d_bn_table; set0.wc = ctx->d_work_counter;
-    set0.bn_start = ctx->d_bn_table + ctx->bn_capacity * 65536;
     auto point_at = [&](const vpt_ctx::ChunkBufs& B) {
         P.records = B.records; R.records = B.records;
         if (P.heads) { P.heads = B.heads; R.heads = B.heads; }
@@ -1529,8 +1525,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         P.queue = B.queue; P.queue_tail = B.wc + 8; P.queue_count = B.wc + 8; P.work_counter = B.wc;
         P.blue_noise = B.bn_table;
         if (R.blue_noise) R.blue_noise = B.bn_table;
-        // the streaming tail re-derives the chunk's jitters from its start state (needs the patches' jitter look-up: R.blue_noise set, and the lean tail)
-        R.bn_start = (R.lean && R.blue_noise && !ctx->no_jitter_recurrence) ? B.bn_start : nullptr;
         if (R.lean) {
             R.td = B.td; R.queue2 = B.queue2; R.queue2_count = B.wc + 4;
             P.resolve.heads = B.heads; P.resolve.td = B.td; P.resolve.queue2 = B.queue2; P.resolve.queue2_tail = B.wc + 4;
@@ -1555,7 +1549,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                 hipError_t e = hipMalloc(&A.records, ctx->records_capacity * sizeof(Record));
                 if (e == hipSuccess) e = hipMalloc(&A.queue, ctx->records_capacity * sizeof(uint32_t));
                 if (e == hipSuccess) e = hipMalloc(&A.heads, ctx->records_capacity * sizeof(float4));
-                if (e == hipSuccess) e = hipMalloc(&A.bn_table, (ctx->bn_capacity + 1) * 65536 * sizeof(float2));
+                if (e == hipSuccess) e = hipMalloc(&A.bn_table, ctx->bn_capacity * 65536 * sizeof(float2));
                 if (e == hipSuccess && ctx->head_org_capacity) e = hipMalloc(&A.head_org, ctx->head_org_capacity * sizeof(float4));
                 if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.td, ctx->td_capacity * sizeof(float2));
                 if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.queue2, ctx->td_capacity * sizeof(uint32_t));
@@ -1564,7 +1558,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
                     set_error(ctx, "vpt_render: hipMalloc of the second set of per-chunk buffers failed: %s (VPT_NO_ASYNC_TAIL=1 renders with one set)", hipGetErrorString(e));
                     return VPT_E_NOMEM;
                 }
-                A.bn_start = A.bn_table + ctx->bn_capacity * 65536;
                 ctx->alt_records_capacity = ctx->records_capacity; ctx->alt_bn_capacity = ctx->bn_capacity;
                 ctx->alt_head_org_capacity = ctx->head_org_capacity; ctx->alt_td_capacity = ctx->td_capacity;
             }
@@ -1585,7 +1578,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
         HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
         ctx->last_wc = P.work_counter;
-        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), const_cast<float2*>(P.blue_noise), const_cast<float2*>(R.bn_start), n, iter_stride,
+        HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), const_cast<float2*>(P.blue_noise), n, iter_stride,
                                       (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull), stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
         int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
@@ -1668,7 +1661,7 @@ int vpt_blue_noise_advance(vpt_ctx* ctx, vpt_float3* blue_noise_buffer, unsigned
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     if (steps == 0) return VPT_OK;
-    HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(blue_noise_buffer), nullptr, nullptr, 1, steps, std::min(num_pixels, 65536u), stream));
+    HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(blue_noise_buffer), nullptr, 1, steps, std::min(num_pixels, 65536u), stream));
     return VPT_OK;
 }
 

@@ -12,14 +12,11 @@ namespace vpt {
 // read/write race is resolved as "a launch reads the pre-update values").  Also leaves
 // the caller's buffer advanced by count*stride steps, as `count` launches would.
 // Only the first `live` = min(W*H, 65536) entries advance (`if (idx < 256*256)` runs for idx < W*H only).
-// start (optional): the (x, y) state the chunk begins with, UNCLAMPED -- the streaming tail re-derives the chunk's jitter sequence from it with this very
-// recurrence instead of reading 8 bytes per pixel-sample of table back (vpt_tail.hip: tail_stream_kernel, ResolveParams::bn_start)
-__global__ __launch_bounds__(256) void blue_noise_kernel(float* bn /* float3[65536] */, float2* table, float2* start, uint32_t count, uint32_t stride, uint32_t live) {
+__global__ __launch_bounds__(256) void blue_noise_kernel(float* bn /* float3[65536] */, float2* table, uint32_t count, uint32_t stride, uint32_t live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 65536u) return;
     float x = bn[3 * i], y = bn[3 * i + 1], z = bn[3 * i + 2];
-    if (start) start[i] = make_float2(x, y);
-    const float phi = VPT_BN_PHI;            // (1.0f + sqrtf(5.0f)) / 2.0f, correctly rounded: 0x3FCF1BBD
+    const float phi = (1.0f + sqrtf(5.0f)) / 2.0f;
     for (uint32_t k = 0; k < count; ++k) {
         // CONTRACT (vpt_abi.h): jitter values lie in [0, 1] (the reference's come from an 8-bit image / 255, then x -> fmod(x + phi, 1)); what
         // raygen and the tail READ is clamped to it -- the never-traced pixel mask and the sky patches are built for that footprint
@@ -33,9 +30,8 @@ __global__ __launch_bounds__(256) void blue_noise_kernel(float* bn /* float3[655
     bn[3 * i] = x; bn[3 * i + 1] = y; bn[3 * i + 2] = z;
 }
 
-static_assert((1.0f + 2.2360679774997896f) / 2.0f == VPT_BN_PHI, "VPT_BN_PHI is (1.0f + sqrtf(5.0f)) / 2.0f in binary32");
-hipError_t launch_blue_noise(float* bn, float2* table, float2* start, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream) {
-    hipLaunchKernelGGL(blue_noise_kernel, dim3(256), dim3(256), 0, stream, bn, table, start, count, stride, live);
+hipError_t launch_blue_noise(float* bn, float2* table, uint32_t count, uint32_t stride, uint32_t live, hipStream_t stream) {
+    hipLaunchKernelGGL(blue_noise_kernel, dim3(256), dim3(256), 0, stream, bn, table, count, stride, live);
     return hipGetLastError();
 }
 

@@ -463,22 +463,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
     const f3 v00 = mk3(pa.x, pa.y, pa.z), v10 = mk3(pa.w, pb.x, pb.y), v01 = mk3(pb.z, pb.w, pc.x), v11 = mk3(pc.y, pc.z, pc.w);
     const bool never = R.never_traced != nullptr && R.never_traced[idx] != 0;
     const uint32_t py = idx / R.width, px = idx - py * R.width;
-    const uint32_t bn_i = (py & 255u) * 256u + (px & 255u);
-    const float2* bnp = R.blue_noise + bn_i;
-    // JITTER BY RECURRENCE (round 5): entry i of iteration k's table is the chunk's start state advanced k x stride golden-ratio steps, clamped to [0, 1]
-    // (blue_noise_kernel, vpt_resolve.hip).  The tail walks its pixel's iterations in order anyway, so it carries (x, y) along and re-derives every jitter with
-    // the table's own operations -- fmodf(x + phi, 1) is EXACT, and for 0 <= t < 2^24 it is t - floorf(t) -- instead of reading 8 bytes per pixel-sample back:
-    // 1.06 of the 2.4 GB the kernel moved per 64-iteration launch at 1080p.  Same bits (tests/test_gpu_edge.py: VPT_NO_JITTER_RECURRENCE).
-    bool rec = R.bn_start != nullptr;
-    float jx = 0.0f, jy = 0.0f;
-    if (rec) {
-        const float2 s0 = R.bn_start[bn_i];
-        jx = s0.x; jy = s0.y;
-        // (a start state outside [0, 2^24) -- outside the contract of vpt_abi.h: jitters lie in [0, 1] -- keeps the table: from a state in range every later one is in [0, 1))
-        rec = jx >= 0.0f && jx < 16777216.0f && jy >= 0.0f && jy < 16777216.0f;
-    }
-    const bool bn_adv = bn_i < R.bn_live;
-    auto bn_step = [&](float v) { const float t = v + VPT_BN_PHI; return t - floorf(t); };
+    const float2* bnp = R.blue_noise + ((py & 255u) * 256u + (px & 255u));
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
     RunningMeans rm = RunningMeans::load(R, idx);
     for (uint32_t k0 = 0; k0 < R.iter_count; k0 += (uint32_t)VPT_TAIL_GROUP) {
@@ -490,13 +475,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
             const bool live = k < R.iter_count;
             // a pixel raygen emitted nothing for has no heads: every sample is untraced with depth 0 (or not rendered)
             h[u] = (live && !never) ? ld_stream(R.heads + ((size_t)k * R.n_pixels + idx)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (rec) {
-                j[u] = make_float2(fminf(fmaxf(jx, 0.0f), 1.0f), fminf(fmaxf(jy, 0.0f), 1.0f));
-                if (bn_adv)
-                    for (uint32_t s = 0; s < R.iter_stride; ++s) { jx = bn_step(jx); jy = bn_step(jy); }
-            } else {
-                j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
-            }
+            j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
         for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
