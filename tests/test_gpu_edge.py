@@ -383,3 +383,38 @@ def test_tails_on_their_own_stream_change_nothing(pkg, monkeypatch, kind):
     assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "cloud vol_integrator"])
+def test_compact_ray_records_change_nothing(pkg, monkeypatch, kind):
+    """Behind a closed lens a queued ray's record is 32 bytes -- {position reached | (t_hit, depth, t_box), packed word} + the Philox block -- instead of 64: the
+    origin is the camera's, the direction is the sample's head, the Philox counter follows from the iteration (csrc/vpt_device.h: TraceParams::compact_rays;
+    vpt_trace_common.h: load_ray_record rebuilds the 64-byte layout's values).  Against VPT_NO_COMPACT_RAYS=1: every buffer and every count identical, counting
+    build (it carries raygen's push count in the word) and timed build, chunked batches, frames."""
+    sd = _frame_scene(pkg, kind)
+    monkeypatch.setenv("VPT_BATCH_ITERS", "3")
+
+    def run(counting):
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(counting)
+        hb.render(7)
+        hb.render_frame()
+        hb.render(2)
+        hb.sync()
+        st = hb.ctx.stats()
+        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+        hb.ctx.close()
+        return out, st
+    res = {}
+    for counting in (True, False):
+        res[counting] = run(counting)
+    monkeypatch.setenv("VPT_NO_COMPACT_RAYS", "1")
+    for counting in (True, False):
+        a, sa = res[counting]
+        b, sb = run(counting)
+        assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg="%s (counting %s)" % (k, counting))
+        if counting:
+            for c in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+                assert getattr(sa, c) == getattr(sb, c), c

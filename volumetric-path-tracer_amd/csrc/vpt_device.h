@@ -186,6 +186,12 @@ struct TraceParams {
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
     uint32_t chunk;                  // queue entries a wave claims per global atomic: VPT_CHUNK, half of it for launches of a few iterations
     uint32_t raygen_small_iters;     // launches of fewer iterations run raygen over 16-row tiles (four times the blocks)
+    // COMPACT RAY RECORDS (round 5; closed lens + heads): a queued ray's record is 32 bytes instead of 64 -- {a.x, a.y, a.z, word} + the Philox block, where
+    // a = the position raygen's empty-node pushes reached, or (t_hit, depth, t_box), and word = obj [0:6] | advanced [7] | pushes [8:13] | Philox word index
+    // [14:16] | Philox blocks since the sample's stream origin [17:31].  The origin is the camera's, the direction is the sample's 16-byte head (written
+    // anyway), the counter follows from the iteration: raygen writes 48 bytes per traced sample instead of 80 (config 3's raygen is store-bound), the refill
+    // reads 48 instead of 64.  The slot stays one 64-byte line: a path the dome cannot serve overwrites it with its path record (load_ray_record, vpt_trace_common.h).
+    int compact_rays;
     uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor

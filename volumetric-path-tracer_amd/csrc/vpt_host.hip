@@ -216,6 +216,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_pixel_cull = std::getenv("VPT_NO_PIXEL_CULL") != nullptr;
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
+    ctx->no_compact_rays = std::getenv("VPT_NO_COMPACT_RAYS") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     ctx->no_leaf_cull = std::getenv("VPT_NO_LEAF_CULL") != nullptr;
     { const char* tw = std::getenv("VPT_TEX_WEIGHTS"); ctx->tex_fixed8 = tw != nullptr && std::strcmp(tw, "fixed8") == 0; }
@@ -1378,6 +1379,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     }
     R.heads = P.heads;
     R.head_org = P.head_org;
+    // compact 32-byte ray records (vpt_device.h): the origin must be the camera's for every sample (closed lens) and the direction in a head
+    P.compact_rays = (compact && cam->lens_radius == 0.0f && !ctx->no_compact_rays && !ctx->use_pool) ? 1 : 0;
     R.cam_origin[0] = cam->origin.x; R.cam_origin[1] = cam->origin.y; R.cam_origin[2] = cam->origin.z;
     P.queue = ctx->d_queue;
     P.queue_tail = ctx->d_work_counter + 8;

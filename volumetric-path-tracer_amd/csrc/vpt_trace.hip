@@ -224,7 +224,12 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
                 // plus its origin when the lens is open (lens_radius == 0: org0 is the camera origin for every sample)
                 st_stream(P.heads + s, make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f)));
                 if (P.head_org && !traced) st_stream(P.head_org + s, make_float4(org0.x, org0.y, org0.z, 0.0f));
-                if (traced) { st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3); }
+                if (traced && P.compact_rays) {
+                    // 32 bytes (TraceParams::compact_rays): the origin is the camera's, the direction is in the head, the counter follows from the iteration
+                    const uint32_t word = ((uint32_t)obj | adv) | (rng.idx << 14) | ((rng.c0 - iteration * 1024u) << 17);
+                    st_stream(dst, make_float4(r0.w, r3.z, r3.w, __uint_as_float(word)));
+                    st_stream(dst + 1, r2);
+                } else if (traced) { st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3); }
             } else {
                 st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3);
             }
@@ -380,10 +385,9 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
                         uint32_t new_kiter, new_pixel;
                         split_slot(P, slot, new_kiter, new_pixel);
-                        const float4* src = reinterpret_cast<const float4*>(P.records + slot);
 #ifdef VPT_PROFILE_SECTIONS
                         // (study builds: the wave waits for its records HERE, outside the divergent block, and times the wait apart from the unpacking)
-                        q0 = ld_stream(src); q1 = ld_stream(src + 1); q2 = ld_stream(src + 2); q3 = ld_stream(src + 3);
+                        load_ray_record(P, slot, P.iter_begin + new_kiter * P.iter_stride, q0, q1, q2, q3);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -393,7 +397,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                         uint32_t new_kiter, new_pixel;
                         split_slot(P, rel >> 6 == 0u ? e0 : (rel >> 6 == 1u ? e1 : (rel >> 6 == 2u ? e2 : e3)), new_kiter, new_pixel);
 #else
-                        const float4 q0 = ld_stream(src), q1 = ld_stream(src + 1), q2 = ld_stream(src + 2), q3 = ld_stream(src + 3);
+                        float4 q0, q1, q2, q3;
+                        load_ray_record(P, slot, P.iter_begin + new_kiter * P.iter_stride, q0, q1, q2, q3);
 #endif
                         kiter = new_kiter;
                         pixel = new_pixel;

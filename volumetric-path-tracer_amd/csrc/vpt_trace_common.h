@@ -158,6 +158,26 @@ VPT_D ColdConst load_cold_const() {
     c.records = k->records;
     return c;
 }
+// A queued ray's record as the refill unpacks it (the 64-byte layout raygen writes behind an open lens or without heads):
+//   q0 = {origin, t_hit | adv.x}  q1 = {dir, obj word}  q2 = Philox block  q3 = {counter, word index, depth | adv.y, t_box | adv.z}
+// -- loaded as such, or REBUILT from a compact 32-byte record + the sample's head + the camera origin (TraceParams::compact_rays): the same values, so
+// everything behind this function is one code path.  Launch constants come through the laundered kernel-argument pointer (scalar loads at the refill,
+// nothing carried through the loop).
+VPT_D void load_ray_record(const TraceParams& P, uint32_t slot, uint32_t iteration, float4& q0, float4& q1, float4& q2, float4& q3) {
+    KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    const float4* src = reinterpret_cast<const float4*>(k->records + slot);
+    if (k->compact_rays) {
+        const float4 c0 = ld_stream(src), c1 = ld_stream(src + 1), h = ld_stream(k->heads + slot);
+        const uint32_t word = __float_as_uint(c0.w);
+        q0 = make_float4(k->cam.origin[0] + 0.0f, k->cam.origin[1] + 0.0f, k->cam.origin[2] + 0.0f, c0.x);      // (raygen's `origin + offset` with the closed lens' offset of +0)
+        q1 = make_float4(h.x, h.y, h.z, __uint_as_float(word & 0x3fffu));
+        q2 = c1;
+        q3 = make_float4(__uint_as_float(iteration * 1024u + (word >> 17)), __uint_as_float((word >> 14) & 7u), c0.y, c0.z);
+    } else {
+        q0 = ld_stream(src); q1 = ld_stream(src + 1); q2 = ld_stream(src + 2); q3 = ld_stream(src + 3);
+    }
+}
 // TraceParams::resolve for one batch of finishing paths (PH_T_FINISH): 13 dwords from the kernel-argument segment
 VPT_D ResolveInTracer load_resolve() {
     KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
