@@ -112,6 +112,8 @@ struct vpt_ctx {
     // scratch
     vpt::Record* d_records = nullptr;
     float4* d_heads = nullptr;             // 16-byte sample heads, same capacity as d_records
+    float4* d_rays32 = nullptr;            // compact 32-byte ray records (TraceParams::rays32), same capacity, allocated on first use
+    size_t rays32_capacity = 0;
     float2* d_td = nullptr;                // {alpha, depth} of the resolved samples (TraceParams::td), same capacity, allocated on first use
     size_t td_capacity = 0;
     uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td

@@ -190,8 +190,10 @@ struct TraceParams {
     // a = the position raygen's empty-node pushes reached, or (t_hit, depth, t_box), and word = obj [0:6] | advanced [7] | pushes [8:13] | Philox word index
     // [14:16] | Philox blocks since the sample's stream origin [17:31].  The origin is the camera's, the direction is the sample's 16-byte head (written
     // anyway), the counter follows from the iteration: raygen writes 48 bytes per traced sample instead of 80 (config 3's raygen is store-bound), the refill
-    // reads 48 instead of 64.  The slot stays one 64-byte line: a path the dome cannot serve overwrites it with its path record (load_ray_record, vpt_trace_common.h).
+    // reads 48 instead of 64.  The compact records live in their OWN dense array (`rays32`, 32-byte stride): written into the first half of the 64-byte record slots
+    // they cost raygen +10-17 % (half-filled lines: profiles/r05_compact_rays.txt); records[] keeps the 64-byte path records of the paths the dome cannot serve.
     int compact_rays;
+    float4* rays32;                  // [iter_count][n_pixels][2]
     uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor

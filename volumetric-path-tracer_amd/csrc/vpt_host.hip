@@ -281,6 +281,7 @@ void vpt_destroy(vpt_ctx* ctx) {
     (void)hipFree(ctx->d_sub_offsets);
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_heads);
+    (void)hipFree(ctx->d_rays32);
     (void)hipFree(ctx->d_td);
     (void)hipFree(ctx->d_queue2);
     (void)hipFree(ctx->d_nopatch);
@@ -1381,6 +1382,15 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     R.head_org = P.head_org;
     // compact 32-byte ray records (vpt_device.h): the origin must be the camera's for every sample (closed lens) and the direction in a head
     P.compact_rays = (compact && cam->lens_radius == 0.0f && !ctx->no_compact_rays && !ctx->use_pool) ? 1 : 0;
+    if (P.compact_rays) {
+        if (ctx->rays32_capacity < ctx->records_capacity) {
+            { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
+            (void)hipFree(ctx->d_rays32); ctx->d_rays32 = nullptr; ctx->rays32_capacity = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_rays32, ctx->records_capacity * 2u * sizeof(float4)));
+            ctx->rays32_capacity = ctx->records_capacity;
+        }
+        P.rays32 = ctx->d_rays32;
+    }
     R.cam_origin[0] = cam->origin.x; R.cam_origin[1] = cam->origin.y; R.cam_origin[2] = cam->origin.z;
     P.queue = ctx->d_queue;
     P.queue_tail = ctx->d_work_counter + 8;

@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
                 if (traced && P.compact_rays) {
                     // 32 bytes (TraceParams::compact_rays): the origin is the camera's, the direction is in the head, the counter follows from the iteration
                     const uint32_t word = ((uint32_t)obj | adv) | (rng.idx << 14) | ((rng.c0 - iteration * 1024u) << 17);
-                    st_stream(dst, make_float4(r0.w, r3.z, r3.w, __uint_as_float(word)));
-                    st_stream(dst + 1, r2);
+                    float4* d32 = P.rays32 + 2u * (size_t)s;
+                    st_stream(d32, make_float4(r0.w, r3.z, r3.w, __uint_as_float(word)));
+                    st_stream(d32 + 1, r2);
                 } else if (traced) { st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3); }
             } else {
                 st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3);

@@ -166,8 +166,8 @@ VPT_D ColdConst load_cold_const() {
 VPT_D void load_ray_record(const TraceParams& P, uint32_t slot, uint32_t iteration, float4& q0, float4& q1, float4& q2, float4& q3) {
     KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
-    const float4* src = reinterpret_cast<const float4*>(k->records + slot);
     if (k->compact_rays) {
+        const float4* src = k->rays32 + 2u * (size_t)slot;
         const float4 c0 = ld_stream(src), c1 = ld_stream(src + 1), h = ld_stream(k->heads + slot);
         const uint32_t word = __float_as_uint(c0.w);
         q0 = make_float4(k->cam.origin[0] + 0.0f, k->cam.origin[1] + 0.0f, k->cam.origin[2] + 0.0f, c0.x);      // (raygen's `origin + offset` with the closed lens' offset of +0)
@@ -175,6 +175,7 @@ VPT_D void load_ray_record(const TraceParams& P, uint32_t slot, uint32_t iterati
         q2 = c1;
         q3 = make_float4(__uint_as_float(iteration * 1024u + (word >> 17)), __uint_as_float((word >> 14) & 7u), c0.y, c0.z);
     } else {
+        const float4* src = reinterpret_cast<const float4*>(k->records + slot);
         q0 = ld_stream(src); q1 = ld_stream(src + 1); q2 = ld_stream(src + 2); q3 = ld_stream(src + 3);
     }
 }
