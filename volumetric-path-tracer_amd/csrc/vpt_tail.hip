@@ -476,11 +476,9 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
             // a pixel raygen emitted nothing for has no heads: every sample is untraced with depth 0 (or not rendered)
             h[u] = (live && !never) ? ld_stream(R.heads + ((size_t)k * R.n_pixels + idx)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
-            const uint32_t k = k0 + u;
-            td[u] = (k < R.iter_count && h[u].w == -1.0f) ? ld_stream(R.td + ((size_t)k * R.n_pixels + idx)) : make_float2(0.0f, 0.0f);
+            // {alpha, depth} is requested WITH the head, not behind it (round 5): only a resolved sample (head.w == -1) uses it, but waiting for the head to know that made
+            // every group two dependent round trips (8 more bytes read per live untraced sample; whatever they hold is ignored).  Tail -3 %: profiles/r05_compact_rays.txt
+            td[u] = (live && !never) ? ld_stream(R.td + ((size_t)k * R.n_pixels + idx)) : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
         for (uint32_t u = 0; u < (uint32_t)VPT_TAIL_GROUP; ++u) {
