@@ -79,7 +79,7 @@ def flips_block(lib, hb):
             "mean_cost_centre_variant": float(f[2]), "largest_mean_cost_all_variants": float(f[3]), "accepted_mean_cost": 3e-4}
 
 
-def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator, lean=False):
+def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator, lean=False, compact=False):
     """cs: stats of a counted pass, st: HIP-event times of the last timed step; lean: the tracer resolved its finished paths itself
     (24 bytes out per ray instead of a 64-byte path record, csrc/vpt_device.h ResolveParams::lean).
 
@@ -90,7 +90,7 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
     Next to it, recomputable from this line and profiles/ of the same commit:
       frac_kernel_issued_fetches: bytes the tracer itself has to move -- `lookup_bytes` (the trilinear fetches it ISSUES: density for the
           instances whose domain holds the point, colour at real collisions, emission) + `record_stream_bytes` (its own ray / path records:
-          4 + 64 B read and 64 B -- 24 B when `lean` -- written per traced ray; self-imposed traffic) / the tracer's HIP-event duration
+          4 + 64 B read -- 4 + 48 B with compact ray records -- and 64 B -- 24 B when `lean` -- written per traced ray; self-imposed traffic) / the tracer's HIP-event duration
       frac_step_issued_fetches: the issued look-up bytes + the 88-byte framebuffer term, x samples / whole-step time
       hbm_measured_frac: FETCH_SIZE x 2 + WRITE_SIZE of the tracer (rocprofv3 --pmc, profiles/traffic.json) / its duration"""
     n = float(max(1, cs.samples))
@@ -99,7 +99,9 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
     counted_iters = max(1.0, n / float(W * H))
     traced = cs.queued_rays / float(W * H) / counted_iters
     b_lookup = 32.0 * fd + 128.0 * fc + 32.0 * fe
-    b_records = (4.0 + 64.0 + (24.0 if lean else 64.0)) * traced
+    # the tracer's own record stream per traced ray: 4 B queue entry + the ray record it reads (64 B; behind a closed lens 32 B compact + the 16-byte head: csrc/vpt_device.h
+    # TraceParams::compact_rays) + what it writes (a 64-byte path record; 16 + 8 B when it resolves the sample itself)
+    b_records = (4.0 + (48.0 if compact else 64.0) + (24.0 if lean else 64.0)) * traced
     b_kernel = b_lookup + b_records
     b_step = b_lookup + 88.0
     b_ref = 32.0 * nd + 128.0 * nc + 32.0 * ne + 88.0
@@ -340,7 +342,9 @@ def main():
             cstate = (C.c_int * 8)()
             lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
             lib.vpt_test_get_cache_state(hb.ctx.h, cstate)
-            roofline = roofline_block(cfg, W, H, spp, cs, st, samples_per_step_rank, step_s, sd.kp.integrator, lean=bool(cstate[6]))
+            compact = float(sd.camera.lens_radius) == 0.0 and "VPT_NO_COMPACT_RAYS" not in os.environ and "VPT_NO_HEADS" not in os.environ
+            roofline = roofline_block(cfg, W, H, spp, cs, st, samples_per_step_rank, step_s, sd.kp.integrator, lean=bool(cstate[6]), compact=compact)
+            roofline["compact_ray_records"] = bool(compact)
             if not multi:
                 # what the per-view caches of the environment tail cost to build (once per view, in the warm-up): one step right after
                 # vpt_invalidate_sky_tables against the timed step
