@@ -716,10 +716,9 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     f3 dv;
                     if (oe.x == rt.cam_origin[0] && oe.y == rt.cam_origin[1] && oe.z == rt.cam_origin[2] && dome_lookup(rt.sky_dome, od, dv)) {
                         const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
-#ifndef VPT_EXPERIMENT_NO_FINISH_STORES          // (study build, wrong image: what the 24 scattered bytes per resolved path cost the tracer)
+                        // (their scatter costs the tracer 1.2 %: the same two stores to a per-thread fixed place, profiles/r05_compact_rays.txt; merged into one 32-byte sector: no better)
                         st_stream(rt.heads + slot, make_float4(val.x, val.y, val.z, -1.0f));
                         st_stream(rt.td + slot, make_float2(fmin_(w.alpha, 1.0f), depth));
-#endif
                         resolved = true;
                     }
                 }
