@@ -308,7 +308,7 @@ def _frame_scene(pkg, kind):
     return sd
 
 
-@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "instances open lens", "cloud vol_integrator"])
+@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "instances open lens", "cloud vol_integrator", "dragon sun+sky, render off at 12"])
 def test_frame_ahead_changes_nothing(pkg, monkeypatch, kind):
     """FRAME-AHEAD (csrc/vpt_ctx.h): from the second identical one-iteration call on, vpt_render traces the rays of the next 2, 4, 8, 16 iterations in
     one raygen + tracer launch and the following calls run only their tail.  Against VPT_NO_FRAME_AHEAD=1 (one launch per frame, as rounds 1-4):
@@ -316,7 +316,9 @@ def test_frame_ahead_changes_nothing(pkg, monkeypatch, kind):
     of the batches, a camera move in the middle of a batch (what was traced ahead is discarded), and a return to the first camera."""
     import ctypes as C
     from vpt_amd.abi import Float3
-    sd = _frame_scene(pkg, kind)
+    sd = _frame_scene(pkg, kind.split(",")[0])
+    if "render off" in kind:
+        sd.kp.max_interactions = 12                  # (iterations from 12 on are "not rendered": WHITE samples, :2248 -- the boundary falls inside a batch traced ahead)
     lib = pkg.load_library()
     frames, move_at, back_at = 23, 9, 14
 
