@@ -420,3 +420,57 @@ def test_compact_ray_records_change_nothing(pkg, monkeypatch, kind):
         if counting:
             for c in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays"):
                 assert getattr(sa, c) == getattr(sb, c), c
+
+
+@pytest.mark.parametrize("kind", ["instances open lens", "dragon open lens", "dragon open lens, sphere in view", "dragon open lens, render off at 3"])
+def test_resolved_samples_behind_an_open_lens_change_nothing(pkg, monkeypatch, kind):
+    """RESOLVED SAMPLES behind an OPEN lens (round 5): every sample starts somewhere on the lens disc, and the dome that serves its environment term is the one of
+    its origin's table variant (csrc/vpt_dome.h: dome_variant).  The tracer resolves finished paths from it, raygen resolves the UNTRACED samples from it (their head
+    then carries the value: no origin stream), sky_fix_kernel evaluates in full what no dome serves, and the tail only streams.  Against VPT_NO_LENS_LEAN=1 -- 64-byte
+    records, heads + origins, the environment added inside the tail's per-pixel loop: the same operations on the same values, so every buffer and count is identical,
+    counting and timed builds, chunked batches, frames (frame-ahead on top)."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    lib = pkg.load_library()
+    if kind.startswith("instances"):
+        sd = _frame_scene(pkg, "instances open lens")
+    else:
+        sd = pkg.scene.dragon_scene(256, 144, "c2")
+        o = sd.camera.origin
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(o.x, o.y, o.z), Float3(0.0, 0.0, 0.0), Float3(0, 1, 0), 30.0, 256 / 144, 1.5)
+        if "sphere" in kind:
+            sd.sphere.center = Float3(o.x * 0.55, o.y * 0.55 + 1.0, o.z * 0.55 - 2.0)
+            sd.sphere.radius = 1.5
+        if "render off" in kind:
+            sd.kp.max_interactions = 3
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    monkeypatch.setenv("VPT_BATCH_ITERS", "3")
+    lib.vpt_test_get_cache_state.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+
+    def run(counting):
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(counting)
+        hb.render(7)
+        state = (C.c_int * 8)()
+        assert lib.vpt_test_get_cache_state(hb.ctx.h, state) == 0
+        for _ in range(4):
+            hb.render_frame()
+        hb.render(2)
+        hb.sync()
+        st = hb.ctx.stats()
+        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+        hb.ctx.close()
+        return out, st, list(state)
+    res = {c: run(c) for c in (True, False)}
+    assert res[False][2][2] and res[False][2][6], res[False][2]           # lens domes + resolved samples in use
+    monkeypatch.setenv("VPT_NO_LENS_LEAN", "1")
+    for counting in (True, False):
+        a, sa, _ = res[counting]
+        b, sb, cb = run(counting)
+        assert cb[2] and not cb[6], cb
+        assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg="%s (counting %s)" % (k, counting))
+        if counting:
+            for c in ("samples", "density_lookups", "color_lookups", "tracking_steps", "skip_steps", "queued_rays"):
+                assert getattr(sa, c) == getattr(sb, c), c

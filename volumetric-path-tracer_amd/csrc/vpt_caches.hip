@@ -311,6 +311,30 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                 ctx->sky_patch_built = false;             // (the closed-lens dome in the same allocation is gone)
             }
             R.sky_dome = ctx->d_sky_dome;
+            // RESOLVED SAMPLES behind the open lens (round 5): the variant's dome serves traced paths in the tracer and untraced samples in raygen
+            if (!ctx->no_lean_tail && !ctx->use_pool && !ctx->no_lens_lean) {
+                if (ctx->td_capacity < ctx->records_capacity) {
+                    CHK(quiesce(ctx, stream));
+                    (void)hipFree(ctx->d_td); ctx->d_td = nullptr; ctx->td_capacity = 0;
+                    (void)hipFree(ctx->d_queue2); ctx->d_queue2 = nullptr;
+                    HIPCHK(ctx, hipMalloc(&ctx->d_td, ctx->records_capacity * sizeof(float2)));
+                    HIPCHK(ctx, hipMalloc(&ctx->d_queue2, ctx->records_capacity * sizeof(uint32_t)));
+                    ctx->td_capacity = ctx->records_capacity;
+                }
+                R.lean = 1;
+                R.td = ctx->d_td;
+                R.queue2 = ctx->d_queue2;
+                R.queue2_count = ctx->d_work_counter + 4;
+                ResolveInTracer rt;
+                std::memset(&rt, 0, sizeof(rt));
+                rt.sky_dome = R.sky_dome; rt.heads = ctx->d_heads; rt.td = ctx->d_td; rt.queue2 = ctx->d_queue2; rt.queue2_tail = ctx->d_work_counter + 4;
+                rt.cam_origin[0] = cam->origin.x; rt.cam_origin[1] = cam->origin.y; rt.cam_origin[2] = cam->origin.z;
+                rt.lens = 1;
+                rt.sky_view = ctx->d_sky_view;
+                rt.sun_dir[0] = R.sun_dir[0]; rt.sun_dir[1] = R.sun_dir[1]; rt.sun_dir[2] = R.sun_dir[2];
+                rt.earth_bottom = R.atm_f[0];
+                P.resolve = rt;
+            }
         }
     }
     return VPT_OK;

@@ -119,6 +119,7 @@ struct vpt_ctx {
     uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td
     uint32_t* d_nopatch = nullptr;         // [0]: count, [1..]: pixels without a usable sky patch (ResolveParams::nopatch_list), with d_sky_patch
     bool no_compact_rays = false;          // VPT_NO_COMPACT_RAYS: 64-byte ray records behind a closed lens too (tests: same bits either way)
+    bool no_lens_lean = false;             // VPT_NO_LENS_LEAN: behind an open lens the samples keep their records and the tail adds the environment (tests, A/B)
     bool no_lean_tail = false;             // VPT_NO_LEAN_TAIL: finished paths keep their 64-byte records and the tail adds the environment (A/B, tests)
     float4* d_head_org = nullptr;          // ray origins of the heads (thin lens: lens_radius != 0), allocated on first use
     size_t head_org_capacity = 0;

@@ -169,7 +169,13 @@ struct ResolveInTracer {
     uint32_t* queue2;                // record slots whose environment term needs the full evaluation
     uint32_t* queue2_tail;
     float cam_origin[3];
-    float pad_;
+    // OPEN LENS (round 5): every sample starts somewhere on the lens disc and the sky sees that origin only through (r, mu_s) -- one dome per table variant
+    // (SkyView: one per binary32 value of r within k steps of the camera origin's).  `lens` != 0: the dome that serves a sample is picked from its origin
+    // (dome_variant, vpt_dome.h) instead of requiring the camera origin bit for bit; raygen resolves the UNTRACED samples the same way.
+    int lens;
+    const SkyView* sky_view;
+    float sun_dir[3];
+    float earth_bottom;              // AtmosphereParameters::bottom_radius
 };
 
 struct TraceParams {

@@ -43,6 +43,16 @@ VPT_D f3 dome_direction(float fu, float fv) {
     const float rxz = fsqrt(fmax_(1.0f - v * v, 0.0f)) * frcp(fsqrt(x * x + z * z));
     return mk3(x * rxz, v, z * rxz);
 }
+// which dome (= which variant of the camera-point tables) serves a sample that looks from `pos`: the one whose r equals pos' binary32 distance from the earth's
+// centre, if that lies within k steps of the camera origin's and mu_s agrees (Sky::CamVariant, vpt_sky.h, with the tail's own operations); -1: none
+VPT_D int dome_variant(const SkyView* view, f3 pos, f3 sun_dir, float earth_bottom) {
+    const f3 pe = pos - mk3(0.0f, -earth_bottom, 0.0f);
+    const float re = length_rn(pe);
+    const float mu_s = dot(pe, sun_dir) * frcp(re);
+    const int vk = view->k;
+    const int k = (int)(__float_as_uint(re) - __float_as_uint(view->r)) + vk;
+    return (k >= 0 && k <= 2 * vk && fabsf(mu_s - view->mu_s) <= 1e-6f) ? k : -1;
+}
 // the dome's value along d (ResolveParams::sky_dome); false: the cell is flagged, evaluate in full
 VPT_D bool dome_lookup(const float4* __restrict__ dome, f3 d, f3& value) {
     float fu, fv;

@@ -217,6 +217,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
     ctx->no_compact_rays = std::getenv("VPT_NO_COMPACT_RAYS") != nullptr;
+    ctx->no_lens_lean = std::getenv("VPT_NO_LENS_LEAN") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     ctx->no_leaf_cull = std::getenv("VPT_NO_LEAF_CULL") != nullptr;
     { const char* tw = std::getenv("VPT_TEX_WEIGHTS"); ctx->tex_fixed8 = tw != nullptr && std::strcmp(tw, "fixed8") == 0; }

@@ -410,13 +410,16 @@ __global__ __launch_bounds__(256, VPT_TAIL_WAVES_PER_EU) void tail_resolve_kerne
 //   (a) queue2: finished paths whose exit direction falls into a flagged dome cell, or whose origin the sphere bounce moved -- their 64-byte
 //       record is read, the environment term added as the tail would (:1838-1842), the sample written as head + td;
 //   (b) the untraced samples of the pixels without a usable patch (nopatch_list x the launch's iterations): L = 0, beta = 1, from the camera origin.
+// LENS (round 5): behind an open lens queue2 also holds the UNTRACED samples raygen could not resolve from a dome (their 64-byte final record: L = 0, beta = 1); there
+// are no patches, so no (b)
+template <bool LENS>
 __global__ __launch_bounds__(256) void sky_fix_kernel(const ResolveParams R, float4* __restrict__ heads) {
     Sky<ResolveParams> sky = {R};
-    load_sky_view<false>(R, sky);
+    load_sky_view<LENS>(R, sky);
     const bool use_dir_tab = R.dir_tab != nullptr && R.dir_tab_err[8] != 0u;
     const f3 sky_color = mk3(R.sky_color[0], R.sky_color[1], R.sky_color[2]);
     const f3 sun_dir = mk3(R.sun_dir[0], R.sun_dir[1], R.sun_dir[2]);
-    const uint32_t n_a = *R.queue2_count, n_b = *R.nopatch_count * R.iter_count;
+    const uint32_t n_a = *R.queue2_count, n_b = LENS ? 0u : *R.nopatch_count * R.iter_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_a + n_b; t += stride) {
         if (t < n_a) {
@@ -455,15 +458,18 @@ __global__ __launch_bounds__(256) void sky_fix_kernel(const ResolveParams R, flo
 #ifndef VPT_TAIL_STREAM_WAVES_PER_EU
 #define VPT_TAIL_STREAM_WAVES_PER_EU 6
 #endif
+// LENS (round 5): behind an open lens there are no patches -- an untraced sample's head already holds its VALUE (raygen resolved it from the dome of its origin's
+// variant): {value, depth}; everything else as behind a closed lens
+template <bool LENS>
 __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream_kernel(const ResolveParams R) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R.n_pixels) return;
-    const float4* pp = R.sky_patch + 3u * (size_t)idx;
-    const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+    float4 pa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pb = pa, pc = pa;
+    if (!LENS) { const float4* pp = R.sky_patch + 3u * (size_t)idx; pa = pp[0]; pb = pp[1]; pc = pp[2]; }
     const f3 v00 = mk3(pa.x, pa.y, pa.z), v10 = mk3(pa.w, pb.x, pb.y), v01 = mk3(pb.z, pb.w, pc.x), v11 = mk3(pc.y, pc.z, pc.w);
-    const bool never = R.never_traced != nullptr && R.never_traced[idx] != 0;
+    const bool never = !LENS && R.never_traced != nullptr && R.never_traced[idx] != 0;
     const uint32_t py = idx / R.width, px = idx - py * R.width;
-    const float2* bnp = R.blue_noise + ((py & 255u) * 256u + (px & 255u));
+    const float2* bnp = LENS ? nullptr : R.blue_noise + ((py & 255u) * 256u + (px & 255u));
     const uint32_t local_it0 = R.iter_begin / R.iter_stride;
     RunningMeans rm = RunningMeans::load(R, idx);
     for (uint32_t k0 = 0; k0 < R.iter_count; k0 += (uint32_t)VPT_TAIL_GROUP) {
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
             const bool live = k < R.iter_count;
             // a pixel raygen emitted nothing for has no heads: every sample is untraced with depth 0 (or not rendered)
             h[u] = (live && !never) ? ld_stream(R.heads + ((size_t)k * R.n_pixels + idx)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            j[u] = live ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
+            j[u] = (live && !LENS) ? bnp[(size_t)k * 65536u] : make_float2(0.0f, 0.0f);
             // {alpha, depth} is requested WITH the head, not behind it (round 5): only a resolved sample (head.w == -1) uses it, but waiting for the head to know that made
             // every group two dependent round trips (8 more bytes read per live untraced sample; whatever they hold is ignored).  Tail -3 %: profiles/r05_compact_rays.txt
             td[u] = (live && !never) ? ld_stream(R.td + ((size_t)k * R.n_pixels + idx)) : make_float2(0.0f, 0.0f);
@@ -490,7 +496,8 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
                 if (never) {
                     value = (iteration < R.max_interactions && R.render) ? flerp3(flerp3(v00, v10, j[u].x), flerp3(v01, v11, j[u].x), j[u].y) : mk3(1.0f);
                 } else if (h[u].w >= 0.0f) {
-                    value = flerp3(flerp3(v00, v10, j[u].x), flerp3(v01, v11, j[u].x), j[u].y);      // untraced: the patch at the sample's jitter
+                    if (LENS) value = mk3(h[u].x, h[u].y, h[u].z);                                  // untraced, resolved by raygen from its origin's dome
+                    else value = flerp3(flerp3(v00, v10, j[u].x), flerp3(v01, v11, j[u].x), j[u].y);      // untraced: the patch at the sample's jitter
                     depth = h[u].w;
                 } else if (h[u].w == -1.0f) {
                     value = mk3(h[u].x, h[u].y, h[u].z);                                               // resolved by the tracer or by sky_fix_kernel
@@ -506,11 +513,13 @@ __global__ __launch_bounds__(256, VPT_TAIL_STREAM_WAVES_PER_EU) void tail_stream
     rm.store(R, idx);
 }
 hipError_t launch_sky_fix(const ResolveParams& R, hipStream_t stream) {
-    hipLaunchKernelGGL(sky_fix_kernel, dim3(512), dim3(256), 0, stream, R, const_cast<float4*>(R.heads));
+    if (R.lens_radius != 0.0f) hipLaunchKernelGGL(sky_fix_kernel<true>, dim3(512), dim3(256), 0, stream, R, const_cast<float4*>(R.heads));
+    else hipLaunchKernelGGL(sky_fix_kernel<false>, dim3(512), dim3(256), 0, stream, R, const_cast<float4*>(R.heads));
     return hipGetLastError();
 }
 hipError_t launch_tail_stream(const ResolveParams& R, hipStream_t stream) {
-    hipLaunchKernelGGL(tail_stream_kernel, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
+    if (R.lens_radius != 0.0f) hipLaunchKernelGGL(tail_stream_kernel<true>, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
+    else hipLaunchKernelGGL(tail_stream_kernel<false>, dim3((R.n_pixels + 255u) / 256u), dim3(256), 0, stream, R);
     return hipGetLastError();
 }
 

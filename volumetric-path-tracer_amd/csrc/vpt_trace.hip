@@ -53,7 +53,9 @@ namespace vpt {
 #ifndef VPT_RAYGEN_WAVES_PER_EU
 #define VPT_RAYGEN_WAVES_PER_EU 7          // 72 registers, no spill (8: 64 registers + 8 spilled, slower; profiles/r04_four_waves.txt)
 #endif
-template <bool COUNT, int VPT_RAYGEN_ROWS>
+// LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
+// would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
+template <bool COUNT, int VPT_RAYGEN_ROWS, bool LENSRES>
 __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(const TraceParams P) {
     // grid: tiles x iterations (1-D, tile-major); a block sweeps a 64x64 pixel tile in 16 passes and
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
@@ -219,7 +221,30 @@ __global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(co
                 r3 = make_float4(__uint_as_float(rng.c0), __uint_as_float(rng.idx), adv ? adv_pos.y : depth, adv ? adv_pos.z : t_box);
                 enqueue = true;
             }
-            if (P.heads) {
+            if (LENSRES && P.heads && !traced && rendered) {
+                // OPEN LENS + RESOLVED SAMPLES (round 5): an untraced sample's value is its environment term alone -- L = 0, beta = 1 -- and behind an open lens
+                // that is a look-up in the dome of its origin's variant (what the tail did per sample, one dependent load after the other): done here, at full
+                // lanes, the sample leaves as ONE 16-byte head {value, depth} (no origin stream).  What the dome cannot serve (no variant for this origin, a
+                // flagged cell) keeps the 64-byte final record and goes to sky_fix_kernel through queue2, like a traced path the tracer could not resolve.
+                f3 dv;
+                const int dcv = dome_variant(P.resolve.sky_view, org0, ld3(P.resolve.sun_dir), P.resolve.earth_bottom);
+                const bool served = dcv >= 0 && dome_lookup(P.resolve.sky_dome + (size_t)dcv * ((size_t)SKY_DOME_NU * SKY_DOME_NV), dir0, dv);
+                if (served) {
+                    const f3 val = mk3(0.0f) + dv * mk3(1.0f);                          // (the tail's `value += dv * beta` with value = L = 0, beta = 1)
+                    st_stream(P.heads + s, make_float4(val.x, val.y, val.z, depth));
+                } else {
+                    st_stream(P.heads + s, make_float4(dir0.x, dir0.y, dir0.z, -1.0f));
+                    st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3);
+                }
+                const unsigned long long qm = __ballot(!served);
+                if (qm != 0ull) {
+                    const int ql = __ffsll((long long)qm) - 1;
+                    uint32_t qb = 0;
+                    if (lane == ql) qb = atomicAdd(P.resolve.queue2_tail, (uint32_t)__popcll(qm));
+                    qb = (uint32_t)__shfl((int)qb, ql);
+                    if (!served) P.resolve.queue2[qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = s;
+                }
+            } else if (P.heads) {
                 // compact stream: a sample that starts no walk is fully described by its 16-byte head {dir0, depth} --
                 // plus its origin when the lens is open (lens_radius == 0: org0 is the camera origin for every sample)
                 st_stream(P.heads + s, make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f)));
@@ -714,7 +739,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 const bool resolving = rt.sky_dome != nullptr;
                 if (resolving) {
                     f3 dv;
-                    if (oe.x == rt.cam_origin[0] && oe.y == rt.cam_origin[1] && oe.z == rt.cam_origin[2] && dome_lookup(rt.sky_dome, od, dv)) {
+                    // the dome that serves this path's origin: the camera origin's (closed lens: env_pos must equal it bit for bit), or the lens variant of its r
+                    int dcv = -1;
+                    if (rt.lens) dcv = dome_variant(rt.sky_view, oe, mk3(rt.sun_dir[0], rt.sun_dir[1], rt.sun_dir[2]), rt.earth_bottom);
+                    else if (oe.x == rt.cam_origin[0] && oe.y == rt.cam_origin[1] && oe.z == rt.cam_origin[2]) dcv = 0;
+                    if (dcv >= 0 && dome_lookup(rt.sky_dome + (size_t)dcv * ((size_t)SKY_DOME_NU * SKY_DOME_NV), od, dv)) {
                         const f3 val = oL + dv * ob;                                    // (the tail's `value += dv * beta`, :1838-1842)
                         // (their scatter costs the tracer 1.2 %: the same two stores to a per-thread fixed place, profiles/r05_compact_rays.txt; merged into one 32-byte sector: no better)
                         st_stream(rt.heads + slot, make_float4(val.x, val.y, val.z, -1.0f));
@@ -779,12 +808,13 @@ hipError_t launch_raygen(const TraceParams& P, hipStream_t stream) {
     const bool small = P.iter_count < P.raygen_small_iters;      // (17 unless VPT_RAYGEN_SMALL_ITERS says otherwise)
     const uint32_t rows = small ? 16u : 64u;
     const dim3 grid(((P.width + 63u) / 64u) * ((P.height + rows - 1u) / rows) * P.iter_count), block(64, 4, 1);
+    const bool lensres = P.heads != nullptr && P.resolve.lens != 0 && P.resolve.sky_dome != nullptr;
     if (small) {
-        if (P.counters) hipLaunchKernelGGL((raygen_kernel<true, 16>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((raygen_kernel<false, 16>), grid, block, 0, stream, P);
+        if (P.counters) { if (lensres) hipLaunchKernelGGL((raygen_kernel<true, 16, true>), grid, block, 0, stream, P); else hipLaunchKernelGGL((raygen_kernel<true, 16, false>), grid, block, 0, stream, P); }
+        else { if (lensres) hipLaunchKernelGGL((raygen_kernel<false, 16, true>), grid, block, 0, stream, P); else hipLaunchKernelGGL((raygen_kernel<false, 16, false>), grid, block, 0, stream, P); }
     } else {
-        if (P.counters) hipLaunchKernelGGL((raygen_kernel<true, 64>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((raygen_kernel<false, 64>), grid, block, 0, stream, P);
+        if (P.counters) { if (lensres) hipLaunchKernelGGL((raygen_kernel<true, 64, true>), grid, block, 0, stream, P); else hipLaunchKernelGGL((raygen_kernel<true, 64, false>), grid, block, 0, stream, P); }
+        else { if (lensres) hipLaunchKernelGGL((raygen_kernel<false, 64, true>), grid, block, 0, stream, P); else hipLaunchKernelGGL((raygen_kernel<false, 64, false>), grid, block, 0, stream, P); }
     }
     return hipGetLastError();
 }

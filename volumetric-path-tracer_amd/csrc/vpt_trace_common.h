@@ -187,7 +187,8 @@ VPT_D ResolveInTracer load_resolve() {
     r.sky_dome = k->resolve.sky_dome; r.heads = k->resolve.heads; r.td = k->resolve.td;
     r.queue2 = k->resolve.queue2; r.queue2_tail = k->resolve.queue2_tail;
     r.cam_origin[0] = k->resolve.cam_origin[0]; r.cam_origin[1] = k->resolve.cam_origin[1]; r.cam_origin[2] = k->resolve.cam_origin[2];
-    r.pad_ = 0.0f;
+    r.lens = k->resolve.lens; r.sky_view = k->resolve.sky_view; r.earth_bottom = k->resolve.earth_bottom;
+    r.sun_dir[0] = k->resolve.sun_dir[0]; r.sun_dir[1] = k->resolve.sun_dir[1]; r.sun_dir[2] = k->resolve.sun_dir[2];
     return r;
 }
 
