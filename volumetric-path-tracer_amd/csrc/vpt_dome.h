@@ -46,12 +46,16 @@ VPT_D f3 dome_direction(float fu, float fv) {
 // which dome (= which variant of the camera-point tables) serves a sample that looks from `pos`: the one whose r equals pos' binary32 distance from the earth's
 // centre, if that lies within k steps of the camera origin's and mu_s agrees (Sky::CamVariant, vpt_sky.h, with the tail's own operations); -1: none
 VPT_D int dome_variant(const SkyView* view, f3 pos, f3 sun_dir, float earth_bottom) {
+    // (the view point's three scalars through the CONSTANT address space: written by sky_view_kernel before this launch, launch-uniform address -> scalar loads;
+    // as plain global loads they were three dependent vector loads per batch of finishing paths)
+    const __attribute__((address_space(4))) SkyView* v = (const __attribute__((address_space(4))) SkyView*)view;
+    const float view_r = v->r, view_mu_s = v->mu_s;
+    const int vk = v->k;
     const f3 pe = pos - mk3(0.0f, -earth_bottom, 0.0f);
     const float re = length_rn(pe);
     const float mu_s = dot(pe, sun_dir) * frcp(re);
-    const int vk = view->k;
-    const int k = (int)(__float_as_uint(re) - __float_as_uint(view->r)) + vk;
-    return (k >= 0 && k <= 2 * vk && fabsf(mu_s - view->mu_s) <= 1e-6f) ? k : -1;
+    const int k = (int)(__float_as_uint(re) - __float_as_uint(view_r)) + vk;
+    return (k >= 0 && k <= 2 * vk && fabsf(mu_s - view_mu_s) <= 1e-6f) ? k : -1;
 }
 // the dome's value along d (ResolveParams::sky_dome); false: the cell is flagged, evaluate in full
 VPT_D bool dome_lookup(const float4* __restrict__ dome, f3 d, f3& value) {

@@ -55,8 +55,11 @@ namespace vpt {
 #endif
 // LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
 // would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
+#ifndef VPT_RAYGEN_LENS_WAVES
+#define VPT_RAYGEN_LENS_WAVES VPT_RAYGEN_WAVES_PER_EU
+#endif
 template <bool COUNT, int VPT_RAYGEN_ROWS, bool LENSRES>
-__global__ __launch_bounds__(256, VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(const TraceParams P) {
     // grid: tiles x iterations (1-D, tile-major); a block sweeps a 64x64 pixel tile in 16 passes and
     // compacts its active rays in LDS, so the global queue tail sees ONE atomic per 4096 samples
     __shared__ uint32_t s_q[64 * VPT_RAYGEN_ROWS];
