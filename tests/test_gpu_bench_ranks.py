@@ -128,8 +128,22 @@ def test_single_rank_bench_line_contract():
     oc = d["other_configs"]
     assert len(oc) == 3
     for o in oc:
-        # (config 5's `frac` may exceed 1: the reference-defined counts charge the colour look-ups the reference evaluates and discards)
-        assert o["value"] > 0 and "workload" in o["config"] and o["roofline"]["frac"] > 0 and 0 < o["roofline"]["frac_step_issued_fetches"] < 1
+        rfo = o["roofline"]
+        assert o["value"] > 0 and "workload" in o["config"] and 0 < rfo["frac_step_issued_fetches"] < 1
+        # no figure in the line is above 1 under the name of a fraction (round 5): where BASELINE.md's bytes per sample x samples/s exceed the peak -- config 5: the
+        # reference-defined counts charge the colour look-ups the reference evaluates and discards -- `frac` is null, `frac_void` says so, the raw ratio travels under
+        # another name and the kernel's own figure is promoted
+        if rfo["frac_void"]:
+            assert rfo["frac"] is None and rfo["achieved"] is None and rfo["reference_count_bytes_over_peak"] > 1.0
+            assert rfo["frac_promoted"]["name"] == "frac_kernel_issued_fetches" and 0 < rfo["frac_promoted"]["value"] < 1
+        else:
+            assert 0 < rfo["frac"] < 1
+    # both scalings, the cold view, the per-frame call either way and config 1 on one host thread travel in the same line
+    assert d["weak"]["value"] == d["value"] == d["strong"]["value"] and d["weak"]["frames_in_flight"] == 1
+    assert 0 < rf["cold_view_msamples_per_s"] <= d["value"] * 1.001 and rf["frac_void"] is False
+    assert pf["frame_by_frame"]["value"] > 0 and "frame_ahead" in pf
+    c1 = d["c1_cpu_single_thread"]
+    assert c1["cpu"]["cores"] == 1 and c1["cpu"]["value"] > 0 and c1["hip"]["value"] > 0 and c1["parity_rel_l2"] <= 1e-3 and c1["parity_depth_pixels_differing"] == 0
 
 
 def test_c_abi_allreduce_single_rank(pkg):
