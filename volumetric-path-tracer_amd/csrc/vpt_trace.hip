@@ -166,11 +166,8 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
             // repeating the pushes at its own lane occupancy.
             f3 adv_pos = mk3(0.0f);
             uint32_t adv = 0u;
-#ifdef VPT_EXPERIMENT_NO_RAYGEN_PUSHES          // (study build: what raygen's walk through the empty nodes costs it; the tracer then repeats the pushes)
-            if (false) {
-#else
+            // (round 5, measured again: these pushes cost raygen 0.22 of its 1.13 ms on config 2 and save the tracer 0.46 ms, profiles/r05_compact_rays.txt)
             if (traced && P.integrator == 0 && obj == 1 && !P.octree_full_single) {
-#endif
                 f3 pos = org0;
                 pos += dir0 * (t_hit + VPT_EPS);                                    // :1783-1785, as the tracer's refill does
                 const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
