@@ -278,6 +278,7 @@ def main():
         # everything a step enqueues goes to its context's own stream; torch ops on it through an ExternalStream view
         cstreams = [torch.cuda.ExternalStream(h.ctx.stream, device=dev) for h in hbs]
         step_no = [0]
+        last_reduce = [None]                              # event behind the previous frame's all-reduce (frames in flight: see below)
 
         def one_step():
             h = hbs[step_no[0] % in_flight]
@@ -299,7 +300,15 @@ def main():
             if not multi:
                 return
             if use_comm:
+                # frames in flight reduce through their own communicators on their own streams: the collectives are chained (each starts behind the previous
+                # frame's, on every rank alike), so that two communicators' kernels never wait for each other across ranks in different orders
+                if in_flight > 1 and last_reduce[0] is not None:
+                    cs_.wait_event(last_reduce[0])
                 pkg.dist.combine_means(h.accum, spp, ctx=h.ctx)
+                if in_flight > 1:
+                    ev_ = torch.cuda.Event()
+                    ev_.record(cs_)
+                    last_reduce[0] = ev_
             else:
                 h.sync()                                    # host-staged fallback (gloo): ctx stream -> torch's stream
                 pkg.dist.combine_means(h.accum, spp)
