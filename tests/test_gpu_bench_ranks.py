@@ -146,6 +146,20 @@ def test_single_rank_bench_line_contract():
     assert c1["cpu"]["cores"] == 1 and c1["cpu"]["value"] > 0 and c1["hip"]["value"] > 0 and c1["parity_rel_l2"] <= 1e-3 and c1["parity_depth_pixels_differing"] == 0
 
 
+def test_frames_in_flight_through_rccl_single_rank():
+    """the strong-scaling step with THREE frames in flight (three contexts, three RCCL communicators, the all-reduces chained by events) -- the N-rank code path with one
+    rank (VPT_BENCH_FORCE_DIST=1: process group + communicators under the C ABI + stream-ordered reduces), which is what a 1-GPU box can run of it"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(VPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "7", "--warmup", "2", "--width", "320", "--height", "180", "--spp", "4",
+           "--scaling", "strong", "--frames-in-flight", "3", "--no-cpu-baseline", "--no-other-configs", "--no-per-frame"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_in_flight"] == 3
+    assert d["config"]["collective"]["backend"].startswith("rccl") and d["config"]["collective"]["comm_ranks"] == 1
+
+
 def test_c_abi_allreduce_single_rank(pkg):
     """vpt_comm_* / vpt_allreduce_accum (RCCL loaded at run time, below the C ABI) on a one-rank communicator: the scale ->
     grouped all-reduce -> divide chain on the context's stream returns the rank's own mean, and vpt_resolve_display
