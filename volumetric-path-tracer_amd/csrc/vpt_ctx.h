@@ -140,7 +140,7 @@ struct vpt_ctx {
     float* d_comm_buf = nullptr;           // the collective's payload: this rank's weighted image + its iteration count in the last float
     size_t comm_buf_floats = 0;
     // tuning / test switches, read from the environment ONCE, when the context is created (vpt_create)
-    size_t relaid_min_bytes = (size_t)8 << 20;    // VPT_RELAID_MIN_BYTES: density / emission grids below this stay dense (they live in L2)
+    size_t relaid_min_bytes = 0;                  // VPT_RELAID_MIN_BYTES: density / emission grids below this stay dense.  0 since round 5: the corner quads are two loads and a third of the address arithmetic of the dense layout's eight -- also for a grid that lives in L2 (config 2's 425 KB dragon: tracer -1.2 %, profiles/r05_compact_rays.txt); 8 MiB in rounds 2-4
     int grid_layout = -1;                  // VPT_GRID_LAYOUT (tests): force "dense" / "bricks" / "quads" for grids >= relaid_min_bytes; -1: quads, bricks if those do not fit
     bool force_no_addr24 = false;          // VPT_NO_ADDR24: tests force the 32-bit texel index arithmetic
     unsigned batch_iters = 0;              // VPT_BATCH_ITERS: iterations per record chunk (0 = the 16-GiB rule)

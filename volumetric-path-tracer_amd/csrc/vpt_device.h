@@ -7,7 +7,7 @@
 //     bits) plus a CSR list of instance indices per leaf -- child boxes are re-derived
 //     arithmetically by halving the parent box (bvh_kernels.cu:150-202 divide_bbox), which
 //     reproduces the reference's node boxes bit-for-bit without the 2.5 KB OCTNode;
-//   * density and emission grids that do not stay in L2 (>= VPT_RELAID_MIN_BYTES, default 8 MiB) are
+//   * density and emission grids (>= VPT_RELAID_MIN_BYTES; default 0 since round 5, 8 MiB before: what does not stay in L2) are
 //     re-laid once as CORNER QUADS (GRID_QUADS): entry (x, j, k), j in [-1, dy-1], k in [-1, dz-1], is the float4
 //     (c(x,j,k), c(x,j+1,k), c(x,j,k+1), c(x,j+1,k+1)) with clamped j, k -- a trilinear footprint is then two float4
 //     loads from ONE 32-byte run (x, x+1) instead of eight dwords on four scattered rows: 4x the memory (288 GB
