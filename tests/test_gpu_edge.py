@@ -348,45 +348,6 @@ def test_frame_ahead_changes_nothing(pkg, monkeypatch, kind):
             np.testing.assert_array_equal(a[f][k], b[f][k], err_msg="frame %d, %s" % (f, k))
 
 
-@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "instances open lens", "cloud vol_integrator"])
-def test_tails_on_their_own_stream_change_nothing(pkg, monkeypatch, kind):
-    """VPT_ASYNC_TAIL=1 (a study switch: measured without gain, profiles/r05_async_tail.txt): the running means of a chunk run on the context's tail
-    stream, under the next chunk's raygen, out of a second set of per-chunk buffers (csrc/vpt_ctx.h).  Against the default (every kernel on the one
-    stream): every buffer bit-identical -- over several batches back to back
-    WITHOUT a host sync in between (the last tail of one render overlaps the next render's raygen), chunked batches (launch boundaries inside a
-    render: both buffer sets in one call), a one-iteration frame and a view change between batches (the caches are rebuilt behind the tail that reads them)."""
-    import ctypes as C
-    from vpt_amd.abi import Float3
-    sd = _frame_scene(pkg, kind)
-    lib = pkg.load_library()
-    monkeypatch.setenv("VPT_BATCH_ITERS", "3")
-
-    def run():
-        hb = pkg.scene.HipBinding(sd, device=0)
-        cam0 = type(hb.sd.camera).from_buffer_copy(hb.sd.camera)
-        hb.render(7)                      # 3 + 3 + 1: three chunks
-        hb.render(3)
-        hb.render(2)
-        hb.render_frame()
-        hb.render(4)
-        o = hb.sd.camera.origin
-        lib.vpt_camera_update(C.byref(hb.sd.camera), Float3(o.x * 0.9, o.y * 1.05, o.z * 0.95), Float3(0.0, 0.0, 0.0), Float3(0, 1, 0), 40.0,
-                              sd.width / sd.height, float(2.0 * hb.sd.camera.lens_radius))
-        hb.render(5)
-        hb.render(2)
-        hb.sync()
-        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
-        C.memmove(C.byref(hb.sd.camera), C.byref(cam0), C.sizeof(cam0))
-        hb.ctx.close()
-        return out
-    a = run()
-    monkeypatch.setenv("VPT_ASYNC_TAIL", "1")
-    b = run()
-    assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
-    for k in a:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-
-
 @pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "cloud vol_integrator"])
 def test_compact_ray_records_change_nothing(pkg, monkeypatch, kind):
     """Behind a closed lens a queued ray's record is 32 bytes -- {position reached | (t_hit, depth, t_box), packed word} + the Philox block -- instead of 64: the

@@ -26,9 +26,6 @@ namespace {
 int quiesce(vpt_ctx* ctx, hipStream_t stream) {
     HIPCHK(ctx, hipStreamSynchronize(stream));
     if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));
-    if (ctx->tail_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tail_stream));      // (a tail of an earlier render may still read what is freed here)
-    ctx->tail_unjoined = false;
-    ctx->tail_pending[0] = ctx->tail_pending[1] = false;
     return VPT_OK;
 }
 #define CHK(expr) do { const int rc_ = (expr); if (rc_ != VPT_OK) return rc_; } while (0)
@@ -108,7 +105,6 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
     R.sky_view = ctx->d_sky_view;
     std::memcpy(R.cam_tab_pos, key.tables.view_pos, sizeof(float) * 3);
     if (!ctx->cam_tab_built || !same_tables(key, ctx->view_built)) {
-        CHK(vpt_join_tail(ctx, stream));            // (a tail still out on the tail stream reads what is rebuilt here)
         HIPCHK(ctx, launch_sky_cam_table(R, ctx->d_sky_view, ctx->d_cam_tab, view_k, stream));
         ctx->view_built.tables = key.tables;
         ctx->cam_tab_built = true;
@@ -129,7 +125,6 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
         R.dir_tab = ctx->d_dir_tab;                  // (set before the build: its check evaluates real rays through the table path)
         R.dir_tab_err = reinterpret_cast<const uint32_t*>(ctx->d_dir_err);
         if (!ctx->dir_tab_built) {
-            CHK(vpt_join_tail(ctx, stream));
             HIPCHK(ctx, launch_sky_dir_table(R, ctx->d_sky_view, ctx->d_dir_tab, ctx->d_dir_err, view_k, stream));
             ctx->dir_tab_built = true;
         }
@@ -237,7 +232,6 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
         ctx->view_seen_valid = true;
         const bool use_caches = built_for_this || iter_count >= 2u || view_repeats;
         if (use_caches && !built_for_this) {
-            CHK(vpt_join_tail(ctx, stream));
             if (R.cull_tiles != nullptr)       // (the tile map the mask is built from; the host copy lives in the context until the next build)
             {
                 HIPCHK(ctx, hipMemcpyAsync(ctx->d_cull_tiles, ctx->cull_tiles_host.data(), ctx->cull_tiles_host.size(), hipMemcpyHostToDevice, stream));
@@ -297,7 +291,6 @@ int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_spher
                            std::memcmp(ctx->view_built.sky_color, key.sky_color, sizeof(key.sky_color)) == 0;
         if (valid || iter_count >= 2u) {
             if (!valid) {
-                CHK(vpt_join_tail(ctx, stream));
                 if (ctx->sky_dome_k < view_k) {
                     CHK(quiesce(ctx, stream));
                     (void)hipFree(ctx->d_sky_dome); ctx->d_sky_dome = nullptr; ctx->sky_dome_k = -1;
@@ -348,8 +341,6 @@ extern "C" {
 // it is handed), and this entry point for a host that rewrites a device table in place.
 int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
     if (!ctx) return VPT_E_INVALID;
-    // whoever calls this is about to change (or has changed) table contents behind unchanged addresses: no tail of an earlier render may still read them
-    if (ctx->tail_stream) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->tail_stream); }
     ctx->cam_tab_built = false;
     ctx->dir_tab_built = false;
     ctx->sky_patch_built = false;

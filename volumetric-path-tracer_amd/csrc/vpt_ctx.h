@@ -182,27 +182,6 @@ struct vpt_ctx {
     hipStream_t render_stream = nullptr;   // the stream of the previous render
     hipEvent_t comm_event = nullptr;       // recorded behind every vpt_allreduce_accum's last kernel
     hipStream_t comm_stream = nullptr;     // the stream of the previous collective
-    // THE TAIL ON ITS OWN STREAM (round 5; a STUDY switch, VPT_ASYNC_TAIL=1 -- measured without gain, see vpt_create): the running means of a chunk (tail_stream_kernel / tail_resolve_kernel: streaming, latency-bound) overlap
-    // the next chunk's raygen (VALU-bound) instead of queueing in front of it.  Everything the tail reads per chunk exists twice (records, queue,
-    // heads, origins, {alpha, depth}, queue2, jitter table, work counters: the context's d_* fields are set 0, `alt` is set 1; allocated when first used),
-    // chunks alternate between the sets, a set is rewritten only behind the tail that last read it (ev_tailed), tails run in order on `tail_stream` (the
-    // running mean is a recurrence over chunks).  A render on the CONTEXT'S OWN stream (stream argument NULL) leaves its last tail unjoined, so that the
-    // next render's raygen overlaps it too -- completion is observed through vpt_sync, and every entry point that touches the frame buffers or the
-    // per-view caches joins first (vpt_join_tail); a render on a caller's stream joins before it returns (that stream's own completion IS the render's).
-    hipStream_t tail_stream = nullptr;
-    struct ChunkBufs {
-        vpt::Record* records = nullptr; uint32_t* queue = nullptr; float4* heads = nullptr; float4* head_org = nullptr; float2* td = nullptr;
-        uint32_t* queue2 = nullptr; float2* bn_table = nullptr; uint32_t* wc = nullptr;
-    } alt;
-    size_t alt_records_capacity = 0, alt_head_org_capacity = 0, alt_td_capacity = 0, alt_bn_capacity = 0;
-    hipEvent_t ev_traced[2] = {nullptr, nullptr}, ev_tailed[2] = {nullptr, nullptr};
-    bool tail_pending[2] = {false, false}; // set p was last read by a tail that has not been waited for on the tracer's stream
-    unsigned chunk_parity = 0;
-    int last_set = 0;
-    bool tail_unjoined = false;            // the last render's final tail is out on tail_stream and nothing has been ordered behind it yet
-    hipStream_t tail_origin = nullptr;     // ... and that render's stream
-    const uint32_t* last_wc = nullptr;     // work counters of the last chunk launched (vpt_get_stats: queued rays)
-    bool no_async_tail = true;             // the default: every kernel of a render on the one stream, as rounds 1-4; VPT_ASYNC_TAIL=1 clears it
     // FRAME-AHEAD (round 5): the reference's host loop is ONE launch + device sync per iteration (main.cpp:1822-1829), and a one-iteration launch of the
     // persistent tracer lasts as long as its longest paths whatever the machine could do meanwhile (0.19 of the frame's 0.35 ms at 1080p).  A still camera
     // repeats the same call with iteration + 1: from the second such call on, a call traces the rays of the NEXT iterations as well (2, 4, 8, ... up to
@@ -245,7 +224,6 @@ void vpt_set_error(vpt_ctx* ctx, const char* fmt, ...);
 // screen-space bounds (pixels) of the world box [lo, hi] through the closed-lens camera (vpt_host.hip); false: a corner at or behind the camera plane
 extern "C" bool vpt_project_box(const vpt_camera* cam, const double lo[3], const double hi[3], double W, double H, double rect[4]);
 // orders `stream` behind the tail a previous render left out on the tail stream (no-op when there is none)
-extern "C" int vpt_join_tail(vpt_ctx* ctx, hipStream_t stream);
 // the per-view caches for this render: builds what is stale, points R / P at what is in use (vpt_caches.hip)
 int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_sphere* ref_sphere, const vpt_kernel_params* kp, bool compact,
                             unsigned int iter_count, vpt::ResolveParams& R, vpt::TraceParams& P, hipStream_t stream);

@@ -227,17 +227,6 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (const char* e = std::getenv("VPT_RAYGEN_SMALL_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) ctx->raygen_small_iters = (uint32_t)v; }
     ctx->ahead.off = std::getenv("VPT_NO_FRAME_AHEAD") != nullptr;
     if (const char* e = std::getenv("VPT_FRAME_AHEAD_MAX")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->ahead.max_k = (unsigned)v; }
-    // MEASURED AND NOT ADOPTED (profiles/r05_async_tail.txt): the overlap buys nothing -- raygen and the tail slow each other down by what they overlap
-    // (config 2: 5.758 vs 5.759 ms per step) and on configs 4 / 5 the tail spills under the TRACER and costs it waves (97.4 -> 110.7 ms, 140.5 -> 143.9 ms).
-    // Off unless VPT_ASYNC_TAIL=1 (the bit-identity test runs it).
-    ctx->no_async_tail = std::getenv("VPT_ASYNC_TAIL") == nullptr || std::getenv("VPT_NO_ASYNC_TAIL") != nullptr;
-    if (!ctx->no_async_tail) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_traced[i], hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tailed[i], hipEventDisableTiming));
-        }
-    }
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
     HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
@@ -256,17 +245,9 @@ void vpt_destroy(vpt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->render_stream && ctx->render_stream != ctx->stream) (void)hipStreamSynchronize(ctx->render_stream);
     (void)vpt_comm_destroy(ctx);
     (void)hipFree(ctx->ahead.d_bn);
-    (void)hipFree(ctx->alt.records); (void)hipFree(ctx->alt.queue); (void)hipFree(ctx->alt.heads); (void)hipFree(ctx->alt.head_org);
-    (void)hipFree(ctx->alt.td); (void)hipFree(ctx->alt.queue2); (void)hipFree(ctx->alt.bn_table); (void)hipFree(ctx->alt.wc);
-    for (int i = 0; i < 2; ++i) {
-        if (ctx->ev_traced[i]) (void)hipEventDestroy(ctx->ev_traced[i]);
-        if (ctx->ev_tailed[i]) (void)hipEventDestroy(ctx->ev_tailed[i]);
-    }
-    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     (void)hipFree(ctx->d_comm_buf);
     for (auto& t : ctx->textures)
         if (t.live && t.owned) (void)hipFree(t.owned);
@@ -306,26 +287,13 @@ void vpt_destroy(vpt_ctx* ctx) {
     delete ctx;
 }
 
-// orders `stream` behind the tail a previous render left out on the tail stream (vpt_ctx.h)
-int vpt_join_tail(vpt_ctx* ctx, hipStream_t stream) {
-    if (!ctx->tail_unjoined) return VPT_OK;
-    HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[ctx->last_set], 0));
-    ctx->tail_unjoined = false;
-    return VPT_OK;
-}
 // frees and reallocations of what kernels of this context may still read: every stream it has work on, idle
 static int quiesce_all(vpt_ctx* ctx, hipStream_t stream) {
     HIPCHK(ctx, hipStreamSynchronize(stream));
     if (ctx->render_stream && ctx->render_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->render_stream));
-    if (ctx->tail_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tail_stream));
-    ctx->tail_unjoined = false;
-    ctx->tail_pending[0] = ctx->tail_pending[1] = false;
     return VPT_OK;
 }
 
-// The context's own stream: everything a render enqueues runs on it, in order.  (Only under the study switch VPT_ASYNC_TAIL=1 -- off by default, measured
-// without gain -- does a render issued with stream = NULL leave its last tail on a second, internal stream (vpt_ctx.h): its results are then complete
-// after vpt_sync, or once a later vpt_* call that touches them has been ordered behind it.)
 void* vpt_stream(vpt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int vpt_sync(vpt_ctx* ctx) {
@@ -388,7 +356,6 @@ int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
     TexEntry& t = ctx->textures[tex - 1];
     if (t.owned) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->tail_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->tail_stream));      // (a tail still out may read this table)
         HIPCHK(ctx, hipFree(t.owned));
     }
     t.live = false;
@@ -750,7 +717,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
     out->samples = ctx->last_samples;
     {
         uint32_t wc[9] = {0};
-        HIPCHK(ctx, hipMemcpy(wc, ctx->last_wc ? ctx->last_wc : ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(wc, ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
         out->queued_rays = wc[8];
     }
     if (ctx->counting) {
@@ -1049,7 +1016,6 @@ int vpt_allreduce_accum(vpt_ctx* ctx, float* accum, unsigned long long n_floats,
     // earlier collective still uses
     if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
     if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));
-    { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }      // (the last render's tail writes the buffer this reduces)
     if (ctx->comm_buf_floats < (size_t)n_floats + 1u) {
         HIPCHK(ctx, hipStreamSynchronize(stream));
         if (ctx->comm_stream && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
@@ -1137,11 +1103,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // (on the device) behind that one's last kernel
     if (ctx->render_event && ctx->render_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->render_event, 0));
     if (ctx->comm_event && ctx->comm_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->comm_event, 0));   // (the reduce rewrites the caller's accumulation buffer)
-    // A batch runs its tails on the context's tail stream (vpt_ctx.h); the per-frame call and counting renders keep everything on `stream`.  A tail the
-    // previous render left out is joined here unless this render continues the pipeline on the same stream (its own tails queue behind it in order, its
-    // raygen waits per buffer set, a cache rebuild joins in vpt_view_caches_prepare).
-    const bool pipelined = ctx->tail_stream != nullptr && !ctx->counting && !ctx->use_pool && iter_count >= 2u;
-    if (ctx->tail_unjoined && (!pipelined || stream != ctx->tail_origin)) { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }
 
     // ---- frame-ahead (vpt_ctx.h: FrameAhead): does this one-iteration call continue a still sequence, and are its rays traced already?
     const bool fa_ok = !ctx->ahead.off && iter_count == 1u && iter_stride == 1u && !ctx->counting && !ctx->use_pool && ctx->batch_iters == 0;
@@ -1459,12 +1420,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         return VPT_OK;
     };
 
-    // ---- frame-ahead (vpt_ctx.h: FrameAhead): a one-iteration call of a still sequence.  Buffer set 0, everything on `stream`.
+    // ---- frame-ahead (vpt_ctx.h: FrameAhead): a one-iteration call of a still sequence.
     if (fa_ok && (fa_hit || fa_n > 1u)) {
-        if (ctx->tail_pending[0]) {                          // (a batch's tail may have read set 0 last)
-            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[0], 0));
-            ctx->tail_pending[0] = false;
-        }
         const uint32_t live = (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull);
         float* const bn_caller = reinterpret_cast<float*>(kp->blue_noise_buffer);
         int rc;
@@ -1475,7 +1432,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             if (!ctx->ahead.d_bn) HIPCHK(ctx, hipMalloc(&ctx->ahead.d_bn, 65536 * 3 * sizeof(float)));
             HIPCHK(ctx, hipMemcpyAsync(ctx->ahead.d_bn, bn_caller, 65536 * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
             HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
-            ctx->last_wc = P.work_counter;
             HIPCHK(ctx, launch_blue_noise(ctx->ahead.d_bn, ctx->d_bn_table, n, 1u, live, stream));
             P.iter_begin = it0; P.iter_count = n;
             R.iter_begin = it0; R.iter_count = n;
@@ -1528,60 +1484,10 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         return VPT_OK;
     }
 
-    // the two sets of per-chunk buffers (vpt_ctx.h): set 0 = the context's d_* fields, as P and R hold them now; set 1 = `alt`
-    vpt_ctx::ChunkBufs set0;
-    set0.records = ctx->d_records; set0.queue = ctx->d_queue; set0.heads = ctx->d_heads; set0.head_org = ctx->d_head_org; set0.td = ctx->d_td;
-    set0.queue2 = ctx->d_queue2; set0.bn_table = ctx->d_bn_table; set0.wc = ctx->d_work_counter;
-    auto point_at = [&](const vpt_ctx::ChunkBufs& B) {
-        P.records = B.records; R.records = B.records;
-        if (P.heads) { P.heads = B.heads; R.heads = B.heads; }
-        if (P.head_org) { P.head_org = B.head_org; R.head_org = B.head_org; }
-        P.queue = B.queue; P.queue_tail = B.wc + 8; P.queue_count = B.wc + 8; P.work_counter = B.wc;
-        P.blue_noise = B.bn_table;
-        if (R.blue_noise) R.blue_noise = B.bn_table;
-        if (R.lean) {
-            R.td = B.td; R.queue2 = B.queue2; R.queue2_count = B.wc + 4;
-            P.resolve.heads = B.heads; P.resolve.td = B.td; P.resolve.queue2 = B.queue2; P.resolve.queue2_tail = B.wc + 4;
-        }
-    };
-    int last_p = 0;
     for (unsigned int done = 0; done < iter_count; done += (unsigned int)chunk) {
         const unsigned int n = (unsigned int)std::min<size_t>(chunk, iter_count - done);
         const unsigned int it0 = kp->iteration + done * iter_stride;
         const bool last = done + n >= iter_count;
-        const int p = pipelined ? (int)(ctx->chunk_parity++ & 1u) : 0;
-        if (p == 1) {
-            // set 1 mirrors set 0's capacities; (re)allocated with every stream of the context idle
-            const bool lens_org = P.head_org != nullptr;
-            if (ctx->alt_records_capacity < ctx->records_capacity || ctx->alt_bn_capacity < ctx->bn_capacity || (lens_org && ctx->alt_head_org_capacity < ctx->head_org_capacity) ||
-                (R.lean && ctx->alt_td_capacity < ctx->td_capacity)) {
-                { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
-                vpt_ctx::ChunkBufs& A = ctx->alt;
-                (void)hipFree(A.records); (void)hipFree(A.queue); (void)hipFree(A.heads); (void)hipFree(A.head_org); (void)hipFree(A.td); (void)hipFree(A.queue2); (void)hipFree(A.bn_table);
-                A.records = nullptr; A.queue = nullptr; A.heads = nullptr; A.head_org = nullptr; A.td = nullptr; A.queue2 = nullptr; A.bn_table = nullptr;
-                ctx->alt_records_capacity = ctx->alt_bn_capacity = ctx->alt_head_org_capacity = ctx->alt_td_capacity = 0;
-                hipError_t e = hipMalloc(&A.records, ctx->records_capacity * sizeof(Record));
-                if (e == hipSuccess) e = hipMalloc(&A.queue, ctx->records_capacity * sizeof(uint32_t));
-                if (e == hipSuccess) e = hipMalloc(&A.heads, ctx->records_capacity * sizeof(float4));
-                if (e == hipSuccess) e = hipMalloc(&A.bn_table, ctx->bn_capacity * 65536 * sizeof(float2));
-                if (e == hipSuccess && ctx->head_org_capacity) e = hipMalloc(&A.head_org, ctx->head_org_capacity * sizeof(float4));
-                if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.td, ctx->td_capacity * sizeof(float2));
-                if (e == hipSuccess && ctx->td_capacity) e = hipMalloc(&A.queue2, ctx->td_capacity * sizeof(uint32_t));
-                if (e == hipSuccess && !A.wc) e = hipMalloc(&A.wc, 16 * sizeof(uint32_t));
-                if (e != hipSuccess) {
-                    set_error(ctx, "vpt_render: hipMalloc of the second set of per-chunk buffers failed: %s (VPT_NO_ASYNC_TAIL=1 renders with one set)", hipGetErrorString(e));
-                    return VPT_E_NOMEM;
-                }
-                ctx->alt_records_capacity = ctx->records_capacity; ctx->alt_bn_capacity = ctx->bn_capacity;
-                ctx->alt_head_org_capacity = ctx->head_org_capacity; ctx->alt_td_capacity = ctx->td_capacity;
-            }
-        }
-        point_at(p ? ctx->alt : set0);
-        // this set is rewritten from here on: behind the tail that last read it
-        if (ctx->tail_pending[p]) {
-            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[p], 0));
-            ctx->tail_pending[p] = false;
-        }
         P.iter_begin = it0; P.iter_count = n;
         R.iter_begin = it0; R.iter_count = n;
         for (unsigned int k = 0; k < 64u; ++k) {
@@ -1591,7 +1497,6 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
         HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
-        ctx->last_wc = P.work_counter;
         HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), const_cast<float2*>(P.blue_noise), n, iter_stride,
                                       (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull), stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
@@ -1611,41 +1516,20 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));
         { const int rt_ = launch_tracer(total, blocks); if (rt_ != VPT_OK) return rt_; }
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[2]], stream));
-        // sky_fix_kernel (what the dome did not serve: reads path records and the queue the tracer filled) stays on the tracer's stream ...
+        // sky_fix_kernel: what the dome did not serve (reads path records and the queue the tracer filled) ...
         if (R.lean) HIPCHK(ctx, launch_sky_fix(R, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[3]], stream));
-        // ... the running means (streaming tail / environment tail + resolve) go to the tail stream: under the next chunk's raygen
-        hipStream_t ts = stream;
-        if (pipelined) {
-            ts = ctx->tail_stream;
-            HIPCHK(ctx, hipEventRecord(ctx->ev_traced[p], stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ts, ctx->ev_traced[p], 0));
-        }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[4]], ts));
-        if (R.lean) HIPCHK(ctx, launch_tail_stream(R, ts));
-        else HIPCHK(ctx, launch_tail_resolve(R, ts));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[5]], ts));
-        if (pipelined) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_tailed[p], ts));
-            ctx->tail_pending[p] = true;
-            last_p = p;
-        }
+        // ... then the running means (streaming tail / environment tail + resolve).  (On a second stream, under the next chunk's raygen: measured without gain,
+        // profiles/r05_async_tail.txt; the study sources are tools/variants/r05_async_tail.patch)
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[4]], stream));
+        if (R.lean) HIPCHK(ctx, launch_tail_stream(R, stream));
+        else HIPCHK(ctx, launch_tail_resolve(R, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[5]], stream));
         ctx->spans.push_back({ev[0], ev[1], 0});
         ctx->spans.push_back({ev[1], ev[2], 1});
         ctx->spans.push_back({ev[2], ev[3], 2});
         ctx->spans.push_back({ev[4], ev[5], 2});
         ctx->last_samples += total;
-    }
-    if (pipelined) {
-        ctx->last_set = last_p;
-        if (stream == ctx->stream) {
-            // the context's own stream: the last tail stays out, the next render's raygen overlaps it (vpt_sync, or whatever touches the results, joins)
-            ctx->tail_unjoined = true;
-            ctx->tail_origin = stream;
-        } else {
-            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_tailed[last_p], 0));      // a caller's stream: its completion is the render's
-            ctx->tail_unjoined = false;
-        }
     }
     if (!ctx->render_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->render_event, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(ctx->render_event, stream));
@@ -1664,7 +1548,6 @@ int vpt_resolve_display(vpt_ctx* ctx, const vpt_kernel_params* kp, void* stream_
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const unsigned long long n = (unsigned long long)kp->resolution.x * kp->resolution.y;
     if (n == 0 || n > 0xffffffffull) return VPT_E_INVALID;
-    { const int rcj = vpt_join_tail(ctx, stream); if (rcj != VPT_OK) return rcj; }
     HIPCHK(ctx, launch_display(reinterpret_cast<const float*>(kp->accum_buffer), kp->display_buffer, reinterpret_cast<float*>(kp->raw_buffer), (uint32_t)n,
                                kp->exposure_scale, stream));
     return VPT_OK;
