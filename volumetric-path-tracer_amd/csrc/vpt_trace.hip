@@ -77,24 +77,31 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
     const uint32_t tile = blockIdx.x / P.iter_count;
     const uint32_t kiter = blockIdx.x - tile * P.iter_count;
     const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int x = (int)(tile_x * 64u + threadIdx.x);
     const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
     const int lane = __lane_id();
     const bool rendered = iteration < P.max_interactions && P.render;
     uint32_t n_final = 0;
+    // A WAVE'S FOOTPRINT IS AN 8 x 8 PIXEL SQUARE (round 5; rounds 1-4: 64 pixels of one row), aligned to the 8 x 8 tiles the never-traced mask is decided on
+    // (sky_patch_kernel: cull_tiles[(y >> 3), (x >> 3)]): a wave is then live or skipped as a whole instead of running the whole body for the live eighths of its
+    // strip, the empty-node pushes and the traced-only Philox blocks see rays that are neighbours in both directions, and the tracer's refills (consecutive queue
+    // entries) take their rays from one square.  Per pass the block's four waves take the squares 4 pass .. 4 pass + 3 of the tile (row-major, 8 per row); every
+    // store of a wave still covers whole 128-byte lines (8 pixels x 16 bytes per row of the square).  The sample is keyed by (pixel, iteration): results do not move.
+    const int sq_x = (int)(tile_x * 64u) + (lane & 7), sq_y = (int)(tile_y * VPT_RAYGEN_ROWS) + (lane >> 3);
     // the never-traced flags of this thread's pixels (one per pass), requested together up front: one memory latency per thread
     // instead of a dependent load at the head of every pass
     uint32_t never_bits = 0;
-    if (P.never_traced && x < (int)P.width) {
+    if (P.never_traced) {
 #pragma unroll
         for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
-            const int yy = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
-            const uint32_t f = yy < (int)P.height ? (uint32_t)P.never_traced[(uint32_t)yy * P.width + (uint32_t)x] : 0u;
+            const int sq = pass * 4 + (int)threadIdx.y;
+            const int xx = sq_x + (sq & 7) * 8, yy = sq_y + (sq >> 3) * 8;
+            const uint32_t f = (xx < (int)P.width && yy < (int)P.height) ? (uint32_t)P.never_traced[(uint32_t)yy * P.width + (uint32_t)xx] : 0u;
             never_bits |= (f & 1u) << pass;
         }
     }
     for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
-        const int y = (int)(tile_y * VPT_RAYGEN_ROWS) + pass * 4 + (int)threadIdx.y;
+        const int sq = pass * 4 + (int)threadIdx.y;
+        const int x = sq_x + (sq & 7) * 8, y = sq_y + (sq >> 3) * 8;
         bool enqueue = false;
         uint32_t s = 0;
         bool live = x < (int)P.width && y < (int)P.height;
