@@ -8,17 +8,24 @@
 
 A "step" = one render of the named workload (default: BASELINE config 2 = dragon.vdb, 1920x1080, 64 spp, procedural
 sun + sky): `spp` iterations of `volume_rt_kernel` per rank (raygen + trace + tail/resolve kernels, inputs resident in
-HBM).  The JSON line of rank 0 carries, next to the headline:
-  roofline       of the headline's dominant kernel (the tracer) -- three labelled fractions, see `roofline_block`
-  other_configs  BASELINE configs 3, 4, 5 on their synthetic stand-ins at spec size, 2 steps each, N = 1 only, each with
-                 its own parity evidence at that size (`parity`: oracle on a pixel lattice across two record chunks / layout A-B)
-  per_frame      the literal drop-in call: one vpt_render (1 iteration) + device sync per frame, as main.cpp:1822-1829
-  cpu_baseline   the reference's own kernel built for the host (oracle/_ref) or the oracle, on a bounded sample of the same
-                 frame -- and the HIP image of the SAME iterations compared with it (`parity_rel_l2`)
+HBM).  Rank 0 prints TWO things (round 6: the round-5 line carried everything and grew past what the driver parses):
+  BENCH_DETAIL {...}   one earlier stdout line (also gpurun_out/bench_detail.json): every block this run measured --
+      roofline       of the headline's dominant kernel (the tracer), all labelled fractions, see `roofline_block`
+      other_configs  BASELINE configs 3, 4, 5 on their synthetic stand-ins at spec size, 2 steps each, each with
+                     its own parity evidence at that size (`parity`: oracle on a pixel lattice across two record chunks / layout A-B);
+                     with N > 1: configs 4 and 5 (the ones BASELINE assigns to 8 GPUs) striped over the ranks, one all-reduce each
+      per_frame      the literal drop-in call: one vpt_render (1 iteration) + device sync per frame, as main.cpp:1822-1829
+      cpu_baseline   the reference's own kernel built for the host (oracle/_ref) or the oracle, on a bounded sample of the same
+                     frame -- and the HIP image of the SAME iterations compared with it (`parity_rel_l2`)
+      c1_cpu_single_thread, weak / strong, the sky caches' gates
+  {"metric": ...}      the LAST stdout line, < 6000 bytes (`headline_line`): the contract's keys, a trimmed `roofline`,
+                       `cpu_baseline`, and per other config its rate, fraction and parity figure
 With N > 1 every rank renders its own iteration stripe and the accumulation buffers are combined with ONE RCCL
 all-reduce below the C ABI (vpt_allreduce_accum) inside the timed region, with no host synchronisation inside a step.
-  --scaling weak   (default) every rank renders `spp` iterations: N*spp samples per pixel per step
-  --scaling strong the job's `spp` iterations are split over the ranks (spp/N each): fixed total work
+  --scaling strong (default) the job's `spp` iterations are split over the ranks (spp/N each): fixed total work --
+                   north_star's own sentence (one frame's sample batches over the GPUs, reduced once)
+  --scaling weak   every rank renders `spp` iterations: N*spp samples per pixel per step
+Both rates travel in the line (`weak`, `strong`) whichever is asked for; at N = 1 they are the same job.
 """
 import argparse
 import json
@@ -131,6 +138,8 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
         # the tracer's own rate: rays it walks per second (the headline counts every pixel-sample, most of which start no walk on config 2)
         "tracer_grays_per_s": round(traced * samples_per_step / trace_s / 1e9, 3) if trace_s > 0 else None,
         "resolved_samples": bool(lean),
+        # one launch of the dominant kernel traces the chunk rule's iterations (vpt_render_batch: <= 64 iterations, <= 16 GiB of records)
+        "samples_per_launch": W * H * max(1, min(64, spp, (16 << 30) // (W * H * 64))),
         "note": "kernel times: HIP events on the context's stream around every launch of the LAST timed step",
     }
     if void:
@@ -150,6 +159,8 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
             launches = -(-spp // ipl)
             r["traffic"] = round(per_sample * samples_per_step / launches / 1e9, 4)
             r["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s at commit %s)" % (tj.get("source", "?"), tj.get("commit", "?"))
+            r["traffic_source"] = "profiles/" + tj.get("source", "?")
+            r["traffic_commit"] = tj.get("commit")
             r["launches_per_step"] = launches
             if trace_s > 0:
                 r["hbm_measured_frac"] = round(per_sample * samples_per_step / trace_s / 1e9 / HBM_PEAK_GBS, 5)
@@ -169,6 +180,90 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
     return r
 
 
+def _kernel_commit():
+    """the commit that last changed what the timed library is built from (csrc/, include/, build.py); None outside a git checkout (the GPU box's snapshot has no .git:
+    there the stamp written by tools/stamp_commit.py travels in profiles/kernel_commit.txt)"""
+    import subprocess
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "volumetric-path-tracer_amd/csrc", "include", "volumetric-path-tracer_amd/build.py"],
+                           capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_commit.txt")) as f:
+            return f.read().split()[0]
+    except Exception:
+        return None
+
+
+def headline_line(d):
+    """The ONE final JSON line (round 6): the contract's keys, a trimmed `roofline`, `cpu_baseline`, and per other config only its rate, fraction and parity.
+    Everything else this run measured is the DETAIL record (`emit`): an earlier stdout line and gpurun_out/bench_detail.json.  The round-5 line carried all
+    of it and grew to 22 KB, which the driver no longer parsed."""
+    rf = d["roofline"]
+    r = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_void", "traffic")}
+    r["definition"] = "(32 N_d + 128 N_c + 32 N_e + 88) B per pixel-sample (BASELINE.md 3, reference-defined look-up counts) x samples of one launch / whole-step time / 8 TB/s"
+    r["bytes_per_sample"] = rf["bytes_per_sample"]["survey_8d_reference_counts"]
+    r["samples_per_launch"] = rf.get("samples_per_launch")
+    for k in ("frac_kernel_issued_fetches", "hbm_measured_frac", "tracer_grays_per_s", "cold_view_msamples_per_s", "launches_per_step"):
+        r[k] = rf.get(k)
+    r["kernel_ms"] = {"raygen": rf["raygen_ms_per_step"], "trace": rf["trace_ms_per_step"], "tail": rf["tail_resolve_ms_per_step"], "timer": "HIP events on the context's stream, last timed step"}
+    valu = rf.get("valu") or {}
+    r["useful_lane_issue"] = valu.get("useful_lane_issue")
+    r["source"] = valu.get("source") or rf.get("traffic_source")
+    r["commit"] = valu.get("commit") or rf.get("traffic_commit")
+    if rf.get("frac_void"):
+        r["frac_promoted"] = rf.get("frac_promoted")
+    c = d["config"]
+    out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: c.get(k) for k in ("workload", "width", "height", "spp_per_gpu", "spp_job", "parallelism", "collective", "frames_in_flight")}
+    out["roofline"] = r
+    if d.get("cpu_baseline"):
+        out["cpu_baseline"] = d["cpu_baseline"]
+    for name in ("weak", "strong"):
+        if d["n_gpus"] > 1 and name in d:
+            out[name] = {k: d[name][k] for k in ("value", "ms_per_step", "spp_per_gpu", "spp_job", "frames_in_flight")}
+    if d.get("per_frame"):
+        pf = d["per_frame"]
+        out["per_frame"] = {"value": pf["value"], "ms_per_frame": pf["ms_per_frame"], "frame_by_frame_value": (pf.get("frame_by_frame") or {}).get("value")}
+    others = []
+    for o in d.get("other_configs") or []:
+        orf, par = o["roofline"], o.get("parity") or {}
+        e = {"workload": o["config"]["workload"].split(" (BASELINE")[0][:96], "config": o.get("name"), "value": o["value"], "ms_per_step": o["ms_per_step"], "n_gpus": o.get("n_gpus", 1),
+             "spp_per_gpu": o["config"]["spp_per_gpu"], "frac": orf.get("frac"), "traffic": orf.get("traffic"), "trace_ms": orf.get("trace_ms_per_step"),
+             "parity_rel_l2": par.get("rel_l2"), "parity_kind": par.get("kind")}
+        if orf.get("frac_void"):
+            e["frac_promoted"] = orf["frac_promoted"]["value"]
+        others.append(e)
+    if others:
+        out["other_configs"] = others
+    c1 = d.get("c1_cpu_single_thread")
+    if c1:
+        out["c1_cpu_single_thread"] = {"cpu_msamples_per_s": c1["cpu"]["value"], "hip_msamples_per_s": c1["hip"]["value"], "parity_rel_l2": c1["parity_rel_l2"], "kind": c1["cpu"]["kind"]}
+    out["kernel_commit"] = d.get("kernel_commit")
+    out["detail"] = "stdout line 'BENCH_DETAIL {...}' before this one; gpurun_out/bench_detail.json"
+    return out
+
+
+def emit(d):
+    """rank 0: the detail record first (a stdout line that does not start with '{', and a file), then the headline as the LAST stdout line"""
+    d["kernel_commit"] = _kernel_commit()
+    detail = json.dumps(d)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    print("BENCH_DETAIL " + detail, flush=True)
+    line = json.dumps(headline_line(d))
+    if len(line) > 6000:                      # the driver's parser stopped at 22 KB; keep far below
+        raise SystemExit("bench.py: the headline line grew to %d bytes (limit 6000)" % len(line))
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +273,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=0, help="iterations per step (weak: per rank; strong: of the whole job); default: the config's own")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong (default, north_star's sentence: ONE job's iterations split over the ranks and reduced once) or weak (every rank renders the job's spp)")
     ap.add_argument("--grid-scale", type=float, default=1.0, help="c4: linear scale of the 1024x704x1216 cloud grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -242,16 +338,17 @@ def main():
     cfg = args.config
     job_spp = args.spp or DEFAULT_SPP.get(cfg, 64)
 
-    def rank_spp(scaling):
+    def rank_spp(scaling, job):
         # strong: the job's iterations striped over the ranks: rank r renders iterations r, r + G, ... (one more on the first spp % G ranks);
         # the all-reduce weights every rank's mean with its own count.  weak: every rank renders the job's spp
-        return len(range(rank, job_spp, world)) if (scaling == "strong" and world > 1) else job_spp
+        return len(range(rank, job, world)) if (scaling == "strong" and world > 1) else job
 
-    def measure(cfg, spp, steps, warmup, W, H, with_extras, scaling=None):
-        """one workload: returns the dict of the JSON line (rank 0) or None"""
+    def measure(cfg, job, steps, warmup, W, H, with_extras, scaling=None):
+        """one workload (`job` = the config's iterations per step as BASELINE names them): returns the dict of the JSON line (rank 0) or None"""
         scaling = scaling or args.scaling
-        job_iters = spp * world if (world == 1 or scaling == "weak") else job_spp       # iterations of the whole job per step
-        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, spp if world == 1 or scaling == "weak" else job_spp, args.grid_scale, dev, local_rank)
+        spp = rank_spp(scaling, job)                                                    # iterations THIS rank renders per step
+        job_iters = job * world if (world > 1 and scaling == "weak") else job           # iterations of the whole job per step
+        sd, workload, data, W, H = make_scene(pkg, cfg, W, H, job, args.grid_scale, dev, local_rank)
         # scene set-up as a rank pays it at start (outside the timed region): texture uploads / adoption, the re-lay of big grids
         # into corner quads (config 4: 3.5 GB -> 14 GB on the GPU), the host octree and its candidate lists, buffer allocation
         torch.cuda.synchronize(dev)
@@ -605,13 +702,13 @@ def main():
                 "parity_depth_pixels_differing": int((dgot != dref).sum()),
                 "parity_note": "HIP accum / depth buffers vs this CPU render after the same %d iterations at full size (tolerance 1e-3 rel. L2)" % args.cpu_iters}
 
-    out = measure(cfg, rank_spp(args.scaling), args.steps, args.warmup, args.width, args.height, True)
+    out = measure(cfg, job_spp, args.steps, args.warmup, args.width, args.height, True)
     # BOTH scalings travel in the one line (round 5): `value` / `scaling` are the mode asked for (weak by default: what the driver's N = 1, 2, 4, 8
     # runs compare), `weak` and `strong` hold the job's rate either way -- strong is north_star's own sentence: ONE frame's sample batches split over
     # the GPUs and reduced once.  At N = 1 the two are the same job.
     other = "strong" if args.scaling == "weak" else "weak"
     if world > 1:
-        o2 = measure(cfg, rank_spp(other), args.steps, args.warmup, args.width, args.height, False, scaling=other)
+        o2 = measure(cfg, job_spp, args.steps, args.warmup, args.width, args.height, False, scaling=other)
     else:
         o2 = out
     if rank == 0 and out is not None and o2 is not None:
@@ -619,19 +716,22 @@ def main():
             out[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
                          "spp_per_gpu": o["config"]["spp_per_gpu"], "spp_job": o["config"]["spp_job"], "n_gpus": world,
                          "frames_in_flight": o["config"]["frames_in_flight"]}
-    if not multi and not args.no_other_configs and cfg == "c2":
+    # The other BASELINE configs at spec size.  N = 1: configs 3, 4, 5 on the one GPU.  N > 1 (round 6): the two configs BASELINE assigns to the 8-GPU node --
+    # config 4 (128 spp: 16 per rank at N = 8) and config 5 (512 spp: 64 per rank) -- iteration-striped over the ranks like the headline, each step ending in its
+    # ONE all-reduce (24.9 MB at 1080p, 99.5 MB at 4K) inside the timed region.  A launcher started by hand with VPT_BENCH_FORCE_DIST runs the headline only.
+    if not args.no_other_configs and cfg == "c2" and args.spp == 0 and (not multi or world > 1):
         others = []
-        for oc in ("c3", "c4", "c5"):
-            o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False)
+        for oc in (("c3", "c4", "c5") if world == 1 else ("c4", "c5")):
+            o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False, scaling="strong")
             if o:
-                others.append({"config": o["config"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
-                               "warmup": o["warmup"], "data": o["data"], "roofline": o["roofline"], "parity": o.get("parity")})
+                others.append({"name": oc, "config": o["config"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                               "warmup": o["warmup"], "n_gpus": world, "scaling": o["scaling"], "data": o["data"], "roofline": o["roofline"], "parity": o.get("parity")})
         if out is not None:
             out["other_configs"] = others
     if not multi and rank == 0 and out is not None and cfg == "c2" and not args.no_c1 and not args.no_cpu_baseline:
         out["c1_cpu_single_thread"] = c1_single_thread()
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
