@@ -131,6 +131,7 @@ def roofline_block(cfg, W, H, spp, cs, st, samples_per_step, step_s, integrator,
         "bytes_per_sample": {"survey_8d_reference_counts": round(b_ref, 2), "lookup_bytes": round(b_lookup, 2), "record_stream_bytes": round(b_records, 2),
                              "kernel_must_move": round(b_kernel, 2), "step_issued_fetches": round(b_step, 2)},
         "per_sample": {"density_fetches": round(fd, 4), "color_fetches": round(fc, 4), "emission_fetches": round(fe, 4),
+                       "density_fetches_answered_by_zero_mask": round(cs.density_zero_skips / n, 4),
                        "density_lookups_reference": round(nd, 4), "color_lookups_reference": round(nc, 4), "emission_lookups_reference": round(ne, 4),
                        "tracking_steps": round(cs.tracking_steps / n, 4), "skip_steps": round(cs.skip_steps / n, 4), "rays_traced_fraction": round(traced, 4)},
         "raygen_ms_per_step": round(st.raygen_ms, 3), "trace_ms_per_step": round(st.trace_ms, 3),
@@ -247,13 +248,13 @@ def headline_line(d):
     return out
 
 
-def emit(d):
+def emit(d, detail_file):
     """rank 0: the detail record first (a stdout line that does not start with '{', and a file), then the headline as the LAST stdout line"""
     d["kernel_commit"] = _kernel_commit()
     detail = json.dumps(d)
     try:
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+        os.makedirs(os.path.dirname(os.path.abspath(detail_file)), exist_ok=True)
+        with open(detail_file, "w") as f:
             f.write(detail + "\n")
     except OSError:
         pass
@@ -286,6 +287,7 @@ def main():
     ap.add_argument("--no-c1", action="store_true", help="skip the config-1 block (reference kernel on ONE host thread, 512x512x16spp)")
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--frames", type=int, default=64, help="frames of the per-frame (vpt_render + sync) measurement")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the detail record is written besides stdout")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -719,7 +721,7 @@ def main():
     # The other BASELINE configs at spec size.  N = 1: configs 3, 4, 5 on the one GPU.  N > 1 (round 6): the two configs BASELINE assigns to the 8-GPU node --
     # config 4 (128 spp: 16 per rank at N = 8) and config 5 (512 spp: 64 per rank) -- iteration-striped over the ranks like the headline, each step ending in its
     # ONE all-reduce (24.9 MB at 1080p, 99.5 MB at 4K) inside the timed region.  A launcher started by hand with VPT_BENCH_FORCE_DIST runs the headline only.
-    if not args.no_other_configs and cfg == "c2" and args.spp == 0 and (not multi or world > 1):
+    if not args.no_other_configs and cfg == "c2" and (not multi or world > 1):
         others = []
         for oc in (("c3", "c4", "c5") if world == 1 else ("c4", "c5")):
             o = measure(oc, DEFAULT_SPP[oc], 2, 1, args.width, args.height, False, scaling="strong")
@@ -731,7 +733,7 @@ def main():
     if not multi and rank == 0 and out is not None and cfg == "c2" and not args.no_c1 and not args.no_cpu_baseline:
         out["c1_cpu_single_thread"] = c1_single_thread()
     if rank == 0 and out is not None:
-        emit(out)
+        emit(out, args.detail_file)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -324,6 +324,8 @@ typedef struct vpt_render_stats {
     unsigned long long density_fetches;
     unsigned long long color_fetches;
     unsigned long long emission_fetches;
+    /* of density_fetches: those a zero-footprint mask answered (all eight texels exactly 0: the value is +0 without the loads) */
+    unsigned long long density_zero_skips;
 } vpt_render_stats;
 /* enable/disable look-up counting (off by default: counting costs atomics) */
 int  vpt_set_counting(vpt_ctx *ctx, int enable);

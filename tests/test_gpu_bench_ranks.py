@@ -27,7 +27,7 @@ def _lines(stdout):
 def test_two_ranks_on_one_gpu():
     env = dict(os.environ, VPT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--width", "320", "--height", "180", "--spp", "4", "--no-cpu-baseline", "--no-other-configs"]
     r = subprocess.run(cmd + ["--scaling", "weak"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -54,7 +54,7 @@ def test_eight_ranks_strong_scaling_dry_run():
     runs on an 8-GPU node (there with one RCCL all-reduce under the C ABI)."""
     env = dict(os.environ, VPT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--gpus", "8", "--steps", "1", "--warmup", "1",
            "--width", "256", "--height", "144", "--spp", "12", "--no-cpu-baseline", "--grid-scale", "0.0625"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -78,7 +78,7 @@ def test_plain_command_launches_its_own_ranks():
     torch.distributed.run, rank 0 prints ONE JSON line with n_gpus = 2"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["VPT_BENCH_BACKEND"] = "gloo"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--width", "320", "--height", "180", "--spp", "4", "--no-other-configs"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -110,7 +110,7 @@ def test_striped_ranks_equal_single_rank(pkg):
 def test_single_rank_bench_line_contract():
     """the N = 1 output: the LAST stdout line is the headline (every key of the contract, a trimmed roofline, the CPU baseline), under 6000 bytes;
     everything else travels in the BENCH_DETAIL line before it"""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
            "--spp", "4", "--cpu-iters", "2", "--frames", "4", "--grid-scale", "0.125"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -183,7 +183,7 @@ def test_frames_in_flight_through_rccl_single_rank():
     rank (VPT_BENCH_FORCE_DIST=1: process group + communicators under the C ABI + stream-ordered reduces), which is what a 1-GPU box can run of it"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(VPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "7", "--warmup", "2", "--width", "320", "--height", "180", "--spp", "4",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--steps", "7", "--warmup", "2", "--width", "320", "--height", "180", "--spp", "4",
            "--scaling", "strong", "--frames-in-flight", "3", "--no-cpu-baseline", "--no-other-configs", "--no-per-frame"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -241,7 +241,7 @@ def test_bench_rccl_step_with_one_rank():
     vpt_allreduce_accum enqueued on the context's stream without host fences, barrier + max-over-ranks timing.  What a second GPU
     would add is the traffic inside ncclAllReduce."""
     env = dict(os.environ, VPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "4"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", os.devnull, "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "180", "--spp", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d, det = _lines(r.stdout)

@@ -140,7 +140,8 @@ class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_ulonglong), ("density_lookups", C.c_ulonglong), ("color_lookups", C.c_ulonglong),
                 ("emission_lookups", C.c_ulonglong), ("tracking_steps", C.c_ulonglong), ("skip_steps", C.c_ulonglong), ("queued_rays", C.c_ulonglong),
                 ("trace_ms", C.c_float), ("raygen_ms", C.c_float), ("tail_ms", C.c_float),
-                ("density_fetches", C.c_ulonglong), ("color_fetches", C.c_ulonglong), ("emission_fetches", C.c_ulonglong)]
+                ("density_fetches", C.c_ulonglong), ("color_fetches", C.c_ulonglong), ("emission_fetches", C.c_ulonglong),
+                ("density_zero_skips", C.c_ulonglong)]
 
 
 class AtmosphereModelOptions(C.Structure):

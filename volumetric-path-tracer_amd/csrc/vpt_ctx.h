@@ -76,6 +76,10 @@ struct vpt_ctx {
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
     uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
+    bool no_zero_mask = false;        // VPT_NO_ZERO_MASK: no zero-footprint mask (DVolume::zmask) -- the A/B switch of its exactness test
+    size_t zmask_min_bytes = (size_t)32 << 20;   // VPT_ZERO_MASK_MIN_BYTES: density grids at or above get a mask (below they stay cache resident: the mask's dependent load costs more than it saves)
+    int zmask_shift = 0;              // VPT_ZERO_MASK_SHIFT: force the block edge (2..6: 4..64 origins; study switch)
+    int raygen_footprint = -1;        // VPT_RAYGEN_FOOTPRINT=rows|squares (study switch); -1: squares where the view has a never-traced mask, rows where it has none (round 6)
     uint32_t raygen_small_iters = 17; // VPT_RAYGEN_SMALL_ITERS: launches of fewer iterations run raygen over 16-row tiles (four times the blocks: 8 iterations 1.102 -> 1.045 ms, 16: 1.669 -> 1.611, 64: no difference; profiles/r05_batch_curve.txt)
     // pool tracer (csrc/variants/vpt_trace_pool.hip, study builds with -DVPT_WITH_POOL only): direct_integrator with the rays in an LDS pool per CU
     bool use_pool = false;         // VPT_TRACER=pool in such a build: measured slower than the lane-bound tracer, kept as the evidence and for A/B runs

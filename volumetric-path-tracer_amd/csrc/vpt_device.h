@@ -84,6 +84,12 @@ struct DVolume {
     // (float) of the three texture extents, host-converted: the compiler keeps a launch-uniform conversion in a VECTOR register for the whole
     // kernel (gfx950 has no scalar float unit); as descriptor fields they are scalar operands (profiles/r04_four_waves.txt (i))
     float dimf[3], edimf[3], cdimf[3];
+    // ZERO-FOOTPRINT MASK of the density grid (round 6; null: none).  A trilinear footprint is the 2x2x2 texels at origin (i, j, k) = floor(u * dim - 0.5), each in
+    // [-1, dim - 1], clamp addressing applied.  Bit (bx, by, bz) -- b = (origin + 1) >> zshift per axis -- is set when EVERY footprint whose origin lies in the block
+    // consists of eight texels that are exactly 0: such a look-up returns 0 + (0 - 0) * a = +0 whatever the weights (bit-exact), so the two quad loads (128-byte
+    // lines that are almost never reused: profiles/r05_c4_pmc.txt, 4.3x the must-move bytes) are skipped.  Word (bx >> 5, by, bz), x fastest; built next to the re-lay.
+    const uint32_t* zmask;
+    int zshift, znwx, znby;
 };
 
 struct DTexture {          // CUDA sampler state restated
@@ -147,7 +153,7 @@ struct Counters {
     // trilinear fetches actually issued (the point lies inside the instance's look-up domain and the value is used):
     // [0] density, [1] colour (float4 texels), [2] emission -- what the tracer really moves, as opposed to the
     // reference-defined look-up counts above (one per instance of the leaf and step, fetched or not)
-    unsigned long long fetches[4];
+    unsigned long long fetches[4];     // ([3]: density fetches the zero-footprint mask answered instead -- counted in [0] too)
     // vol_integrator's runs of empty sample() calls (vpt_walk.h: use_retries; counting builds only; wave-level sums of LANE-passes through
     // the tracking step proper): [0] lane-passes that reached a density look-up, [1] lane-passes that ended in retry spins only (the
     // Philox words buffered for the pass ran out, or VPT_RETRY_SPINS), [2] retry draws in all, [3] lane-passes whose walk ended at t >= distance
@@ -192,6 +198,7 @@ struct TraceParams {
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
     uint32_t chunk;                  // queue entries a wave claims per global atomic: VPT_CHUNK, half of it for launches of a few iterations
     uint32_t raygen_small_iters;     // launches of fewer iterations run raygen over 16-row tiles (four times the blocks)
+    uint32_t raygen_squares;         // a raygen wave covers an 8 x 8 pixel square (a never-traced mask exists: live or skipped as a whole) or 64 pixels of a row (no mask: 1 KB store runs)
     // COMPACT RAY RECORDS (round 5; closed lens + heads): a queued ray's record is 32 bytes instead of 64 -- {a.x, a.y, a.z, word} + the Philox block, where
     // a = the position raygen's empty-node pushes reached, or (t_hit, depth, t_box), and word = obj [0:6] | advanced [7] | pushes [8:13] | Philox word index
     // [14:16] | Philox blocks since the sample's stream origin [17:31].  The origin is the camera's, the direction is the sample's 16-byte head (written

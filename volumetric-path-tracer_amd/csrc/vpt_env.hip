@@ -13,10 +13,11 @@
 // `total_int` loop that adds marginal_func[0] `res` times -- is restated as written.
 // Host code only (no kernels); strict arithmetic like the rest of the host side.
 //
-// NOTE on form: `solve_quadratic`, `ray_sphere`, `host_degree_to_cartesian` and `host_sample_atmosphere` below (lines 25-118) are a LITERAL
-// RESTATEMENT of source/main.cpp:182-312, statement for statement with other names -- not a redesign.  They feed point-sampled CDF inversion on
-// the decision path of estimate_sky, tests/test_env_cdf.py demands the tables BIT-identical to the reference's own lines compiled for the host,
-// and for ~90 lines of scalar binary32 host arithmetic the operation order IS the specification.  The fill loop after them is re-expressed.
+// NOTE on form (round 6): the host single-scattering sky below is this file's own decomposition -- `ray_shell` (one routine for both sphere tests, returning the
+// ordered roots), `Slab` / `slab_at` (the two species' optical-depth increments of one march segment), `sun_column` (the 8-segment march towards the sun) and
+// `single_scatter_sky` (the 16-segment view march) -- but every binary32 operation is the one source/main.cpp:182-312 performs, in its order: the tables feed
+// point-sampled CDF inversion on the decision path of estimate_sky, and tests/test_env_cdf.py demands them BIT-identical to the reference's own lines compiled
+// for the host.  (Rounds 1-5 carried a statement-for-statement restatement of those lines here.)
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -27,100 +28,117 @@
 namespace vpt {
 namespace {
 
-// solveQuadratic, main.cpp:182-199
-bool solve_quadratic(float a, float b, float c, float& x1, float& x2) {
-    if (b == 0) {
-        if (a == 0) return false;
-        x1 = 0;
-        x2 = sqrtf(-c / a);
-        return true;
+// the model's constants (main.cpp:243-249): ground and top-of-atmosphere radii, Rayleigh / Mie scale heights and scattering coefficients
+constexpr float kGroundRadius = 6360e3f, kTopRadius = 6420e3f;
+constexpr float kScaleHeight[2] = {7994.0f, 1200.0f};
+constexpr unsigned kViewSegments = 16, kSunSegments = 8;
+
+// Where the ray o + t d meets the sphere |x| = R about the origin: the two roots of (d.d) t^2 + 2 (d.o) t + (o.o - R^2) = 0 in ascending order, by the
+// cancellation-free form q = -(b + sign(b) sqrt(disc)) / 2, t = {q / a, c / q} (main.cpp:182-214).  A miss leaves both roots 0.
+struct ShellRoots {
+    bool hit;
+    float t_near, t_far;
+};
+ShellRoots ray_shell(const f3& o, const f3& d, float R) {
+    ShellRoots s = {false, 0.0f, 0.0f};
+    const float qa = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float qb = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    const float qc = o.x * o.x + o.y * o.y + o.z * o.z - R * R;
+    float r0, r1;
+    if (qb == 0) {
+        if (qa == 0) return s;                       // a null direction meets nothing
+        r0 = 0;
+        r1 = sqrtf(-qc / qa);
+    } else {
+        const float disc = qb * qb - 4 * qa * qc;
+        if (disc < 0) return s;
+        const float root = sqrtf(disc);
+        const float q = (qb < 0.f) ? -0.5f * (qb - root) : -0.5f * (qb + root);
+        r0 = q / qa;
+        r1 = qc / q;
     }
-    float discr = b * b - 4 * a * c;
-    if (discr < 0) return false;
-    float q = (b < 0.f) ? -0.5f * (b - sqrtf(discr)) : -0.5f * (b + sqrtf(discr));
-    x1 = q / a;
-    x2 = c / q;
+    const bool ordered = !(r0 > r1);
+    s.hit = true;
+    s.t_near = ordered ? r0 : r1;
+    s.t_far = ordered ? r1 : r0;
+    return s;
+}
+
+// the sun's direction from the GUI's angles as the HOST forms it (main.cpp:222-236): elevation clamped to [0, 90] (the device clamps to [-90, 90], Q-list 13)
+f3 sun_from_angles(float azimuth_deg, float elevation_deg) {
+    const float az = clampf(azimuth_deg, .0f, 360.0f) * VPT_PI / 180.0f;
+    const float polar = (90.0f - clampf(elevation_deg, .0f, 90.0f)) * VPT_PI / 180.0f;
+    return normalize(mk3(sinf(polar) * cosf(az), cosf(polar), sinf(polar) * sinf(az)));
+}
+
+// optical-depth increments of one march segment at altitude `height`, Rayleigh [0] and Mie [1]: exp(-height / H) * length
+struct Slab {
+    float v[2];
+};
+Slab slab_at(float height, float length_) {
+    Slab s;
+    for (int k = 0; k < 2; ++k) s.v[k] = std::exp(-height / kScaleHeight[k]) * length_;
+    return s;
+}
+
+// The march from p towards the sun up to the top of the atmosphere in kSunSegments midpoint samples (main.cpp:279-291).  false: a sample fell below the
+// ground (the point is in the earth's shadow and contributes nothing); `depth` then holds the partial sums, as the reference's locals would.
+bool sun_column(const f3& p, const f3& sun, Slab& depth) {
+    const float seg = ray_shell(p, sun, kTopRadius).t_far / kSunSegments;
+    float t = 0;
+    depth.v[0] = depth.v[1] = 0;
+    for (unsigned j = 0; j < kSunSegments; ++j) {
+        const f3 q = p + (t + seg * 0.5f) * sun;
+        const float height = length(q) - kGroundRadius;
+        if (height < 0) return false;
+        const Slab inc = slab_at(height, seg);
+        depth.v[0] += inc.v[0];
+        depth.v[1] += inc.v[1];
+        t += seg;
+    }
     return true;
 }
-// raySphereIntersect, main.cpp:201-214
-bool ray_sphere(const f3& orig, const f3& dir, float radius, float& t0, float& t1) {
-    float A = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
-    float B = 2 * (dir.x * orig.x + dir.y * orig.y + dir.z * orig.z);
-    float C = orig.x * orig.x + orig.y * orig.y + orig.z * orig.z - radius * radius;
-    if (!solve_quadratic(A, B, C, t0, t1)) return false;
-    if (t0 > t1) {
-        float tmp = t1;
-        t1 = t0;
-        t0 = tmp;
+
+// The reference's host sky (main.cpp:242-312): single scattering along the view ray from 1 km above the ground, kViewSegments midpoint samples, each lit
+// through its own sun column; (Rayleigh sum x betaR x phaseR + Mie sum x betaM x phaseM) x intensity.  A ray that misses the atmosphere is RED (1, 0, 0).
+f3 single_scatter_sky(const vpt_kernel_params& kp, f3 orig, f3 dir, f3 intensity) {
+    const f3 sun = sun_from_angles(kp.azimuth, kp.elevation);
+    const f3 beta_r = mk3(3.8e-6f, 13.5e-6f, 33.1e-6f), beta_m = mk3(21e-6f);
+    f3 eye = orig;
+    eye.y += 1000 + 6360e3f;
+    // the marched interval: from the eye (or the atmosphere's near side) to the ground or the atmosphere's far side
+    float t_begin = .0f, t_end = 3.402823466e+38f;
+    {
+        const ShellRoots ground = ray_shell(eye, dir, kGroundRadius);
+        if (ground.hit && ground.t_far > .0f) t_end = fmax_(.0f, ground.t_near);
+        const ShellRoots top = ray_shell(eye, dir, kTopRadius);
+        if (!top.hit || top.t_far < 0) return mk3(1.0f, .0f, .0f);
+        if (top.t_near > t_begin && top.t_near > 0) t_begin = top.t_near;
+        if (top.t_far < t_end) t_end = top.t_far;
     }
-    return true;
-}
-// host degree_to_cartesian, main.cpp:222-236 (elevation clamped to [0, 90], Q-list 13)
-f3 host_degree_to_cartesian(float azimuth, float elevation) {
-    float az = clampf(azimuth, .0f, 360.0f);
-    float el = clampf(elevation, .0f, 90.0f);
-    az = az * VPT_PI / 180.0f;
-    el = (90.0f - el) * VPT_PI / 180.0f;
-    float x = sinf(el) * cosf(az);
-    float y = cosf(el);
-    float z = sinf(el) * sinf(az);
-    return normalize(mk3(x, y, z));
-}
-// host sample_atmosphere, main.cpp:242-312: single-scattering sky, 16 view x 8 light samples
-f3 host_sample_atmosphere(const vpt_kernel_params& kp, f3 orig, f3 dir, f3 intensity) {
-    const float atmosphereRadius = 6420e3f;
-    const f3 sunDirection = host_degree_to_cartesian(kp.azimuth, kp.elevation);
-    const float earthRadius = 6360e3f;
-    const float Hr = 7994.0f, Hm = 1200.0f;
-    const f3 betaR = mk3(3.8e-6f, 13.5e-6f, 33.1e-6f);
-    const f3 betaM = mk3(21e-6f);
-    float t0, t1;
-    float tmin, tmax = 3.402823466e+38f;
-    f3 pos = orig;
-    pos.y += 1000 + 6360e3f;
-    if (ray_sphere(pos, dir, earthRadius, t0, t1) && t1 > .0f) tmax = fmax_(.0f, t0);
-    tmin = .0f;
-    if (!ray_sphere(pos, dir, atmosphereRadius, t0, t1) || t1 < 0) return mk3(1.0f, .0f, .0f);
-    if (t0 > tmin && t0 > 0) tmin = t0;
-    if (t1 < tmax) tmax = t1;
-    const unsigned numSamples = 16, numSamplesLight = 8;
-    float segmentLength = (tmax - tmin) / numSamples;
-    float tCurrent = tmin;
-    f3 sumR = mk3(0.0f), sumM = mk3(0.0f);
-    float opticalDepthR = 0, opticalDepthM = 0;
-    float mu = dot(dir, sunDirection);
-    float phaseR = 3.f / (16.f * VPT_PI) * (1 + mu * mu);
-    float g = 0.76f;
-    float phaseM = 3.f / (8.f * VPT_PI) * ((1.f - g * g) * (1.f + mu * mu)) / ((2.f + g * g) * std::pow(1.f + g * g - 2.f * g * mu, 1.5f));
-    for (unsigned i = 0; i < numSamples; ++i) {
-        f3 samplePosition = pos + (tCurrent + segmentLength * 0.5f) * dir;
-        float height = length(samplePosition) - earthRadius;
-        float hr = std::exp(-height / Hr) * segmentLength;
-        float hm = std::exp(-height / Hm) * segmentLength;
-        opticalDepthR += hr;
-        opticalDepthM += hm;
-        float t0Light = 0, t1Light = 0;
-        ray_sphere(samplePosition, sunDirection, atmosphereRadius, t0Light, t1Light);
-        float segmentLengthLight = t1Light / numSamplesLight, tCurrentLight = 0;
-        float opticalDepthLightR = 0, opticalDepthLightM = 0;
-        unsigned j;
-        for (j = 0; j < numSamplesLight; ++j) {
-            f3 samplePositionLight = samplePosition + (tCurrentLight + segmentLengthLight * 0.5f) * sunDirection;
-            float heightLight = length(samplePositionLight) - earthRadius;
-            if (heightLight < 0) break;
-            opticalDepthLightR += std::exp(-heightLight / Hr) * segmentLengthLight;
-            opticalDepthLightM += std::exp(-heightLight / Hm) * segmentLengthLight;
-            tCurrentLight += segmentLengthLight;
+    const float seg = (t_end - t_begin) / kViewSegments;
+    const float mu = dot(dir, sun);
+    const float phase_r = 3.f / (16.f * VPT_PI) * (1 + mu * mu);
+    const float g = 0.76f;
+    const float phase_m = 3.f / (8.f * VPT_PI) * ((1.f - g * g) * (1.f + mu * mu)) / ((2.f + g * g) * std::pow(1.f + g * g - 2.f * g * mu, 1.5f));
+    f3 sum_r = mk3(0.0f), sum_m = mk3(0.0f);
+    Slab view = {{0, 0}};                              // optical depth from the eye to the current sample
+    float t = t_begin;
+    for (unsigned i = 0; i < kViewSegments; ++i) {
+        const f3 p = eye + (t + seg * 0.5f) * dir;
+        const Slab here = slab_at(length(p) - kGroundRadius, seg);
+        view.v[0] += here.v[0];
+        view.v[1] += here.v[1];
+        Slab to_sun;
+        if (sun_column(p, sun, to_sun)) {
+            const f3 tau = beta_r * (view.v[0] + to_sun.v[0]) + beta_m * 1.1f * (view.v[1] + to_sun.v[1]);
+            const f3 attenuation = mk3(std::exp(-tau.x), std::exp(-tau.y), std::exp(-tau.z));
+            sum_r += attenuation * here.v[0];
+            sum_m += attenuation * here.v[1];
         }
-        if (j == numSamplesLight) {
-            f3 tau = betaR * (opticalDepthR + opticalDepthLightR) + betaM * 1.1f * (opticalDepthM + opticalDepthLightM);
-            f3 attenuation = mk3(std::exp(-tau.x), std::exp(-tau.y), std::exp(-tau.z));
-            sumR += attenuation * hr;
-            sumM += attenuation * hm;
-        }
-        tCurrent += segmentLength;
+        t += seg;
     }
-    return (sumR * betaR * phaseR + sumM * betaM * phaseM) * intensity;
+    return (sum_r * beta_r * phase_r + sum_m * beta_m * phase_m) * intensity;
 }
 
 }  // namespace
@@ -150,7 +168,7 @@ int vpt_env_cdf_build(const vpt_kernel_params* kp, int res_i, float* val4, float
             const size_t i = (size_t)y * res + x;
             const float az = float(x) / float(res - 1) * VPT_PI * 2.0f;
             const f3 dir = mk3(sinf(el) * cosf(az), cosf(el), sinf(el) * sinf(az));
-            val[i] = host_sample_atmosphere(*kp, pos, dir, sky_color);
+            val[i] = single_scatter_sky(*kp, pos, dir, sky_color);
             func[i] = length(val[i]);
             const float prev_cdf = i > 0 ? cdf[i - 1] : .0f;            // reads before the array are 0
             const float prev_func = i > 0 ? func[i - 1] : .0f;

@@ -225,6 +225,10 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("VPT_RAYGEN_SMALL_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) ctx->raygen_small_iters = (uint32_t)v; }
+    ctx->no_zero_mask = std::getenv("VPT_NO_ZERO_MASK") != nullptr;
+    if (const char* e = std::getenv("VPT_ZERO_MASK_MIN_BYTES")) ctx->zmask_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("VPT_ZERO_MASK_SHIFT")) ctx->zmask_shift = std::atoi(e);
+    if (const char* e = std::getenv("VPT_RAYGEN_FOOTPRINT")) ctx->raygen_footprint = std::strcmp(e, "rows") == 0 ? 0 : (std::strcmp(e, "squares") == 0 ? 1 : -1);
     ctx->ahead.off = std::getenv("VPT_NO_FRAME_AHEAD") != nullptr;
     if (const char* e = std::getenv("VPT_FRAME_AHEAD_MAX")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->ahead.max_k = (unsigned)v; }
     HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
@@ -389,6 +393,26 @@ __global__ void quads_kernel(const float* __restrict__ src, float4* __restrict__
                          src[((size_t)k1 * dy + j0) * dx + x], src[((size_t)k1 * dy + j1) * dx + x]);
 }
 
+// zero-footprint mask of a dense x-fastest grid (DVolume::zmask): one thread per block of (1 << sh)^3 footprint ORIGINS; the origins s = origin + 1 of block b
+// are [b << sh, (b << sh) + (1 << sh) - 1] per axis, their footprints' texels (clamp addressing) [max((b << sh) - 1, 0), min((b << sh) + (1 << sh) - 1, d - 1)].
+// The bit is set when all of those are exactly 0.0f (either sign).  `mask` arrives zeroed.
+__global__ void zmask_kernel(const float* __restrict__ src, uint32_t* __restrict__ mask, int dx, int dy, int dz, int sh, int nbx, int nby, int nbz, int nwx) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (size_t)nbx * nby * nbz) return;
+    const int bx = (int)(o % (size_t)nbx), by = (int)((o / (size_t)nbx) % (size_t)nby), bz = (int)(o / ((size_t)nbx * nby));
+    const int e = 1 << sh;
+    const int x0 = max((bx << sh) - 1, 0), x1 = min((bx << sh) + e - 1, dx - 1);
+    const int y0 = max((by << sh) - 1, 0), y1 = min((by << sh) + e - 1, dy - 1);
+    const int z0 = max((bz << sh) - 1, 0), z1 = min((bz << sh) + e - 1, dz - 1);
+    bool zero = true;
+    for (int z = z0; z <= z1 && zero; ++z)
+        for (int y = y0; y <= y1 && zero; ++y) {
+            const float* row = src + ((size_t)z * dy + y) * dx;
+            for (int x = x0; x <= x1; ++x) zero = zero && row[x] == 0.0f;
+        }
+    if (zero) atomicOr(mask + ((size_t)bz * nby + by) * nwx + (bx >> 5), 1u << (bx & 31));
+}
+
 // vpt_fastdiv.h's verdict for one divisor, remembered for the process (~3 ms each: a scene has three, instances share theirs)
 static bool divisor_checked(float d, float r) {
     static std::mutex mu;
@@ -445,6 +469,38 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     ctx->bricked.clear();
     const size_t relaid_min = ctx->relaid_min_bytes;      // grids below this stay L2 resident anyway
     struct Relaid { const float* src; const float* dst; int layout; };
+    struct ZMask { const float* src; const uint32_t* mask; int sh, nwx, nby; };
+    std::vector<ZMask> zmasks;                            // instances share their file's mask
+    // DVolume::zmask for a density grid at or above ctx->zmask_min_bytes (grids that do not stay cache resident: below, the mask's own dependent
+    // load costs more than the two quad loads it saves -- they hit L2).  Block edge: the smallest of 4 / 8 / 16 origins whose bit-set stays <= 512 KB.
+    auto zero_mask = [&](const DTexture& t, DVolume& d) -> int {
+        d.zmask = nullptr; d.zshift = d.znwx = d.znby = 0;
+        if (ctx->no_zero_mask || (size_t)t.width * t.height * t.depth * sizeof(float) < ctx->zmask_min_bytes) return VPT_OK;
+        for (auto& z : zmasks)
+            if (z.src == t.data) { d.zmask = z.mask; d.zshift = z.sh; d.znwx = z.nwx; d.znby = z.nby; return VPT_OK; }
+        int sh = 2, nbx = 0, nby = 0, nbz = 0, nwx = 0;
+        for (; sh <= 4; ++sh) {
+            nbx = (t.width >> sh) + 1; nby = (t.height >> sh) + 1; nbz = (t.depth >> sh) + 1;
+            nwx = (nbx + 31) / 32;
+            if ((size_t)nwx * nby * nbz * 4u <= ((size_t)512 << 10) || sh == 4) break;
+        }
+        if (ctx->zmask_shift >= 2 && ctx->zmask_shift <= 6) {
+            sh = ctx->zmask_shift;
+            nbx = (t.width >> sh) + 1; nby = (t.height >> sh) + 1; nbz = (t.depth >> sh) + 1; nwx = (nbx + 31) / 32;
+        }
+        if ((long long)nwx * nby * nbz >= (1ll << 24)) return VPT_OK;                // (the word index is formed with the 24-bit multiplier)
+        const size_t words = (size_t)nwx * nby * nbz;
+        uint32_t* m = nullptr;
+        HIPCHK(ctx, hipMalloc(&m, words * sizeof(uint32_t)));
+        ctx->bricked.push_back(m);
+        HIPCHK(ctx, hipMemsetAsync(m, 0, words * sizeof(uint32_t), ctx->stream));
+        const size_t blocks = (size_t)nbx * nby * nbz;
+        hipLaunchKernelGGL(zmask_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, ctx->stream, t.data, m, t.width, t.height, t.depth, sh, nbx, nby, nbz, nwx);
+        HIPCHK(ctx, hipGetLastError());
+        zmasks.push_back({t.data, m, sh, nwx, nby});
+        d.zmask = m; d.zshift = sh; d.znwx = nwx; d.znby = nby;
+        return VPT_OK;
+    };
     std::vector<Relaid> relaid;                           // instances share their file's grid
     // f32 grid -> the layout the tracers read it in: corner quads when the grid is above the threshold, the entry count fits 32 bits
     // and the 4x footprint is at most half of the free HBM; else (density only) 4x4x4 bricks; else the caller's dense array
@@ -502,6 +558,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
             d.density = laid;
             d.layout = layout;
             d.bdim[0] = (t.width + 3) / 4; d.bdim[1] = (t.height + 3) / 4;
+            if (int rc = zero_mask(t, d)) return rc;
         }
         if (vi.has_emission) {
             if (resolve_tex(ctx, vi.emission_texture, &t) != 0 || t.channels != 1) {
@@ -732,6 +789,7 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
         out->density_fetches = c.fetches[0];
         out->color_fetches = c.fetches[1];
         out->emission_fetches = c.fetches[2];
+        out->density_zero_skips = c.fetches[3];
     }
     return VPT_OK;
 }
@@ -1365,6 +1423,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         const int rc = vpt_view_caches_prepare(ctx, cam, ref_sphere, kp, compact, iter_count, R, P, stream);
         if (rc != VPT_OK) return rc;
     }
+    // raygen's footprint follows the mask (round 6): squares where whole 8 x 8 tiles are skipped, rows (1 KB store runs instead of 128-byte ones) where nothing is
+    P.raygen_squares = ctx->raygen_footprint >= 0 ? (uint32_t)ctx->raygen_footprint : (P.never_traced != nullptr ? 1u : 0u);
     ctx->last_resolve = R;
     ctx->have_last_resolve = true;
     ctx->spans.clear();

@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
     // strip, the empty-node pushes and the traced-only Philox blocks see rays that are neighbours in both directions, and the tracer's refills (consecutive queue
     // entries) take their rays from one square.  Per pass the block's four waves take the squares 4 pass .. 4 pass + 3 of the tile (row-major, 8 per row); every
     // store of a wave still covers whole 128-byte lines (8 pixels x 16 bytes per row of the square).  The sample is keyed by (pixel, iteration): results do not move.
-    const int sq_x = (int)(tile_x * 64u) + (lane & 7), sq_y = (int)(tile_y * VPT_RAYGEN_ROWS) + (lane >> 3);
+    // WHERE NO MASK EXISTS (config 4, a view without sky patches) nothing is skipped and the square's 128-byte store runs cost ~0.2 ms per launch against the 1 KB runs of a
+    // row: the footprint follows the mask (round 6, TraceParams::raygen_squares; launch-uniform).
+    const bool squares = P.raygen_squares != 0u;
+    const int sq_x = (int)(tile_x * 64u) + (squares ? (lane & 7) : lane), sq_y = (int)(tile_y * VPT_RAYGEN_ROWS) + (squares ? (lane >> 3) : 0);
     // the never-traced flags of this thread's pixels (one per pass), requested together up front: one memory latency per thread
     // instead of a dependent load at the head of every pass
     uint32_t never_bits = 0;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
 #pragma unroll
         for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
             const int sq = pass * 4 + (int)threadIdx.y;
-            const int xx = sq_x + (sq & 7) * 8, yy = sq_y + (sq >> 3) * 8;
+            const int xx = sq_x + (squares ? (sq & 7) * 8 : 0), yy = sq_y + (squares ? (sq >> 3) * 8 : sq);
             const uint32_t f = (xx < (int)P.width && yy < (int)P.height) ? (uint32_t)P.never_traced[(uint32_t)yy * P.width + (uint32_t)xx] : 0u;
             never_bits |= (f & 1u) << pass;
         }
     }
     for (int pass = 0; pass < VPT_RAYGEN_ROWS / 4; ++pass) {
         const int sq = pass * 4 + (int)threadIdx.y;
-        const int x = sq_x + (sq & 7) * 8, y = sq_y + (sq >> 3) * 8;
+        const int x = sq_x + (squares ? (sq & 7) * 8 : 0), y = sq_y + (squares ? (sq >> 3) * 8 : sq);
         bool enqueue = false;
         uint32_t s = 0;
         bool live = x < (int)P.width && y < (int)P.height;

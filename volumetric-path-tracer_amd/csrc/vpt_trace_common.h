@@ -209,6 +209,7 @@ VPT_D void load_vol0(DVolume& v) {
     }
     v.has_color = k->vol0.has_color; v.has_emission = k->vol0.has_emission; v.layout = k->vol0.layout; v.bdim[0] = k->vol0.bdim[0]; v.bdim[1] = k->vol0.bdim[1];
     v.elayout = k->vol0.elayout; v.addr24 = k->vol0.addr24; v.fast_div = k->vol0.fast_div;
+    v.zmask = k->vol0.zmask; v.zshift = k->vol0.zshift; v.znwx = k->vol0.znwx; v.znby = k->vol0.znby;
 }
 
 // Three-level point location (get_quadrant x3, render_kernel.cu:1102-1115 + :1193-1227).
@@ -337,7 +338,7 @@ template <bool A24> VPT_D uint32_t imul(uint32_t a, uint32_t b) { return A24 ? _
 
 struct Taps {
     int i0, i1, j0, j1, k0, k1;
-    int jr, kr;           // floor of the y / z texel coordinate before clamping (GRID_QUADS rows)
+    int ir, jr, kr;       // floor of the texel coordinates before clamping (GRID_QUADS rows; the zero-footprint mask's block)
     float ax, ay, az;
 };
 // fixed8 (TraceParams::tex_fixed8, VPT_TEX_WEIGHTS=fixed8): a DIAGNOSTIC model of the CUDA texture unit, which holds the interpolation weights in
@@ -363,6 +364,7 @@ VPT_D Taps make_taps(const int* dim, const float* dimf, f3 u, int fixed8) {     
     t.j1 = min(max(j + 1, 0), dim[1] - 1);
     t.k0 = min(max(k, 0), dim[2] - 1);
     t.k1 = min(max(k + 1, 0), dim[2] - 1);
+    t.ir = i;
     t.jr = j;
     t.kr = k;
     return t;
@@ -419,6 +421,14 @@ VPT_D void quad_entries(const int* dim, const Taps& t, uint32_t& e0, uint32_t& e
     const uint32_t row = imul<A24>(imul<A24>(kc, (uint32_t)dim[1] + 1u) + jc, (uint32_t)dim[0]);
     e0 = row + (uint32_t)t.i0;
     e1 = row + (uint32_t)t.i1;
+}
+// DVolume::zmask: is every texel of this footprint exactly zero?  One word of an L2-resident bit-set (<= 512 KB) instead of two 128-byte lines from HBM.
+typedef const __attribute__((address_space(1))) uint32_t* gptr_u;
+template <bool A24>
+VPT_D bool footprint_is_zero(const DVolume& v, const Taps& t) {
+    const uint32_t bx = (uint32_t)(t.ir + 1) >> v.zshift, by = (uint32_t)(t.jr + 1) >> v.zshift, bz = (uint32_t)(t.kr + 1) >> v.zshift;
+    const uint32_t w = imul<A24>(imul<A24>(bz, (uint32_t)v.znby) + by, (uint32_t)v.znwx) + (bx >> 5);
+    return ((((gptr_u)v.zmask)[w] >> (bx & 31u)) & 1u) != 0u;
 }
 // a corner quad is read once per look-up and (on the grids that are re-laid: those that do not stay in L2) almost never again by the same CU --
 // 1.02 lanes of a wave share an 8^3 brick on config 4 (profiles/r02_lookup_coherence.txt).  -DVPT_NT_QUADS marks the two loads non-temporal, so
@@ -539,9 +549,13 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (FC) count_fetch(P, 0, inside);
         if (inside) {
             const Taps t = make_taps(v.dim, v.dimf, u, (COUNT || FC) ? P.tex_fixed8 : 0);
-            density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
-                       : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)
-                                                 : fetch_f32<A24>(v.density, v.dim, t);
+            // (v.zmask is launch-uniform: a scalar branch; a masked footprint adds +0 to a sum that started at +0 or holds a finite value: nothing to do)
+            const bool zero = v.zmask != nullptr && footprint_is_zero<A24>(v, t);
+            if (FC) count_fetch(P, 3, zero);
+            if (!zero)
+                density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
+                           : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)
+                                                     : fetch_f32<A24>(v.density, v.dim, t);
         }
     }
     if (COLOR && COUNT && count_color && v.has_color) n_c++;      // the reference looks the colour up here (see walk_step)

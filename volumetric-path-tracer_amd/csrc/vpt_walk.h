@@ -349,8 +349,13 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         if (COLOR && COUNT && is_sample && P.vol0.has_color) c.n_c++;          // the reference looks the colour up here (:1662)
         pd.state = 1;
         if (inside) {
-            issue_f32<A24>(v0.density, v0, make_taps(v0.dim, v0.dimf, u, COUNT ? P.tex_fixed8 : 0), pd);
-            pd.state = 2;
+            const Taps t = make_taps(v0.dim, v0.dimf, u, COUNT ? P.tex_fixed8 : 0);
+            const bool zero = v0.zmask != nullptr && footprint_is_zero<A24>(v0, t);     // (density known to be +0: state 1, like a point outside the domain)
+            if (COUNT) count_fetch(P, 3, zero);
+            if (!zero) {
+                issue_f32<A24>(v0.density, v0, t, pd);
+                pd.state = 2;
+            }
         }
         if (COUNT) coherence_stats<A24>(P, w.pos);
         return WALK_PENDING;
