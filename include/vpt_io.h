@@ -10,9 +10,9 @@
  *   BN0.bmp        -> blue-noise float3        load_texture_bmp_gpu, source/util/fileIO.cpp:460-495
  *   256x1 EXR LUTs -> float3[256]              load_texture_exr_gpu, source/util/fileIO.cpp:356-390
  *   Radiance .hdr  -> float4 lat-long map      load_hdr_float4, source/hdr_loader.h:249-277
- *   PFM / PPM      <- accum / display buffers  (the reference writes EXR/PNG/JPG/TGA through
- *                                              OpenImageIO, fileIO.cpp:53-288; headless tools here
- *                                              write the two dependency-free formats)
+ *   PFM / PPM / PNG <- accum / display buffers (the reference writes EXR/PNG/JPG/TGA through
+ *                                              OpenImageIO, fileIO.cpp:53-288; here the two
+ *                                              dependency-free formats and PNG over zlib)
  * Every function returns VPT_OK or a negative VPT_E_* code (vpt_abi.h); vpt_io_last_error() gives
  * the message.  Buffers returned through `float **` are malloc'ed: release with vpt_io_free.
  */
@@ -76,6 +76,12 @@ int  vpt_io_load_hdr(const char *filename, float **rgba, int *width, int *height
 int  vpt_io_write_pfm(const char *filename, const float *pixels, int channels, int width, int height);
 /* binary PPM from the 0xffRRGGBB display buffer */
 int  vpt_io_write_ppm(const char *filename, const unsigned int *display, int width, int height);
+/* PNG, 8 bits per channel, from the 0xffRRGGBB display buffer (save_texture_png(uint32_t*), fileIO.cpp:140-154): RGB, or RGBA with the
+ * word's top byte as alpha when with_alpha != 0.  Deflate and CRC-32 come from the zlib the library already links. */
+int  vpt_io_write_png(const char *filename, const unsigned int *display, int width, int height, int with_alpha);
+/* PNG from a top-down float3 / float4 buffer, converted as OpenImageIO converts FLOAT to UINT8 (the float3 / float4 overloads of save_texture_png,
+ * fileIO.cpp:110-138): clamp to [0, 1], x 255, round to nearest; NaN -> 0 */
+int  vpt_io_write_png_float(const char *filename, const float *pixels, int channels, int width, int height);
 
 #ifdef __cplusplus
 }

@@ -160,52 +160,22 @@ def test_relaid_density_layouts_are_bit_identical(pkg, monkeypatch, scene, layou
     assert rel_l2(b.accum.cpu().numpy(), ob.accum) <= (1e-3 if scene == "cloud_vol" else 2e-6)      # value-only sky code in the vol_integrator
 
 
-@pytest.mark.parametrize("shift", ["2", "3"])
-@pytest.mark.parametrize("scene", ["dragon", "fireball", "instanced", "cloud_vol"])
-def test_zero_footprint_mask_is_bit_identical(pkg, monkeypatch, scene, shift):
-    """big density grids carry a zero-footprint mask (round 6, DVolume::zmask): one bit per block of footprint origins, set when every footprint of the block
-    is eight exact zeros -- such a look-up is +0 whatever its weights, so the two quad loads are skipped.  Forced onto small scenes (VPT_ZERO_MASK_MIN_BYTES=0;
-    block edges 4 and 8; grids with odd extents, so partial edge blocks and clamped footprints on every face): every buffer and every count equal to the
-    render without a mask, the mask really answers look-ups, and the result is the oracle's"""
-    import oracle_binding
-    def make():
-        if scene == "dragon":
-            return pkg.scene.dragon_scene(96, 64, "sun")
-        if scene == "fireball":
-            return pkg.scene.fireball_scene(96, 64, n=37)
-        if scene == "cloud_vol":
-            sd = pkg.scene.cloud_scene(96, 64, shape=(45, 31, 38), env=(64, 32))        # vol_integrator: the split-phase look-up
-            pkg.atmosphere.attach_default_atmosphere(sd, device=0)
-            return sd
-        return pkg.scene.instanced_scene(96, 64, n=18, grid=3, aperture=0.3)
-    sd = make()
-    monkeypatch.setenv("VPT_NO_ZERO_MASK", "1")
-    a = pkg.scene.HipBinding(sd, device=0)
-    a.ctx.set_counting(True)
-    a.render(3); a.sync()
-    sa = a.ctx.stats()
-    monkeypatch.delenv("VPT_NO_ZERO_MASK")
-    monkeypatch.setenv("VPT_ZERO_MASK_MIN_BYTES", "0")
-    monkeypatch.setenv("VPT_ZERO_MASK_SHIFT", shift)
-    b = pkg.scene.HipBinding(sd, device=0)
-    b.ctx.set_counting(True)
-    b.render(3); b.sync()
-    sb = b.ctx.stats()
-    assert a.accum.abs().max() > 0 and sa.density_zero_skips == 0
-    for name in ("accum", "depth", "raw", "display", "cost"):
-        np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), err_msg=name)
-    for c in ("samples", "density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps", "queued_rays", "density_fetches", "color_fetches", "emission_fetches"):
-        assert getattr(sa, c) == getattr(sb, c), c
-    assert 0 < sb.density_zero_skips < sb.density_fetches          # (every scene has empty space inside its grid's domain, and matter)
-    # ... and the timed (non-counting) instantiation takes the same path
-    c = pkg.scene.HipBinding(sd, device=0)
-    c.render(3); c.sync()
-    np.testing.assert_array_equal(a.accum.cpu().numpy(), c.accum.cpu().numpy())
-    np.testing.assert_array_equal(a.depth.cpu().numpy(), c.depth.cpu().numpy())
-    ob = oracle_binding.OracleBinding(sd)
-    ob.render(3)
-    np.testing.assert_array_equal(b.depth.cpu().numpy(), ob.depth)
-    assert rel_l2(b.accum.cpu().numpy(), ob.accum) <= (1e-3 if scene == "cloud_vol" else 2e-6)
+def test_zero_footprint_mask_is_bit_identical():
+    """The zero-footprint mask (round 6, DVolume::zmask: one bit per block of footprint origins, set when every footprint of the block is eight exact zeros -- such a
+    look-up is +0 whatever its weights, so the two quad loads are skipped) is exact and measured SLOWER than the loads it saves on every config (its own dependent load
+    ahead of the quads: profiles/r06_zero_mask.txt), so it is NOT part of the product library.  Where its study library exists
+    (`python volumetric-path-tracer_amd/build.py --variant zmask -DVPT_ZERO_MASK`), tools/zmask_ab.py renders four scenes with block edges 4 and 8 (odd extents: partial edge
+    blocks, clamped footprints on every face): every buffer and every count equal to the render without a mask, the mask really answers look-ups, the image is the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "volumetric-path-tracer_amd", "libvpt_hip_zmask.so")
+    if not os.path.exists(lib):
+        pytest.skip("study library libvpt_hip_zmask.so not built (build.py --variant zmask -DVPT_ZERO_MASK)")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "zmask_ab.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, VPT_LIB_PATH=lib), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "8 cases bit-identical" in r.stdout
 
 
 @pytest.mark.parametrize("layout", [None, "bricks", "quads"])

@@ -418,6 +418,56 @@ def test_pfm_ppm_writers(pkg, tmp_path):
     np.testing.assert_array_equal(px, np.stack([(disp >> 16) & 255, (disp >> 8) & 255, disp & 255], 1).astype(np.uint8))
 
 
+def _read_png(path):
+    """an independent decoder: chunk walk with CRC checks, zlib inflate, filter type 0 only -> (height, width, channels) uint8"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(tag + data) & 0xFFFFFFFF, tag
+        chunks.append((tag, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"] and chunks[2][1] == b""
+    w, h, depth, ctype, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, comp, flt, lace) == (8, 0, 0, 0) and ctype in (2, 6)
+    ch = 3 if ctype == 2 else 4
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, w * ch + 1)
+    assert (rows[:, 0] == 0).all()                       # filter type None on every scanline
+    return rows[:, 1:].reshape(h, w, ch)
+
+
+def test_png_writers(pkg, tmp_path):
+    """vpt_io_write_png / _png_float (the reference's save_texture_png overloads, fileIO.cpp:110-154) against an independent decoder"""
+    rng = np.random.default_rng(5)
+    w, h = 13, 7
+    disp = ((rng.integers(0, 256, h * w).astype(np.uint32) << 24) | rng.integers(0, 1 << 24, h * w).astype(np.uint32)).astype(np.uint32)
+    rgb = np.stack([(disp >> 16) & 255, (disp >> 8) & 255, disp & 255], 1).astype(np.uint8).reshape(h, w, 3)
+    pkg.io.write_png(str(tmp_path / "d.png"), disp, w, h)
+    np.testing.assert_array_equal(_read_png(str(tmp_path / "d.png")), rgb)
+    pkg.io.write_png(str(tmp_path / "da.png"), disp, w, h, with_alpha=True)
+    got = _read_png(str(tmp_path / "da.png"))
+    np.testing.assert_array_equal(got[..., :3], rgb)
+    np.testing.assert_array_equal(got[..., 3], ((disp >> 24) & 255).astype(np.uint8).reshape(h, w))
+    for ch in (3, 4):
+        img = (rng.random((h, w, ch)) * 1.6 - 0.3).astype(np.float32)           # values below 0 and above 1 are clamped
+        img[0, 0, 0] = np.nan
+        pkg.io.write_png_float(str(tmp_path / "f.png"), img, w, h)
+        exp = np.floor(np.clip(np.nan_to_num(img, nan=0.0), 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        np.testing.assert_array_equal(_read_png(str(tmp_path / "f.png")), exp)
+    # a 1080p frame goes through one IDAT chunk and round-trips
+    big = (0xFF000000 | rng.integers(0, 1 << 24, 1920 * 1080)).astype(np.uint32)
+    pkg.io.write_png(str(tmp_path / "big.png"), big, 1920, 1080)
+    got = _read_png(str(tmp_path / "big.png"))
+    assert got.shape == (1080, 1920, 3) and (got[..., 2].reshape(-1) == (big & 255).astype(np.uint8)).all()
+    with pytest.raises(pkg.VptError):
+        pkg.io.write_png(str(tmp_path / "no_such_dir" / "x.png"), disp, w, h)
+
+
 def test_io_symbols_exported(pkg):
     lib = pkg.load_library()
     assert [s for s in pkg.io.IO_SYMBOLS if not hasattr(lib, s)] == []

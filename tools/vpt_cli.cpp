@@ -12,6 +12,7 @@
 //     --sun AZ EL         degrees                                                       (default 120 30)
 //     --fov F --aperture A --density-mult D --emission-scale E --g G --ray-depth N --volume-depth N
 //     --out PREFIX        writes PREFIX.pfm (linear accum) and PREFIX.ppm (display)     (default render)
+//     --png               ... and PREFIX.png (the display image, 8-bit RGB: fileIO.cpp:140-154)
 //     --device N          first device
 //     --ranks G           render on G GPUs (devices N .. N+G-1), one host thread + one context each: rank r renders
 //                         iterations r, r+G, ... (spp / G of them) and the images are combined with ONE RCCL all-reduce
@@ -58,6 +59,7 @@ static bool ends_with(const std::string& s, const char* suf) {
 struct Options {
     std::string scene, assets = "./assets", env, lights_file, out = "render";
     int W = 1920, H = 1080, spp = 64, device = 0, ranks = 1;
+    bool png = false;
     float fov = 30.0f, aperture = 0.0f;
     vpt_kernel_params kp;
 };
@@ -69,7 +71,7 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: vpt_cli <scene.vdb|scene.ins> [--assets DIR] [--size W H] [--spp N] [--env F.hdr] [--lights F.ins] "
                         "[--integrator 0|1] [--sun AZ EL] [--fov F] [--aperture A] [--density-mult D] [--emission-scale E] [--g G] "
-                        "[--ray-depth N] [--volume-depth N] [--out PREFIX] [--device N]\n");
+                        "[--ray-depth N] [--volume-depth N] [--out PREFIX] [--png] [--device N] [--ranks G]\n");
         return 2;
     }
     Options opt;
@@ -102,6 +104,7 @@ int main(int argc, char** argv) {
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
         else if (a == "--ranks") { need(1); opt.ranks = atoi(argv[++i]); }
+        else if (a == "--png") { opt.png = true; }
         else { fprintf(stderr, "vpt_cli: unknown option %s\n", a.c_str()); return 2; }
     }
     if (W <= 0 || H <= 0 || spp <= 0) { fprintf(stderr, "vpt_cli: bad --size / --spp\n"); return 2; }
@@ -266,6 +269,7 @@ static int render_rank(const Options& opt, int rank, const unsigned char* comm_i
     HIP(hipMemcpy(disp.data(), d_disp, n * 4, hipMemcpyDeviceToHost));
     CHECK(vpt_io_write_pfm((out + ".pfm").c_str(), accum.data(), 3, W, H));
     CHECK(vpt_io_write_ppm((out + ".ppm").c_str(), disp.data(), W, H));
+    if (opt.png) CHECK(vpt_io_write_png((out + ".png").c_str(), disp.data(), W, H, 0));      // the reference's save_texture_png(uint32_t*), fileIO.cpp:140-154
     double mean = 0;
     for (float v : accum) mean += v;
     vpt_float3 lo, hi;

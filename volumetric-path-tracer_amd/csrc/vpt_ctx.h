@@ -76,7 +76,9 @@ struct vpt_ctx {
     uint32_t regen_min_vol = 1;    // vol_integrator tracer: walks are long (config 4: 71 steps per ray), refill at once
     uint32_t trans_min = 48;       // direct_integrator tracer: run the transition states once >= 48 lanes wait for them
     uint32_t trans_min_vol = 24;   // vol_integrator tracer (swept 8..48 on config 4)
-    bool no_zero_mask = false;        // VPT_NO_ZERO_MASK: no zero-footprint mask (DVolume::zmask) -- the A/B switch of its exactness test
+    // The zero-footprint mask (DVolume::zmask) is OPT-IN (VPT_ZERO_MASK=1): exact, and it takes the look-ups' HBM traffic down, but its own dependent load ahead of the
+    // two quad loads costs every config more than the skipped lines return (tracer +2.3 % on config 4, +1.3 % on 3, +3 % on 5, +1.7 % on 2: profiles/r06_zero_mask.txt)
+    bool no_zero_mask = true;
     size_t zmask_min_bytes = (size_t)32 << 20;   // VPT_ZERO_MASK_MIN_BYTES: density grids at or above get a mask (below they stay cache resident: the mask's dependent load costs more than it saves)
     int zmask_shift = 0;              // VPT_ZERO_MASK_SHIFT: force the block edge (2..6: 4..64 origins; study switch)
     int raygen_footprint = -1;        // VPT_RAYGEN_FOOTPRINT=rows|squares (study switch); -1: squares where the view has a never-traced mask, rows where it has none (round 6)

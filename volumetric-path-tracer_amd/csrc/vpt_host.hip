@@ -225,7 +225,7 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     if (const char* e = std::getenv("VPT_DIR_TABLE_TOL")) ctx->dir_tab_tol = (float)std::atof(e);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     if (const char* e = std::getenv("VPT_RAYGEN_SMALL_ITERS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) ctx->raygen_small_iters = (uint32_t)v; }
-    ctx->no_zero_mask = std::getenv("VPT_NO_ZERO_MASK") != nullptr;
+    ctx->no_zero_mask = std::getenv("VPT_ZERO_MASK") == nullptr || std::getenv("VPT_NO_ZERO_MASK") != nullptr;
     if (const char* e = std::getenv("VPT_ZERO_MASK_MIN_BYTES")) ctx->zmask_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VPT_ZERO_MASK_SHIFT")) ctx->zmask_shift = std::atoi(e);
     if (const char* e = std::getenv("VPT_RAYGEN_FOOTPRINT")) ctx->raygen_footprint = std::strcmp(e, "rows") == 0 ? 0 : (std::strcmp(e, "squares") == 0 ? 1 : -1);
@@ -475,6 +475,9 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     // load costs more than the two quad loads it saves -- they hit L2).  Block edge: the smallest of 4 / 8 / 16 origins whose bit-set stays <= 512 KB.
     auto zero_mask = [&](const DTexture& t, DVolume& d) -> int {
         d.zmask = nullptr; d.zshift = d.znwx = d.znby = 0;
+#ifndef VPT_ZERO_MASK
+        return VPT_OK;                                     // (the product library's tracers do not carry the mask test: vpt_trace_common.h footprint_is_zero)
+#endif
         if (ctx->no_zero_mask || (size_t)t.width * t.height * t.depth * sizeof(float) < ctx->zmask_min_bytes) return VPT_OK;
         for (auto& z : zmasks)
             if (z.src == t.data) { d.zmask = z.mask; d.zshift = z.sh; d.znwx = z.nwx; d.znby = z.nby; return VPT_OK; }

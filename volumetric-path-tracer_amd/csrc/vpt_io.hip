@@ -998,4 +998,72 @@ int vpt_io_write_ppm(const char* filename, const unsigned int* display, int widt
     return VPT_OK;
 }
 
+// PNG (ISO/IEC 15948): signature, IHDR, one IDAT holding the zlib stream of the filtered scanlines (filter type 0 per row), IEND; chunk CRCs and
+// the deflate stream come from the zlib this library already links for ZIP-compressed VDB / EXR data.  The reference writes its display buffer through
+// OpenImageIO as four 8-bit channels (save_texture_png(uint32_t*), fileIO.cpp:140-154); here the 0xffRRGGBB words are unpacked to R, G, B (, A).
+namespace {
+void png_chunk(FILE* f, const char tag[4], const uint8_t* data, size_t n) {
+    uint8_t len[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+    fwrite(len, 1, 4, f);
+    fwrite(tag, 1, 4, f);
+    if (n) fwrite(data, 1, n, f);
+    uLong c = crc32(0L, (const Bytef*)tag, 4);
+    if (n) c = crc32(c, (const Bytef*)data, (uInt)n);
+    uint8_t crc[4] = {(uint8_t)(c >> 24), (uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c};
+    fwrite(crc, 1, 4, f);
+}
+int write_png8(const char* filename, const std::vector<uint8_t>& raw, int width, int height, int channels) {
+    uLongf zn = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) return fail(VPT_E_IO, "deflate failed for %s", filename);
+    if (zn > 0x7fffffffu) return fail(VPT_E_UNSUPPORTED, "%s: image too large for one IDAT chunk", filename);
+    FILE* f = fopen(filename, "wb");
+    if (!f) return fail(VPT_E_IO, "cannot write %s", filename);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    const uint32_t w = (uint32_t)width, h = (uint32_t)height;
+    const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h,
+                              8, (uint8_t)(channels == 4 ? 6 : 2), 0, 0, 0};      // 8 bits per sample, colour type 2 (RGB) / 6 (RGBA), deflate, adaptive filtering, no interlace
+    png_chunk(f, "IHDR", ihdr, sizeof(ihdr));
+    png_chunk(f, "IDAT", z.data(), (size_t)zn);
+    png_chunk(f, "IEND", nullptr, 0);
+    const bool ok = ferror(f) == 0;
+    fclose(f);
+    return ok ? VPT_OK : fail(VPT_E_IO, "short write to %s", filename);
+}
+}  // namespace
+
+int vpt_io_write_png(const char* filename, const unsigned int* display, int width, int height, int with_alpha) {
+    if (!filename || !display || width <= 0 || height <= 0) return VPT_E_INVALID;
+    const int ch = with_alpha ? 4 : 3;
+    std::vector<uint8_t> raw(((size_t)width * ch + 1) * (size_t)height);
+    uint8_t* o = raw.data();
+    for (int y = 0; y < height; ++y) {
+        *o++ = 0;                                                        // filter type 0 (None)
+        for (int x = 0; x < width; ++x) {
+            const unsigned int v = display[(size_t)y * width + x];       // 0xffRRGGBB (render_kernel.cu:2311)
+            *o++ = (uint8_t)(v >> 16); *o++ = (uint8_t)(v >> 8); *o++ = (uint8_t)v;
+            if (with_alpha) *o++ = (uint8_t)(v >> 24);
+        }
+    }
+    return write_png8(filename, raw, width, height, ch);
+}
+
+// float3 / float4 image -> 8-bit PNG the way OpenImageIO converts FLOAT to UINT8 on write (save_texture_png(float3*), fileIO.cpp:110-123): clamp to [0, 1],
+// scale by 255, round to nearest.  No tone curve: pass the raw buffer (display-referred) for a viewable image, the accumulation buffer for a clipped linear one.
+int vpt_io_write_png_float(const char* filename, const float* pixels, int channels, int width, int height) {
+    if (!filename || !pixels || (channels != 3 && channels != 4) || width <= 0 || height <= 0) return VPT_E_INVALID;
+    std::vector<uint8_t> raw(((size_t)width * channels + 1) * (size_t)height);
+    uint8_t* o = raw.data();
+    for (int y = 0; y < height; ++y) {
+        *o++ = 0;
+        for (size_t i = 0; i < (size_t)width * channels; ++i) {
+            const float v = pixels[(size_t)y * width * channels + i];
+            const float c = v != v ? 0.0f : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+            *o++ = (uint8_t)(c * 255.0f + 0.5f);
+        }
+    }
+    return write_png8(filename, raw, width, height, channels);
+}
+
 }  // extern "C"

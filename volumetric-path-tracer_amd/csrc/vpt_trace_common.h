@@ -209,7 +209,9 @@ VPT_D void load_vol0(DVolume& v) {
     }
     v.has_color = k->vol0.has_color; v.has_emission = k->vol0.has_emission; v.layout = k->vol0.layout; v.bdim[0] = k->vol0.bdim[0]; v.bdim[1] = k->vol0.bdim[1];
     v.elayout = k->vol0.elayout; v.addr24 = k->vol0.addr24; v.fast_div = k->vol0.fast_div;
+#ifdef VPT_ZERO_MASK
     v.zmask = k->vol0.zmask; v.zshift = k->vol0.zshift; v.znwx = k->vol0.znwx; v.znby = k->vol0.znby;
+#endif
 }
 
 // Three-level point location (get_quadrant x3, render_kernel.cu:1102-1115 + :1193-1227).
@@ -423,12 +425,19 @@ VPT_D void quad_entries(const int* dim, const Taps& t, uint32_t& e0, uint32_t& e
     e1 = row + (uint32_t)t.i1;
 }
 // DVolume::zmask: is every texel of this footprint exactly zero?  One word of an L2-resident bit-set (<= 512 KB) instead of two 128-byte lines from HBM.
+// STUDY BUILDS ONLY (-DVPT_ZERO_MASK, `build.py --variant zmask -DVPT_ZERO_MASK`; at run time VPT_ZERO_MASK=1): exact, and slower on every config -- the mask word
+// is one more DEPENDENT load ahead of the quads (EXPERIMENTS.md round 6, profiles/r06_zero_mask.txt); the product library does not carry the test.
 typedef const __attribute__((address_space(1))) uint32_t* gptr_u;
 template <bool A24>
 VPT_D bool footprint_is_zero(const DVolume& v, const Taps& t) {
+#ifdef VPT_ZERO_MASK
+    if (v.zmask == nullptr) return false;              // (launch-uniform: a scalar branch)
     const uint32_t bx = (uint32_t)(t.ir + 1) >> v.zshift, by = (uint32_t)(t.jr + 1) >> v.zshift, bz = (uint32_t)(t.kr + 1) >> v.zshift;
     const uint32_t w = imul<A24>(imul<A24>(bz, (uint32_t)v.znby) + by, (uint32_t)v.znwx) + (bx >> 5);
     return ((((gptr_u)v.zmask)[w] >> (bx & 31u)) & 1u) != 0u;
+#else
+    return false;
+#endif
 }
 // a corner quad is read once per look-up and (on the grids that are re-laid: those that do not stay in L2) almost never again by the same CU --
 // 1.02 lanes of a wave share an 8^3 brick on config 4 (profiles/r02_lookup_coherence.txt).  -DVPT_NT_QUADS marks the two loads non-temporal, so
@@ -550,8 +559,10 @@ VPT_D void lookup_volume(const TraceParams& P, const float* m, const DVolume& v,
         if (inside) {
             const Taps t = make_taps(v.dim, v.dimf, u, (COUNT || FC) ? P.tex_fixed8 : 0);
             // (v.zmask is launch-uniform: a scalar branch; a masked footprint adds +0 to a sum that started at +0 or holds a finite value: nothing to do)
-            const bool zero = v.zmask != nullptr && footprint_is_zero<A24>(v, t);
+            const bool zero = footprint_is_zero<A24>(v, t);
+#ifdef VPT_ZERO_MASK
             if (FC) count_fetch(P, 3, zero);
+#endif
             if (!zero)
                 density += v.layout == GRID_QUADS    ? fetch_f32_quads<A24>(v.density, v.dim, t)
                            : v.layout == GRID_BRICKS ? fetch_f32_bricked<A24>(v.density, v, t)

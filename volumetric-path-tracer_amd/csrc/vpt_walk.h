@@ -350,8 +350,10 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
         pd.state = 1;
         if (inside) {
             const Taps t = make_taps(v0.dim, v0.dimf, u, COUNT ? P.tex_fixed8 : 0);
-            const bool zero = v0.zmask != nullptr && footprint_is_zero<A24>(v0, t);     // (density known to be +0: state 1, like a point outside the domain)
+            const bool zero = footprint_is_zero<A24>(v0, t);     // (study builds: density known to be +0 -- state 1, like a point outside the domain)
+#ifdef VPT_ZERO_MASK
             if (COUNT) count_fetch(P, 3, zero);
+#endif
             if (!zero) {
                 issue_f32<A24>(v0.density, v0, t, pd);
                 pd.state = 2;

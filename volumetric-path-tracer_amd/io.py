@@ -20,7 +20,7 @@ IO_SYMBOLS = [
     "vpt_io_vdb_stats", "vpt_io_vdb_upload", "vpt_io_ins_read", "vpt_io_ins_free", "vpt_io_ins_is_light_file",
     "vpt_io_ins_num_files", "vpt_io_ins_file_name", "vpt_io_ins_num_instances", "vpt_io_ins_instances",
     "vpt_io_ins_num_lights", "vpt_io_ins_lights", "vpt_io_load_bmp", "vpt_io_load_exr_rgb", "vpt_io_load_hdr",
-    "vpt_io_write_pfm", "vpt_io_write_ppm",
+    "vpt_io_write_pfm", "vpt_io_write_ppm", "vpt_io_write_png", "vpt_io_write_png_float",
 ]
 
 _ready = False
@@ -57,6 +57,8 @@ def _lib():
             getattr(lib, f).argtypes = [cp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.vpt_io_write_pfm.argtypes = [cp, vp, C.c_int, C.c_int, C.c_int]
         lib.vpt_io_write_ppm.argtypes = [cp, vp, C.c_int, C.c_int]
+        lib.vpt_io_write_png.argtypes = [cp, vp, C.c_int, C.c_int, C.c_int]
+        lib.vpt_io_write_png_float.argtypes = [cp, vp, C.c_int, C.c_int, C.c_int]
         _ready = True
     return lib
 
@@ -162,3 +164,15 @@ def write_pfm(path, pixels, width, height):
 def write_ppm(path, display, width, height):
     a = np.ascontiguousarray(display).view(np.uint32).reshape(height, width)
     _chk(_lib().vpt_io_write_ppm(path.encode(), a.ctypes.data_as(C.c_void_p), width, height), "vpt_io_write_ppm")
+
+
+def write_png(path, display, width, height, with_alpha=False):
+    """8-bit PNG of the 0xffRRGGBB display buffer (the reference's save_texture_png(uint32_t*), fileIO.cpp:140-154)"""
+    a = np.ascontiguousarray(display).view(np.uint32).reshape(height, width)
+    _chk(_lib().vpt_io_write_png(path.encode(), a.ctypes.data_as(C.c_void_p), width, height, 1 if with_alpha else 0), "vpt_io_write_png")
+
+
+def write_png_float(path, pixels, width, height):
+    """8-bit PNG of a float3 / float4 image, clamped to [0, 1] (OpenImageIO's FLOAT -> UINT8 conversion, fileIO.cpp:110-138)"""
+    a = np.ascontiguousarray(pixels, np.float32).reshape(height, width, -1)
+    _chk(_lib().vpt_io_write_png_float(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[2], width, height), "vpt_io_write_png_float")
