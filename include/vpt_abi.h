@@ -262,6 +262,17 @@ int  vpt_texture_destroy(vpt_ctx *ctx, vpt_texture_t tex);
  * a texture and vpt_atmosphere_precompute drop that cache themselves; a host that rewrites the CONTENTS of an adopted device
  * table in place (vpt_texture_create_device) calls this before its next render. */
 int  vpt_invalidate_sky_tables(vpt_ctx *ctx);
+/* FRAME-AHEAD.  The literal drop-in loop (one vpt_render + device sync per iteration, main.cpp:1822-1829) is served from rays traced ahead: from
+ * the second identical one-iteration call on, a call traces the rays of the next 2, 4, 8, 16 iterations in ONE launch and the following calls run
+ * only their tail (every buffer after every frame bit-identical to frame by frame).  "Identical" is decided on the BYTES of the argument structs
+ * (camera, sphere, atmosphere, kernel params, lights, stream); scene / texture / sky-table changes made through this API void what was traced.
+ * What the key cannot see is device memory rewritten IN PLACE behind unchanged pointers between two calls: the emission / density-colour
+ * look-up tables, the blue-noise buffer (the ahead batch's jitter comes from a copy taken when it was traced), a grid or table adopted with
+ * vpt_texture_create_device.  A host that does that calls vpt_frame_ahead_invalidate before its next vpt_render (the rays are traced again from
+ * the current contents), or switches the mechanism off for the context with vpt_set_frame_ahead(ctx, 0) (also: VPT_NO_FRAME_AHEAD in the
+ * environment when the context is created).  vpt_render_batch calls of more than one iteration never use it. */
+int  vpt_frame_ahead_invalidate(vpt_ctx *ctx);
+int  vpt_set_frame_ahead(vpt_ctx *ctx, int enable);
 
 /* ---- scene: instances + octree ---------------------------------------------------------
  * replaces: cuMemAlloc+HtoD of instances[] (source/main.cpp:1301-1303) and

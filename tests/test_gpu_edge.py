@@ -366,6 +366,77 @@ def test_frame_ahead_changes_nothing(pkg, monkeypatch, kind):
             np.testing.assert_array_equal(a[f][k], b[f][k], err_msg="frame %d, %s" % (f, k))
 
 
+def test_frame_ahead_invalidate_after_an_in_place_edit(pkg, monkeypatch):
+    """include/vpt_abi.h "FRAME-AHEAD": device memory rewritten IN PLACE behind an unchanged pointer is invisible to the key of the rays traced ahead.  A host that
+    rewrites its emission table between two frames calls vpt_frame_ahead_invalidate: the sequence then equals frame by frame bit for bit (without the call, frames
+    already traced would run their tails on samples that saw the old table); vpt_set_frame_ahead(ctx, 0) does the same for good."""
+    sd = _frame_scene(pkg, "fireball sun+sky")
+    frames, edit_at = 14, 6
+
+    def run(mode):
+        hb = pkg.scene.HipBinding(sd, device=0)
+        if mode == "off":
+            hb.ctx.set_frame_ahead(False)
+        out = []
+        for f in range(frames):
+            if f == edit_at:
+                hb.sync()
+                hb.emission_lut.mul_(0.25)                       # in place: same pointer in kernel_params
+                import torch
+                torch.cuda.synchronize()
+                if mode == "invalidate":
+                    hb.ctx.frame_ahead_invalidate()
+            hb.render_frame()
+            hb.sync()
+            out.append({b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "depth", "raw", "display", "blue_noise")})
+        hb.ctx.close()
+        return out
+    a = run("invalidate")
+    c = run("off")
+    monkeypatch.setenv("VPT_NO_FRAME_AHEAD", "1")
+    b = run("plain")
+    assert np.isfinite(a[-1]["accum"]).all() and a[-1]["accum"].max() > 0
+    assert not np.array_equal(a[edit_at - 1]["accum"], a[-1]["accum"])
+    for f in range(frames):
+        for k in a[f]:
+            np.testing.assert_array_equal(a[f][k], b[f][k], err_msg="invalidate: frame %d, %s" % (f, k))
+            np.testing.assert_array_equal(c[f][k], b[f][k], err_msg="set_frame_ahead(0): frame %d, %s" % (f, k))
+
+
+@pytest.mark.parametrize("kind", ["instances open lens", "dragon sun+sky"])
+def test_frame_ahead_after_a_batch(pkg, monkeypatch, kind):
+    """A batch render followed by the per-frame call (advisor, round 5: the combination no test covered): render(7) builds the per-view caches -- behind the open
+    lens the lens domes, so raygen resolves the untraced samples itself (LENSRES) and the tracer resolves the finished paths; behind the closed one the compact
+    32-byte ray records -- and the 12 one-iteration calls after it are served from rays traced ahead over those caches: one raygen + tracer launch per 2, 4, 8
+    iterations, sky_fix over the whole ahead batch, a tail per slice with its td / heads / origin offsets.  Every buffer after the batch and after every frame
+    equals VPT_NO_FRAME_AHEAD=1, and (open lens) VPT_NO_LENS_LEAN=1."""
+    sd = _frame_scene(pkg, kind)
+
+    def run():
+        hb = pkg.scene.HipBinding(sd, device=0)
+        out = []
+        hb.render(7)
+        hb.sync()
+        out.append({b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")})
+        for _ in range(12):
+            hb.render_frame()
+            hb.sync()
+            out.append({b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")})
+        hb.ctx.close()
+        return out
+    monkeypatch.delenv("VPT_BATCH_ITERS", raising=False)
+    a = run()
+    assert np.isfinite(a[-1]["accum"]).all() and a[-1]["accum"].max() > 0
+    variants = ["VPT_NO_FRAME_AHEAD"] + (["VPT_NO_LENS_LEAN"] if "open lens" in kind else ["VPT_NO_COMPACT_RAYS"])
+    for sw in variants:
+        monkeypatch.setenv(sw, "1")
+        b = run()
+        monkeypatch.delenv(sw)
+        for f in range(len(a)):
+            for k in a[f]:
+                np.testing.assert_array_equal(a[f][k], b[f][k], err_msg="%s: step %d, %s" % (sw, f, k))
+
+
 @pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "cloud vol_integrator"])
 def test_compact_ray_records_change_nothing(pkg, monkeypatch, kind):
     """Behind a closed lens a queued ray's record is 32 bytes -- {position reached | (t_hit, depth, t_box), packed word} + the Philox block -- instead of 64: the
@@ -407,7 +478,7 @@ def test_resolved_samples_behind_an_open_lens_change_nothing(pkg, monkeypatch, k
     its origin's table variant (csrc/vpt_dome.h: dome_variant).  The tracer resolves finished paths from it, raygen resolves the UNTRACED samples from it (their head
     then carries the value: no origin stream), sky_fix_kernel evaluates in full what no dome serves, and the tail only streams.  Against VPT_NO_LENS_LEAN=1 -- 64-byte
     records, heads + origins, the environment added inside the tail's per-pixel loop: the same operations on the same values, so every buffer and count is identical,
-    counting and timed builds, chunked batches, frames (frame-ahead on top)."""
+    counting and timed builds, chunked batches, frames (VPT_BATCH_ITERS switches frame-ahead off here: the two together are test_frame_ahead_after_a_batch)."""
     import ctypes as C
     from vpt_amd.abi import Float3
     lib = pkg.load_library()

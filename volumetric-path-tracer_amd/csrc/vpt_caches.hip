@@ -350,6 +350,20 @@ int vpt_invalidate_sky_tables(vpt_ctx* ctx) {
     return VPT_OK;
 }
 
+// include/vpt_abi.h "FRAME-AHEAD": device memory rewritten in place behind unchanged pointers is invisible to the key
+int vpt_frame_ahead_invalidate(vpt_ctx* ctx) {
+    if (!ctx) return VPT_E_INVALID;
+    ctx->ahead.key_valid = false;
+    ctx->ahead.n = 0;
+    ctx->ahead.streak = 0;
+    return VPT_OK;
+}
+int vpt_set_frame_ahead(vpt_ctx* ctx, int enable) {
+    if (!ctx) return VPT_E_INVALID;
+    ctx->ahead.off = enable == 0;
+    return vpt_frame_ahead_invalidate(ctx);
+}
+
 int vpt_test_get_cache_state(vpt_ctx* ctx, int out[8]) {
     if (!ctx || !out) return VPT_E_INVALID;
     for (int i = 0; i < 8; ++i) out[i] = 0;

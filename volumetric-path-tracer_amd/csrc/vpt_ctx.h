@@ -229,7 +229,6 @@ void vpt_set_error(vpt_ctx* ctx, const char* fmt, ...);
 
 // screen-space bounds (pixels) of the world box [lo, hi] through the closed-lens camera (vpt_host.hip); false: a corner at or behind the camera plane
 extern "C" bool vpt_project_box(const vpt_camera* cam, const double lo[3], const double hi[3], double W, double H, double rect[4]);
-// orders `stream` behind the tail a previous render left out on the tail stream (no-op when there is none)
 // the per-view caches for this render: builds what is stale, points R / P at what is in use (vpt_caches.hip)
 int vpt_view_caches_prepare(vpt_ctx* ctx, const vpt_camera* cam, const vpt_sphere* ref_sphere, const vpt_kernel_params* kp, bool compact,
                             unsigned int iter_count, vpt::ResolveParams& R, vpt::TraceParams& P, hipStream_t stream);

@@ -359,9 +359,10 @@ int vpt_texture_destroy(vpt_ctx* ctx, vpt_texture_t tex) {
     if (!ctx || tex == 0 || tex > ctx->textures.size() || !ctx->textures[tex - 1].live) return VPT_E_INVALID;
     TexEntry& t = ctx->textures[tex - 1];
     if (t.owned) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rq = quiesce_all(ctx, ctx->stream); if (rq != VPT_OK) return rq; }      // (renders -- rays traced ahead and their tails included -- may be running on the caller's stream)
         HIPCHK(ctx, hipFree(t.owned));
     }
+    ctx->ahead.key_valid = false; ctx->ahead.n = 0;            // (rays traced ahead may have read it)
     t.live = false;
     t.owned = nullptr;
     vpt_invalidate_sky_tables(ctx);
@@ -464,7 +465,7 @@ int vpt_scene_set_volumes(vpt_ctx* ctx, const vpt_gpu_vdb* volumes, int num_volu
     ctx->scene_ready = false;
     ctx->any_color = ctx->any_emission = false;
     ctx->ahead.key_valid = false; ctx->ahead.n = 0;            // (rays traced ahead walked the previous scene)
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rq = quiesce_all(ctx, ctx->stream); if (rq != VPT_OK) return rq; }          // (the re-laid grids freed below may still be read by a render on the caller's stream)
     for (void* b : ctx->bricked) (void)hipFree(b);
     ctx->bricked.clear();
     const size_t relaid_min = ctx->relaid_min_bytes;      // grids below this stay L2 resident anyway
@@ -1189,8 +1190,17 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             ctx->ahead.streak = consecutive ? ctx->ahead.streak + 1u : 0u;
             ctx->ahead.n = 0;                                   // whatever was traced ahead is void
             if (ctx->ahead.streak >= 1u) fa_n = std::min(ctx->ahead.max_k, 1u << std::min(ctx->ahead.streak, 6u));
-            const unsigned long long rule = std::max<unsigned long long>(1ull, ((unsigned long long)16 << 30) / ((unsigned long long)n_pixels * sizeof(Record)));
+            // what `fa_n` iterations of rays cost in scratch: EVERY per-sample stream (records 64, queue 4, heads 16, {alpha, depth} 8, second queue 4, compact rays 32
+            // behind a closed lens / origins 16 behind an open one) -- ~130-150 bytes per sample, not sizeof(Record) alone (advisor, round 5).  The 16 GiB rule of the
+            // batch path applies to that sum, and where the buffers must GROW for it the growth has to fit in half of what is free now.
+            const unsigned long long per_sample = sizeof(Record) + 4u + 16u + 8u + 4u + (cam->lens_radius == 0.0f ? 32u : 16u);
+            const unsigned long long rule = std::max<unsigned long long>(1ull, ((unsigned long long)16 << 30) / ((unsigned long long)n_pixels * per_sample));
             fa_n = (unsigned)std::min<unsigned long long>(fa_n, std::min<unsigned long long>(rule, 64ull));
+            if (fa_n > 1u && (unsigned long long)fa_n * n_pixels > ctx->records_capacity) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+                while (fa_n > 1u && ((unsigned long long)fa_n * n_pixels - ctx->records_capacity) * per_sample > (unsigned long long)free_b / 2ull) fa_n >>= 1;
+            }
             while (fa_n > 1u && (unsigned long long)kp->iteration + fa_n >= (1ull << 20)) fa_n >>= 1;
         }
         ctx->ahead.key.swap(key);
@@ -1362,8 +1372,8 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     if (chunk > 64) chunk = 64;
     if (chunk > iter_count) chunk = iter_count;
     if (ctx->batch_iters > 0) chunk = std::min<size_t>(std::min<size_t>((size_t)ctx->batch_iters, iter_count), 64);     // (ResolveParams::rcp_n, split_slot: <= 64 per launch)
-    const size_t cap_iters = std::max<size_t>(chunk, fa_iters);
-    if (ctx->records_capacity < cap_iters * per_iter) {
+    size_t cap_iters = std::max<size_t>(chunk, fa_iters);
+    for (int attempt = 0; attempt < 2 && ctx->records_capacity < cap_iters * per_iter; ++attempt) {
         { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr; ctx->records_capacity = 0;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
@@ -1374,6 +1384,18 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         if (e == hipSuccess) e = hipMalloc(&ctx->d_queue, cap_iters * per_iter * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_heads, cap_iters * per_iter * sizeof(float4));
         if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
+            (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
+            (void)hipFree(ctx->d_heads); ctx->d_heads = nullptr;
+            if (attempt == 0 && fa_iters > chunk && !fa_hit) {
+                // the larger buffers were for rays traced AHEAD: this context renders frame by frame from here on, and the call goes on with what one launch needs
+                // (a frame loop that ran before frame-ahead existed must not fail on its third frame because memory is tight)
+                ctx->ahead.max_k = 1; ctx->ahead.n = 0; ctx->ahead.streak = 0;
+                fa_n = 1;
+                cap_iters = chunk;
+                continue;
+            }
             set_error(ctx, "vpt_render: hipMalloc(%zu bytes of path records) failed: %s", cap_iters * per_iter * sizeof(Record), hipGetErrorString(e));
             return VPT_E_NOMEM;
         }
@@ -1515,6 +1537,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             ctx->spans.push_back({e1, e2, 1});
             ctx->spans.push_back({e2, e3, 2});
             ctx->ahead.it0 = it0; ctx->ahead.n = n; ctx->ahead.next = 0;
+            ctx->last_samples = total;                             // (what THIS call traced: the following calls of the slice trace nothing)
         }
         // this call's iteration: slice k of what is traced -- its tail, exactly as a one-iteration launch runs it
         const unsigned k = ctx->ahead.next;
@@ -1539,7 +1562,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[eb], stream));
         ctx->spans.push_back({ea, eb, 2});
         ctx->ahead.next = k + 1u;
-        ctx->last_samples = n_pixels;
+        if (fa_hit) ctx->last_samples = n_pixels;                  // (its tail's samples)
         ctx->last_resolve = Rk;
         if (!ctx->render_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->render_event, hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->render_event, stream));

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(HERE, "libvpt_hip.so")
 ABI_SYMBOLS = [
     "vpt_create", "vpt_destroy", "vpt_last_error", "vpt_abi_version", "vpt_stream", "vpt_sync",
     "vpt_texture_create", "vpt_texture_create_device", "vpt_texture_destroy", "vpt_invalidate_sky_tables",
+    "vpt_frame_ahead_invalidate", "vpt_set_frame_ahead",
     "vpt_scene_set_volumes", "vpt_scene_get_root", "vpt_scene_get_octree_stats",
     "vpt_render", "vpt_render_batch", "vpt_blue_noise_advance",
     "vpt_set_counting", "vpt_get_stats",
@@ -63,6 +64,8 @@ def load_library(path=None):
     lib.vpt_texture_create_device.argtypes = [vp, C.POINTER(TextureDesc), vp, C.POINTER(vpt_texture_t)]
     lib.vpt_texture_destroy.argtypes = [vp, vpt_texture_t]
     lib.vpt_invalidate_sky_tables.argtypes = [vp]
+    lib.vpt_frame_ahead_invalidate.argtypes = [vp]
+    lib.vpt_set_frame_ahead.argtypes = [vp, C.c_int]
     lib.vpt_scene_set_volumes.argtypes = [vp, C.POINTER(GpuVdb), C.c_int]
     lib.vpt_scene_get_root.argtypes = [vp, C.POINTER(Float3), C.POINTER(Float3), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.vpt_scene_get_octree_stats.argtypes = [vp, C.POINTER(C.c_int * 3)]
@@ -201,6 +204,13 @@ class Context:
     def invalidate_sky_tables(self):
         """drop the per-view caches of the environment tail (they are rebuilt by the next render that needs them)"""
         self._chk(self.lib.vpt_invalidate_sky_tables(self.h), "vpt_invalidate_sky_tables")
+
+    def frame_ahead_invalidate(self):
+        """void the rays traced ahead of a one-iteration call sequence (a device buffer behind an unchanged pointer was rewritten in place)"""
+        self._chk(self.lib.vpt_frame_ahead_invalidate(self.h), "vpt_frame_ahead_invalidate")
+
+    def set_frame_ahead(self, on):
+        self._chk(self.lib.vpt_set_frame_ahead(self.h, int(bool(on))), "vpt_set_frame_ahead")
 
     def set_counting(self, on):
         self._chk(self.lib.vpt_set_counting(self.h, int(bool(on))), "vpt_set_counting")
