@@ -249,7 +249,7 @@ def headline_line(d):
 
 
 def emit(d, detail_file):
-    """rank 0: the detail record first (a stdout line that does not start with '{', and a file), then the headline as the LAST stdout line"""
+    """rank 0: the detail record (a stdout line that does not start with '{', and a file); returns the headline, which main() prints as the LAST stdout line"""
     d["kernel_commit"] = _kernel_commit()
     detail = json.dumps(d)
     try:
@@ -262,7 +262,7 @@ def emit(d, detail_file):
     line = json.dumps(headline_line(d))
     if len(line) > 6000:                      # the driver's parser stopped at 22 KB; keep far below
         raise SystemExit("bench.py: the headline line grew to %d bytes (limit 6000)" % len(line))
-    print(line, flush=True)
+    return line
 
 
 def main():
@@ -732,11 +732,19 @@ def main():
             out["other_configs"] = others
     if not multi and rank == 0 and out is not None and cfg == "c2" and not args.no_c1 and not args.no_cpu_baseline:
         out["c1_cpu_single_thread"] = c1_single_thread()
-    if rank == 0 and out is not None:
-        emit(out, args.detail_file)
+    headline = emit(out, args.detail_file) if (rank == 0 and out is not None) else None
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    # the headline is the LAST thing this process writes to stdout: RCCL prints its version banner through C stdio, which a pipe buffers until the
+    # process exits -- flushed here, ahead of the line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if headline is not None:
+        print(headline, flush=True)
 
 
 if __name__ == "__main__":

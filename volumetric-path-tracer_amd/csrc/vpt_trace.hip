@@ -55,6 +55,9 @@ namespace vpt {
 #endif
 // LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
 // would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
+#ifndef VPT_RAYGEN_PUSH_MIN
+#define VPT_RAYGEN_PUSH_MIN 1              // (study switch, round 6: see the push loop)
+#endif
 #ifndef VPT_RAYGEN_LENS_WAVES
 #define VPT_RAYGEN_LENS_WAVES VPT_RAYGEN_WAVES_PER_EU
 #endif
@@ -184,6 +187,27 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                 f3 nmin = mk3(0.0f), nmax = mk3(0.0f);
                 int leaf = 0, st = LOC_EMPTY;
                 uint32_t pushes = 0;
+#if VPT_RAYGEN_PUSH_MIN > 1
+                // (round 6, as the tracer's skip loop: vpt_walk.h VPT_SKIP_MIN) the rounds go on while at least VPT_RAYGEN_PUSH_MIN lanes of the wave are still
+                // crossing empty nodes; the few with longer runs leave with the position reached -- still inside an empty node -- and the tracer's own loop
+                // continues from there with the same operations
+                bool pushing = true;
+#pragma unroll 1
+                for (int it = 0; it < 32; ++it) {
+                    if (pushing) {
+                        st = locate(P, s_occ, occ_top, pos, nmin, nmax, leaf);
+                        if (st != LOC_EMPTY) pushing = false;
+                        else {
+                            float t_min, t_max;
+                            box_intersect(nmin, nmax, pos, inv0, t_min, t_max);
+                            t_max = fmax_(t_max, 0.1f);
+                            pos += dir0 * t_max;
+                            pushes++;
+                        }
+                    }
+                    if ((int)__popcll(__ballot(pushing)) < VPT_RAYGEN_PUSH_MIN) break;
+                }
+#else
 #pragma unroll 1
                 for (int it = 0; it < 32; ++it) {
                     st = locate(P, s_occ, occ_top, pos, nmin, nmax, leaf);
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                     pos += dir0 * t_max;
                     pushes++;
                 }
+#endif
                 if (st == LOC_OUTSIDE) {
                     float t2;
                     if (closest_object(P, pos, dir0, inv0, t2) == 0) {
@@ -206,6 +231,8 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                 }
             }
             if (closed && traced) {
+#ifdef VPT_RAYGEN_REJECTION_LOOP
+                // (rounds 1-5, kept as the A/B switch of the block-wise form below: same stream position, same bits)
                 rng_init(rng, pixel, iteration * 4096u);
                 f3 pd;
                 do {
@@ -214,6 +241,35 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                     pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
                 } while (dot(pd, pd) >= 1.0f);
                 (void)rnd_simple(rng, pixel, draws);                          // the `time` draw
+#else
+                // random_in_unit_disk's rejection loop (camera.h:65-75) decides nothing behind a closed lens but HOW MANY words get_ray consumes: attempt k reads words
+                // 2k - 2 and 2k - 1 of the stream, the accepted attempt K is followed by the `time` draw (word 2K), and the tracer's stream starts at word 2K + 1.  A
+                // Philox block holds two attempts, so the loop is run BLOCK-WISE (round 6): both attempts of a block are tested together (their four table reads in
+                // flight at once instead of a dependent load pair per attempt), and one more block is generated while any lane is still undecided or accepted at a
+                // block's second attempt (its `time` draw is word 0 of the next block).  Same words, same tests, same position: {block, counter, word index, draws}
+                // are what the loop above leaves.  The draw-by-draw form cost raygen 0.18 of its 1.06 ms on config 2 (profiles/r06_raygen_blockwise.txt).
+                uint32_t cb = iteration * 1024u, b0, b1, b2, b3;
+                philox_block(cb, pixel, b0, b1, b2, b3);
+                uint32_t accepted = 0u;                                       // K, 0 while undecided
+                bool placed = false;                                          // the block that holds word 2K is in {b0..b3}
+                for (uint32_t j = 0u;; ++j) {
+                    if (accepted == 0u) {
+                        const bool a1 = lens_sample_accepted(P.vdc_tables, b0, b1), a2 = lens_sample_accepted(P.vdc_tables, b2, b3);
+                        accepted = a1 ? 2u * j + 1u : (a2 ? 2u * j + 2u : 0u);
+                        placed = a1;                                          // K odd: the `time` draw is word 2 of this very block
+                    }
+                    if (!__any(!placed)) break;
+                    if (!placed) {
+                        cb += 1u;
+                        philox_block(cb, pixel, b0, b1, b2, b3);
+                        placed = accepted != 0u;                              // K even: the `time` draw is word 0 of the block just generated
+                    }
+                }
+                rng.c0 = cb; rng.o0 = b0; rng.o1 = b1; rng.o2 = b2; rng.o3 = b3;
+                rng.idx = (accepted & 1u) ? 3u : 1u;                          // next word behind the `time` draw
+                rng.carry = 0u; rng.has_carry = 0u;
+                draws = 2u * accepted + 1u;
+#endif
             }
             // :1883-1888: sphere first -> depth is the distance to it
             const float depth = (obj == 2) ? length(org0 - (org0 + dir0 * t_hit)) : 0.0f;

@@ -629,4 +629,13 @@ VPT_D float van_der_corput(const float* table, Rng& rng, uint32_t key, uint32_t&
     return table[n];
 }
 
+// one attempt of random_in_unit_disk (camera.h:65-75) on two stream words: p = 2 (vdc_2(n_a), vdc_3(n_b), 0) - (1, 1, 0), accepted unless dot(p, p) >= 1.
+// The same operations as van_der_corput + the loop's test, on words instead of a generator state (raygen's block-wise form).
+VPT_D bool lens_sample_accepted(const float* tables, uint32_t wa, uint32_t wb) {
+    const float ua = (float)wa * 2.3283064365386963e-10f + 1.1641532182693481e-10f, ub = (float)wb * 2.3283064365386963e-10f + 1.1641532182693481e-10f;   // curand_uniform
+    const float a = tables[(int)(ua * 100)], b = tables[101 + (int)(ub * 100)];
+    const f3 pd = 2.0f * mk3(a, b, 0) - mk3(1.0f, 1.0f, 0.0f);
+    return !(dot(pd, pd) >= 1.0f);
+}
+
 }  // namespace vpt
