@@ -56,10 +56,11 @@ namespace vpt {
 // LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
 // would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
 #ifndef VPT_RAYGEN_PUSH_MIN
-#define VPT_RAYGEN_PUSH_MIN 1              // (study switch, round 6: see the push loop)
+#define VPT_RAYGEN_PUSH_MIN 8              // (round 6: see the push loop; 1 = rounds 1-5's loop.  Raygen -2.7 % on config 2, -1 % on config 5: profiles/r06_raygen.txt)
 #endif
+// (round 6: SIX waves per SIMD for the open-lens instantiation -- 74 registers, no spill; at seven it kept 72 and spilled 7 dwords since its footprint became a square: config 5's raygen -2.6 %)
 #ifndef VPT_RAYGEN_LENS_WAVES
-#define VPT_RAYGEN_LENS_WAVES VPT_RAYGEN_WAVES_PER_EU
+#define VPT_RAYGEN_LENS_WAVES 6
 #endif
 template <bool COUNT, int VPT_RAYGEN_ROWS, bool LENSRES>
 __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_WAVES_PER_EU) void raygen_kernel(const TraceParams P) {
@@ -580,7 +581,12 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         // >= trans_min lanes wait for it or nothing else can make progress.
         const unsigned long long tmask = __ballot(phase >= PH_T_FIRST);
         // (a lower threshold once the wave's queue is empty -- 1, 8, 16 lanes -- changes nothing measurable, not even on a one-iteration launch: profiles/r05_short_launches.txt)
+#if VPT_WALK_MIN > 1
+        // (study switch, round 6: ... or fewer than VPT_WALK_MIN lanes are walking -- a walk pass for a handful of lanes costs what one for sixty does)
+        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || (int)__popcll(__ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST)) < VPT_WALK_MIN);
+#else
         const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
+#endif
         if (COUNT) {
             const unsigned long long wm = __ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST), im = __ballot(phase == PH_IDLE);
             if (lane == 0) {
@@ -723,6 +729,12 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 }
             }
             VPT_TICK(ts1);                       // TRACK_DONE .. EMIT / SPH
+#ifdef VPT_HOIST_GCO
+            // (study switch, round 6) get_closest_object of :1806 (OUTER_SECOND) and of :1782 (OUTER_TOP, for the lanes that enter it with a stale result) in ONE
+            // place: the two states are populated in the same pass, and the ~120 instructions then issue once for both groups instead of once each
+            if (gco_obj < 0 && (phase == PH_T_OUTER_SECOND || (phase == PH_T_OUTER_TOP && (int)rd <= C.ray_depth)))
+                gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t);
+#endif
             if (phase == PH_T_OUTER_SECOND) {
                 if (gco_obj < 0) gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t); // :1806
                 if (gco_obj == 2) {
