@@ -581,12 +581,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         // >= trans_min lanes wait for it or nothing else can make progress.
         const unsigned long long tmask = __ballot(phase >= PH_T_FIRST);
         // (a lower threshold once the wave's queue is empty -- 1, 8, 16 lanes -- changes nothing measurable, not even on a one-iteration launch: profiles/r05_short_launches.txt)
-#if VPT_WALK_MIN > 1
-        // (study switch, round 6: ... or fewer than VPT_WALK_MIN lanes are walking -- a walk pass for a handful of lanes costs what one for sixty does)
-        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || (int)__popcll(__ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST)) < VPT_WALK_MIN);
-#else
+        // (round 6, measured and closed: ... "or fewer than 8 / 16 / 24 lanes are walking" -- +0.4 / +0.5 / +2 % tracer time; threshold 40 / 56 instead of 48: +1.6 / +0.3 %.  profiles/r06_closed.txt)
         const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= PH_W_FIRST && phase <= PH_W_LAST));
-#endif
         if (COUNT) {
             const unsigned long long wm = __ballot(phase >= PH_W_FIRST && phase <= PH_W_LAST), im = __ballot(phase == PH_IDLE);
             if (lane == 0) {
@@ -729,12 +725,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 }
             }
             VPT_TICK(ts1);                       // TRACK_DONE .. EMIT / SPH
-#ifdef VPT_HOIST_GCO
-            // (study switch, round 6) get_closest_object of :1806 (OUTER_SECOND) and of :1782 (OUTER_TOP, for the lanes that enter it with a stale result) in ONE
-            // place: the two states are populated in the same pass, and the ~120 instructions then issue once for both groups instead of once each
-            if (gco_obj < 0 && (phase == PH_T_OUTER_SECOND || (phase == PH_T_OUTER_TOP && (int)rd <= C.ray_depth)))
-                gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t);
-#endif
+            // (round 6, measured and closed: get_closest_object of OUTER_SECOND and of OUTER_TOP hoisted into one place ahead of both states -- no change, profiles/r06_closed.txt)
             if (phase == PH_T_OUTER_SECOND) {
                 if (gco_obj < 0) gco_obj = closest_object(K.root_lo, K.root_hi, C.sph_center, C.sph_radius, w.pos, w.dir, w.inv, gco_t); // :1806
                 if (gco_obj == 2) {

@@ -332,11 +332,7 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
 
         // ==== transitions ===================================================================
         const unsigned long long tmask = __ballot(phase >= VH_T_FIRST);
-#if VPT_WALK_MIN > 1
-        const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || (int)__popcll(__ballot(phase >= VH_W_FIRST && phase <= VH_W_LAST)) < VPT_WALK_MIN);
-#else
         const bool run_trans = tmask != 0ull && ((uint32_t)__popcll(tmask) >= trans_min || !__any(phase >= VH_W_FIRST && phase <= VH_W_LAST));
-#endif
         if (COUNT) {                     // schedule statistics (vpt_test_get_schedule), as in trace_kernel
             const unsigned long long wm = __ballot(phase >= VH_W_FIRST && phase <= VH_W_LAST), im = __ballot(phase == VH_IDLE);
             if (lane == 0) {

@@ -61,9 +61,6 @@ enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
 #ifndef VPT_SKIP_MIN
 #define VPT_SKIP_MIN 8
 #endif
-#ifndef VPT_WALK_MIN
-#define VPT_WALK_MIN 1                    // (study switch, round 6: see run_trans in the tracers)
-#endif
 #ifndef VPT_RETRY_SPINS
 #define VPT_RETRY_SPINS 4
 #endif
