@@ -208,7 +208,7 @@ __global__ __launch_bounds__(768) void trace_pool_kernel(const TraceParams P) {
             // ==== FILL: new rays from the compacted queue into free columns ================================
             // the wave owns a chunk of VPT_CHUNK queue entries at a time (one global atomic per 256 rays), 4 entries per lane
             if (chunk_next == chunk_end && more) {
-                claim_chunk(P, total, lane, 0, chunk_next, chunk_end, more);
+                claim_chunk<1>(P, total, lane, 0, chunk_next, chunk_end, more);
                 chunk_base = chunk_next;
                 qi0 = chunk_base + (uint32_t)lane < chunk_end ? P.queue[chunk_base + (uint32_t)lane] : 0u;
                 qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? P.queue[chunk_base + 64u + (uint32_t)lane] : 0u;

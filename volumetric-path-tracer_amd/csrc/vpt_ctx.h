@@ -81,6 +81,7 @@ struct vpt_ctx {
     bool no_zero_mask = true;
     size_t zmask_min_bytes = (size_t)32 << 20;   // VPT_ZERO_MASK_MIN_BYTES: density grids at or above get a mask (below they stay cache resident: the mask's dependent load costs more than it saves)
     int zmask_shift = 0;              // VPT_ZERO_MASK_SHIFT: force the block edge (2..6: 4..64 origins; study switch)
+    uint32_t chunk_entries = 0;       // VPT_CHUNK_ENTRIES: queue entries per claim (study switch; 0: 256, 128 for launches of a few iterations)
     int raygen_footprint = -1;        // VPT_RAYGEN_FOOTPRINT=rows|squares (study switch); -1: squares where the view has a never-traced mask, rows where it has none (round 6)
     uint32_t raygen_small_iters = 17; // VPT_RAYGEN_SMALL_ITERS: launches of fewer iterations run raygen over 16-row tiles (four times the blocks: 8 iterations 1.102 -> 1.045 ms, 16: 1.669 -> 1.611, 64: no difference; profiles/r05_batch_curve.txt)
     // pool tracer (csrc/variants/vpt_trace_pool.hip, study builds with -DVPT_WITH_POOL only): direct_integrator with the rays in an LDS pool per CU

@@ -131,6 +131,8 @@ struct DCamera {           // vpt_camera, same field order
     unsigned char viz_dof;
 };
 
+// words of vpt_ctx::d_work_counter: [0] the tracer's dequeue cursor, [4] second queue's tail, [8] raygen's queue tail, [32 + 32 c] claim counter c (128 bytes apart)
+#define VPT_WORK_COUNTER_WORDS (32 + 32 * 32)
 struct Counters {
     unsigned long long samples;
     unsigned long long density_lookups;
@@ -207,7 +209,7 @@ struct TraceParams {
     // they cost raygen +10-17 % (half-filled lines: profiles/r05_compact_rays.txt); records[] keeps the 64-byte path records of the paths the dome cannot serve.
     int compact_rays;
     float4* rays32;                  // [iter_count][n_pixels][2]
-    uint32_t* work_counter;          // next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h)
+    uint32_t* work_counter;          // [0] next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h); [32 + 32 c]: the interleaved claim counters (VPT_CLAIM_COUNTERS)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor
     const uint32_t* queue_count;     // == queue_tail, read by the tracer

@@ -228,10 +228,11 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_zero_mask = std::getenv("VPT_ZERO_MASK") == nullptr || std::getenv("VPT_NO_ZERO_MASK") != nullptr;
     if (const char* e = std::getenv("VPT_ZERO_MASK_MIN_BYTES")) ctx->zmask_min_bytes = (size_t)std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VPT_ZERO_MASK_SHIFT")) ctx->zmask_shift = std::atoi(e);
+    if (const char* e = std::getenv("VPT_CHUNK_ENTRIES")) { const int v = std::atoi(e); if (v >= 16 && v <= VPT_CHUNK) ctx->chunk_entries = (uint32_t)v; }
     if (const char* e = std::getenv("VPT_RAYGEN_FOOTPRINT")) ctx->raygen_footprint = std::strcmp(e, "rows") == 0 ? 0 : (std::strcmp(e, "squares") == 0 ? 1 : -1);
     ctx->ahead.off = std::getenv("VPT_NO_FRAME_AHEAD") != nullptr;
     if (const char* e = std::getenv("VPT_FRAME_AHEAD_MAX")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->ahead.max_k = (unsigned)v; }
-    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, 16 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_work_counter, VPT_WORK_COUNTER_WORDS * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_counters, sizeof(Counters)));
     HIPCHK(ctx, hipMemset(ctx->d_counters, 0, sizeof(Counters)));
     {
@@ -1516,14 +1517,14 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             const unsigned n = fa_n, it0 = kp->iteration;
             if (!ctx->ahead.d_bn) HIPCHK(ctx, hipMalloc(&ctx->ahead.d_bn, 65536 * 3 * sizeof(float)));
             HIPCHK(ctx, hipMemcpyAsync(ctx->ahead.d_bn, bn_caller, 65536 * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
+            HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, VPT_WORK_COUNTER_WORDS * sizeof(uint32_t), stream));
             HIPCHK(ctx, launch_blue_noise(ctx->ahead.d_bn, ctx->d_bn_table, n, 1u, live, stream));
             P.iter_begin = it0; P.iter_count = n;
             R.iter_begin = it0; R.iter_count = n;
             const unsigned long long total = (unsigned long long)n_pixels * n;
             int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
             if (blocks < 1) blocks = 1;
-            P.chunk = total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK;
+            P.chunk = ctx->chunk_entries ? ctx->chunk_entries : (total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK);
             int e0, e1, e2, e3;
             if ((rc = get_events(ctx, &e0, &e1)) != 0 || (rc = get_events(ctx, &e2, &e3)) != 0) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
@@ -1582,7 +1583,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
         }
         R.display = last ? kp->display_buffer : nullptr;
         R.raw = last ? reinterpret_cast<float*>(kp->raw_buffer) : nullptr;
-        HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, 16 * sizeof(uint32_t), stream));
+        HIPCHK(ctx, hipMemsetAsync(P.work_counter, 0, VPT_WORK_COUNTER_WORDS * sizeof(uint32_t), stream));
         HIPCHK(ctx, launch_blue_noise(reinterpret_cast<float*>(kp->blue_noise_buffer), const_cast<float2*>(P.blue_noise), n, iter_stride,
                                       (uint32_t)std::min<unsigned long long>((unsigned long long)n_pixels, 65536ull), stream));
         const unsigned long long total = (unsigned long long)n_pixels * n;
@@ -1596,7 +1597,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             ev[i] = a;
             ev[i + 1] = b;
         }
-        P.chunk = total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK;
+        P.chunk = ctx->chunk_entries ? ctx->chunk_entries : (total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK);
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             VPT_TICK(tr0);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
                 if (PROF) nr2++;
-                claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
+                claim_chunk<MULTI ? 1 : VPT_CLAIM_COUNTERS>(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
                 chunk_base = chunk_next;

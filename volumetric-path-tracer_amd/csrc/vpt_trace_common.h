@@ -316,13 +316,42 @@ VPT_D void split_slot(const TraceParams& P, uint32_t slot, uint32_t& kiter, uint
 // the last chunks are shorter (per-frame tracer 0.215 -> 0.17 ms on config 2; profiles/r03_small_launch.txt).  (Partitioning the queue per XCD -- blockIdx % 8, own L2
 // -- with stealing was measured: load imbalance between image regions cost more than the L2 locality
 // gained, +4..6 % tracer time on configs 2-4.)
+#ifndef VPT_CLAIM_COUNTERS
+#define VPT_CLAIM_COUNTERS 8
+#endif
+// NC cursors, 128 bytes apart, that hand out the chunks INTERLEAVED (round 6) -- cursor c owns chunks c, c + NC, c + 2 NC, ... -- so every cursor sweeps the whole
+// queue at 1 / NC of the rate (no imbalance between image regions, unlike a partition); a workgroup starts at cursor blockIdx % NC and moves on to the next ones when its
+// own is past the end.  ONE cursor takes ~27 atomics per microsecond from the 4096 waves of a config-2 launch and answers a claim in ~9 us (7.5 % of the tracer's wave
+// cycles, profiles/r06_sections_c2_before_cursors.txt), and the first claims of a launch queue up behind each other for ~150 us: with 8 cursors config 2's tracer takes 3.72 -> 3.63 ms per
+// 64 iterations and 0.71 -> 0.53 ms per 8 (profiles/r06_claim_cursors.txt).  NC = 1 (the single cursor) for the instantiations whose claims are rare anyway -- instanced
+// scenes, the vol tracer: there the loop's scalar registers cost more than the cursors return (+1.5 % / +3 %).  Which wave traces which ray never mattered: results cannot move.
+template <int NC>
 VPT_D void claim_chunk(const TraceParams& P, uint32_t total, int lane, int leader, uint32_t& chunk_next, uint32_t& chunk_end, bool& more) {
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(P.work_counter, P.chunk);
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);     // wave-uniform: the claim lives in scalar registers
-    chunk_next = min(base, total);
-    chunk_end = min(base + P.chunk, total);
-    if (chunk_end == total) more = false;
+    if (NC > 1) {
+        uint32_t base = total;
+        if (lane == leader) {
+            const uint32_t c0 = blockIdx.x & (uint32_t)(NC - 1);
+            // (32-bit arithmetic: total < 2^31 and a cursor overshoots the end by at most one chunk index per workgroup and attempt)
+#pragma unroll 1
+            for (uint32_t a = 0; a < (uint32_t)NC; ++a) {
+                const uint32_t c = (c0 + a) & (uint32_t)(NC - 1);
+                const uint32_t k = atomicAdd(P.work_counter + 32u + 32u * c, 1u);
+                const uint32_t b = (k * (uint32_t)NC + c) * P.chunk;
+                if (b < total) { base = b; break; }
+            }
+        }
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        chunk_next = min(base, total);
+        chunk_end = base < total ? min(base + P.chunk, total) : total;
+        if (base >= total) more = false;
+    } else {
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(P.work_counter, P.chunk);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);     // wave-uniform: the claim lives in scalar registers
+        chunk_next = min(base, total);
+        chunk_end = min(base + P.chunk, total);
+        if (chunk_end == total) more = false;
+    }
 }
 
 // Grid pointers read from an instance descriptor in memory are generic pointers to the compiler, which

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
             const unsigned long long active = __ballot(1);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
-                claim_chunk(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
+                claim_chunk<1>(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
                 chunk_base = chunk_next;
