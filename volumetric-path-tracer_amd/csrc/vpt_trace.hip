@@ -549,6 +549,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 }
                 if (PROF) { nr0++; nr1 += take; }
                 VPT_TICK(tr3);
+                // (round 6, measured and closed: the NEXT refill's records touched here through global_load_lds -- no destination register, nothing waits -- so that
+                // the refill's own loads hit L2: no change, profiles/r06_closed.txt)
             }
         }
 
