@@ -160,6 +160,19 @@ def test_relaid_density_layouts_are_bit_identical(pkg, monkeypatch, scene, layou
     assert rel_l2(b.accum.cpu().numpy(), ob.accum) <= (1e-3 if scene == "cloud_vol" else 2e-6)      # value-only sky code in the vol_integrator
 
 
+def _skip_if_stale(lib):
+    """a study library left over from an earlier state of the sources (it is git-ignored and built by hand) may lack entry points the Python host binds"""
+    import ctypes
+    import __graft_entry__ as ge
+    try:
+        h = ctypes.CDLL(lib)
+    except OSError as e:
+        pytest.skip("study library %s does not load: %s" % (os.path.basename(lib), e))
+    missing = [sym for sym in ge.load_package().ABI_SYMBOLS if not hasattr(h, sym)]
+    if missing:
+        pytest.skip("stale study library %s (lacks %s): rebuild it" % (os.path.basename(lib), ", ".join(missing[:3])))
+
+
 def test_zero_footprint_mask_is_bit_identical():
     """The zero-footprint mask (round 6, DVolume::zmask: one bit per block of footprint origins, set when every footprint of the block is eight exact zeros -- such a
     look-up is +0 whatever its weights, so the two quad loads are skipped) is exact and measured SLOWER than the loads it saves on every config (its own dependent load
@@ -172,6 +185,7 @@ def test_zero_footprint_mask_is_bit_identical():
     lib = os.path.join(root, "volumetric-path-tracer_amd", "libvpt_hip_zmask.so")
     if not os.path.exists(lib):
         pytest.skip("study library libvpt_hip_zmask.so not built (build.py --variant zmask -DVPT_ZERO_MASK)")
+    _skip_if_stale(lib)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "zmask_ab.py")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, VPT_LIB_PATH=lib), cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -248,6 +262,7 @@ def test_pool_tracer_is_bit_identical_to_lane_tracer():
     lib = os.path.join(root, "volumetric-path-tracer_amd", "libvpt_hip_pool.so")
     if not os.path.exists(lib):
         pytest.skip("study library libvpt_hip_pool.so not built (build.py --variant pool --with-pool)")
+    _skip_if_stale(lib)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "pool_ab.py")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, VPT_LIB_PATH=lib), cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

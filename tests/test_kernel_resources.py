@@ -107,3 +107,31 @@ def test_timed_tracer_kernels_do_not_park_launch_constants_in_vgpr_lanes(tracer_
         # were read per look-up)
         assert lanes <= (320 if (multi and emit) else 40), (name, lanes, len(ops))
     assert seen >= 20
+
+
+def test_timed_raygen_kernels_do_not_spill(pkg):
+    """raygen's timed instantiations (template argument COUNT = false) run without scratch: the closed-lens one at seven waves per SIMD (<= 72 registers), the
+    open-lens one that resolves untraced samples from the lens domes at six (<= 80): at seven it kept 72 registers and spilled 7 dwords once its footprint became a
+    square (round 5; config 5's raygen +5 %, repaired in round 6 -- profiles/r06_raygen.txt)"""
+    if not os.path.exists(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    seen = {}
+    for blob in _code_objects(LIB):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(blob)
+        try:
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name], capture_output=True, text=True).stdout
+        finally:
+            os.unlink(f.name)
+        if "raygen_kernel" not in notes:
+            continue
+        for blk in notes.split("- .agpr_count:")[1:]:
+            g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, None])[1]
+            name = g("name")
+            m = re.search(r"raygen_kernelILb([01])ELi(\d+)ELb([01])E", name or "")
+            if m and m.group(1) == "0":
+                seen[name] = (m.group(3) == "1", int(g("vgpr_count")), int(g("private_segment_fixed_size")), int(g("vgpr_spill_count")))
+    assert len(seen) == 4, sorted(seen)                 # rows 16 / 64 x closed / open lens
+    for name, (lens, vgpr, scratch, spill) in seen.items():
+        assert scratch == 0 and spill == 0, (name, vgpr, scratch, spill)
+        assert vgpr <= (80 if lens else 72), (name, vgpr)

@@ -56,7 +56,7 @@ namespace vpt {
 // LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
 // would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
 #ifndef VPT_RAYGEN_PUSH_MIN
-#define VPT_RAYGEN_PUSH_MIN 8              // (round 6: see the push loop; 1 = rounds 1-5's loop.  Raygen -2.7 % on config 2, -1 % on config 5: profiles/r06_raygen.txt)
+#define VPT_RAYGEN_PUSH_MIN 1              // (study switch, round 6: see the push loop.  8: raygen -2.7 % on config 2 -- NOT adopted, it makes WHICH approximation serves a sample depend on the wave it sat in)
 #endif
 // (round 6: SIX waves per SIMD for the open-lens instantiation -- 74 registers, no spill; at seven it kept 72 and spilled 7 dwords since its footprint became a square: config 5's raygen -2.6 %)
 #ifndef VPT_RAYGEN_LENS_WAVES
@@ -189,9 +189,12 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                 int leaf = 0, st = LOC_EMPTY;
                 uint32_t pushes = 0;
 #if VPT_RAYGEN_PUSH_MIN > 1
-                // (round 6, as the tracer's skip loop: vpt_walk.h VPT_SKIP_MIN) the rounds go on while at least VPT_RAYGEN_PUSH_MIN lanes of the wave are still
-                // crossing empty nodes; the few with longer runs leave with the position reached -- still inside an empty node -- and the tracer's own loop
-                // continues from there with the same operations
+                // (study switch, round 6; as the tracer's skip loop: vpt_walk.h VPT_SKIP_MIN) the rounds go on while at least VPT_RAYGEN_PUSH_MIN lanes of the wave are still
+                // crossing empty nodes; the few with longer runs leave with the position reached -- still inside an empty node -- and the tracer's own loop continues from
+                // there with the same operations.  Walk decisions, depth and alpha cannot move -- but a ray that would have been found to cross empty nodes only (final here,
+                // its sky value from the pixel's PATCH) is then finished by the tracer (its sky value from the DOME): two value-only approximations of the same
+                // function, 1e-4 apart, and which one a sample gets would depend on its wave's other lanes -- on the footprint, on the never-traced mask being on or off.
+                // tests/test_gpu_atmosphere.py::test_never_traced_pixels_change_nothing caught it; the 0.03 ms are not worth an image that depends on the schedule.
                 bool pushing = true;
 #pragma unroll 1
                 for (int it = 0; it < 32; ++it) {
