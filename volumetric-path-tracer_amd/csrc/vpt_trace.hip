@@ -55,6 +55,9 @@ namespace vpt {
 #endif
 // LENSRES: behind an open lens with resolved samples raygen resolves the untraced ones from their origin's dome (its own instantiation: the look-up's registers
 // would cost the closed-lens kernel two spilled dwords at seven waves per SIMD)
+#ifndef VPT_TR_CONVEX_EXIT
+#define VPT_TR_CONVEX_EXIT 1               // (round 6: vpt_walk.h TRX; 0 = every Tr walk pushes on to the root's far side, as rounds 1-5)
+#endif
 #ifndef VPT_RAYGEN_PUSH_MIN
 #define VPT_RAYGEN_PUSH_MIN 1              // (study switch, round 6: see the push loop.  8: raygen -2.7 % on config 2 -- NOT adopted, it makes WHICH approximation serves a sample depend on the wave it sat in)
 #endif
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             // (one-piece step: moving the refill behind the step, as the split-phase look-up of the vol tracer needs, costs this tracer
             // 16 % -- its refilled lanes would idle for a pass -- against 1 % gained from the overlap; measured, not used here)
             Pending no_pd;
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false, 256, HCAP>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
+            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false, 256, HCAP, VPT_TR_CONVEX_EXIT && !MULTI && !COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;
@@ -859,7 +862,10 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 
             VPT_TICK(ts3);                       // FINISH
             // ---- Tr prologue :1153-1167 (shared by sun / point-light / sphere shadow rays) ---
-            if (start_tr) phase = tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir, tr_inv) ? tr_walk_phase : tr_done_phase;
+            if (start_tr) {
+                phase = tr_begin(C.sph_center, C.sph_radius, K, w, f3(ppos), tr_dir, tr_inv) ? tr_walk_phase : tr_done_phase;
+                w.geo = false;                     // (of a Tr walk: "has been inside a non-empty leaf", vpt_walk.h TRX; every `sample` walk clears it where it starts)
+            }
             VPT_TICK(ts4);                       // Tr prologue
         }
         }

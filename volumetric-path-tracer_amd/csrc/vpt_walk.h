@@ -255,7 +255,13 @@ VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample,
 // lanes from the ray queue, itself a ~1 us record read -- before walk_finish interpolates and decides: the two memory
 // latencies of a pass overlap instead of adding up.  Per lane the operations and their order are unchanged.
 enum { WALK_GOES_ON = 0, WALK_DONE = 1, WALK_PENDING = 2 };
-template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false, int HS = 256, int HCAP = VPT_HIST_CAP>
+// TRX (round 6; single-volume scenes, timed instantiations of the direct tracer): a RATIO-TRACKING walk that has been inside a non-empty leaf and now stands in an empty
+// node is over.  With one volume the non-empty leaves are a BOX of leaves (every leaf its bounds overlap), the walk moves forward along a straight line, and a line that
+// has left a convex set does not come back: from here to the root's far side there are only empty nodes -- pushes (:1193-1227), which draw nothing and look nothing up --
+// and Tr's value is trw x exp(-sigma_c x the distance taken at its start) (:1166, :1267): nothing the remaining pushes compute is ever read.  (A delta-tracking walk's
+// final position IS read -- get_closest_object starts from it, :1806 -- so `sample` walks push on; counting instantiations push on too: their skip counts are the oracle's.)
+// Walk::geo, which only `sample` walks read, carries "has been inside a leaf" for the Tr walk (cleared where the walk starts).
+template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false, int HS = 256, int HCAP = VPT_HIST_CAP, bool TRX = false>
 VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
                     int& retries, bool use_retries, Pending& pd) {
@@ -277,6 +283,10 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
     for (int it = 0; it < VPT_SKIP_LOOP; ++it) {
         if (st == LOC_EMPTY) {
             st = locate(P, s_occ, occ_top, w.pos, nmin, nmax, leaf);
+            if (TRX && kind == WALK_TR) {
+                if (st == LOC_LEAF) w.geo = true;
+                else if (st == LOC_EMPTY && w.geo) st = LOC_OUTSIDE;          // left the box of non-empty leaves for good: nothing ahead can change trw
+            }
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
                 float t_min, t_max;
