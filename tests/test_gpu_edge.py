@@ -160,6 +160,66 @@ def test_relaid_density_layouts_are_bit_identical(pkg, monkeypatch, scene, layou
     assert rel_l2(b.accum.cpu().numpy(), ob.accum) <= (1e-3 if scene == "cloud_vol" else 2e-6)      # value-only sky code in the vol_integrator
 
 
+@pytest.mark.parametrize("scene", ["dragon sun", "dragon sun+sky", "sphere close by", "sphere on the way out", "point lights, deeper loops", "rotated volume"])
+def test_convex_exit_changes_nothing(pkg, scene):
+    """CONVEX EXIT (round 6, vpt_walk.h TRX; single-volume scenes, TIMED instantiations of the direct tracer): a walk that has taken a tracking step and stands in an
+    empty node has left the box of non-empty leaves for good.  A ratio-tracking walk ends there (nothing ahead can change its value); a delta-tracking walk ends the PATH
+    there when its ray's line misses the reference sphere by a wide margin (get_closest_object at :1806 would answer "nothing" from wherever the pushes end).  The COUNTING
+    instantiations push on as the reference does (their skip counts are the oracle's): timed vs counting is therefore the A/B -- every buffer bit-identical, on views
+    where the sphere is far, where it sits right next to the volume (many exits do NOT clear it: those push on), with point lights (eleven Tr walks per scatter), with
+    volume_depth 2 / a short ray_depth, and with a rotated volume (its bounds are the box of its oriented box: still a box of leaves)."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    lib = pkg.load_library()
+    if scene == "dragon sun":
+        sd = pkg.scene.dragon_scene(192, 108, "sun")
+    elif scene == "dragon sun+sky":
+        sd = pkg.scene.dragon_scene(192, 108, "c2")
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    elif scene in ("sphere close by", "sphere on the way out"):
+        sd = pkg.scene.dragon_scene(192, 108, "sun")
+        lo, hi = Float3(), Float3()
+        lib.vpt_gpu_vdb_bounds(C.byref(sd.volumes[0][0]), C.byref(lo), C.byref(hi))
+        if scene == "sphere close by":
+            sd.sphere.center = Float3(hi.x + 0.9, (lo.y + hi.y) * 0.5, (lo.z + hi.z) * 0.5)     # touching the padded root box: rays leave the volume straight at it
+            sd.sphere.radius = 1.2
+        else:
+            o = sd.camera.origin
+            sd.sphere.center = Float3(hi.x * 2.0 - o.x * 0.2, hi.y * 1.5, hi.z * 2.0 - o.z * 0.2)
+            sd.sphere.radius = 2.5
+    elif scene == "point lights, deeper loops":
+        sd = pkg.scene.dragon_scene(160, 90, "c1")
+        sd.kp.sun_mult = 1.0
+        sd.kp.ray_depth = 4
+        sd.kp.volume_depth = 2
+    else:
+        sd = pkg.scene.dragon_scene(192, 108, "sun")
+        import numpy as np_
+        vdb = sd.volumes[0][0]
+        ang = 0.6
+        rot = np_.array([[np_.cos(ang), 0, np_.sin(ang), 0], [0, 1, 0, 0], [-np_.sin(ang), 0, np_.cos(ang), 0], [0, 0, 0, 1]], np_.float32)
+        m = np_.array([[vdb.xform[r][c] for c in range(4)] for r in range(4)], np_.float32) @ rot
+        for r in range(4):
+            for c in range(4):
+                vdb.xform[r][c] = float(m[r, c])
+
+    def run(counting):
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(counting)
+        hb.render(6)
+        hb.sync()
+        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+        st = hb.ctx.stats()
+        hb.ctx.close()
+        return out, st
+    a, sa = run(False)
+    b, sb = run(True)
+    assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0 and sb.skip_steps > 0 and sb.tracking_steps > 0
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg="%s: %s" % (scene, k))
+    assert sa.queued_rays == sb.queued_rays
+
+
 def _skip_if_stale(lib):
     """a study library left over from an earlier state of the sources (it is git-ignored and built by hand) may lack entry points the Python host binds"""
     import ctypes

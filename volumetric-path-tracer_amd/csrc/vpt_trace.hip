@@ -569,7 +569,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             // (one-piece step: moving the refill behind the step, as the split-phase look-up of the vol tracer needs, costs this tracer
             // 16 % -- its refilled lanes would idle for a pass -- against 1 % gained from the overlap; measured, not used here)
             Pending no_pd;
-            const bool done = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false, 256, HCAP, VPT_TR_CONVEX_EXIT && !MULTI && !COUNT>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd) == WALK_DONE;
+            constexpr bool TRX = VPT_TR_CONVEX_EXIT && !MULTI && !COUNT;
+            const int wr = walk_step<MULTI, COLOR, EMIT, COUNT, EMIT, A24, false, 256, HCAP, TRX>(P, s_occ, K, kind, phase == PH_W_FIRST, s_hist + threadIdx.x, n_hist, w, rng, draws, cnt, no_retry, false, no_pd);
+            const bool done = wr == WALK_DONE || wr == WALK_DONE_CLEAR;
+            // (TRX: Walk::geo is dead once a `sample` walk has ended -- it carries "nothing ahead of this ray" to TRACK_DONE)
+            if (TRX && done && kind == WALK_SAMPLE) w.geo = wr == WALK_DONE_CLEAR;
             if (done) {
                 if (phase == PH_W_FIRST) phase = PH_T_FIRST_DONE;
                 else if (phase == PH_W_TRACK) phase = PH_T_TRACK_DONE;
@@ -660,7 +664,8 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                     sample_hg(w.dir, rng, draws, C.phase_g1);
                     w.inv = rcp3(w.dir);
                 }
-                gco_obj = -1;
+                // (a walk that ended WALK_DONE_CLEAR -- vpt_walk.h TRX -- has get_closest_object's answer with it: nothing)
+                gco_obj = (VPT_TR_CONVEX_EXIT && !MULTI && !COUNT && w.geo) ? 0 : -1;
                 vd++;
                 if (!brk && (int)vd <= C.volume_depth) {
                     w.mi = false;

@@ -61,6 +61,9 @@ enum { WALK_SAMPLE = 0, WALK_TR = 1, WALK_EMIT = 2 };
 #ifndef VPT_SKIP_MIN
 #define VPT_SKIP_MIN 8
 #endif
+#ifndef VPT_SAMPLE_CONVEX_EXIT
+#define VPT_SAMPLE_CONVEX_EXIT 1
+#endif
 #ifndef VPT_RETRY_SPINS
 #define VPT_RETRY_SPINS 4
 #endif
@@ -254,13 +257,15 @@ VPT_D bool walk_decide(const TraceParams& P, const WalkConst& K, bool is_sample,
 // eight texels (returns WALK_PENDING, `pd` holds them) and the caller runs whatever else the wave has to do -- refilling idle
 // lanes from the ray queue, itself a ~1 us record read -- before walk_finish interpolates and decides: the two memory
 // latencies of a pass overlap instead of adding up.  Per lane the operations and their order are unchanged.
-enum { WALK_GOES_ON = 0, WALK_DONE = 1, WALK_PENDING = 2 };
+enum { WALK_GOES_ON = 0, WALK_DONE = 1, WALK_PENDING = 2, WALK_DONE_CLEAR = 3 };      // (DONE_CLEAR: TRX, a `sample` walk that ended with nothing ahead of its ray)
 // TRX (round 6; single-volume scenes, timed instantiations of the direct tracer): a RATIO-TRACKING walk that has been inside a non-empty leaf and now stands in an empty
 // node is over.  With one volume the non-empty leaves are a BOX of leaves (every leaf its bounds overlap), the walk moves forward along a straight line, and a line that
 // has left a convex set does not come back: from here to the root's far side there are only empty nodes -- pushes (:1193-1227), which draw nothing and look nothing up --
-// and Tr's value is trw x exp(-sigma_c x the distance taken at its start) (:1166, :1267): nothing the remaining pushes compute is ever read.  (A delta-tracking walk's
-// final position IS read -- get_closest_object starts from it, :1806 -- so `sample` walks push on; counting instantiations push on too: their skip counts are the oracle's.)
-// Walk::geo, which only `sample` walks read, carries "has been inside a leaf" for the Tr walk (cleared where the walk starts).
+// and Tr's value is trw x exp(-sigma_c x the distance taken at its start) (:1166, :1267): nothing the remaining pushes compute is ever read.  A DELTA-TRACKING walk's
+// final position is read once more -- get_closest_object starts from it, :1806 -- so it ends early only where that call's answer is known (see VPT_SAMPLE_CONVEX_EXIT in
+// the loop below); counting instantiations push on in both cases: their skip counts are the oracle's, and timed vs counting is the exactness A/B
+// (tests/test_gpu_edge.py::test_convex_exit_changes_nothing).  Walk::geo, which only `sample` walks read while they run, carries "has been inside a leaf" for a Tr walk
+// (cleared where the walk starts) and "ended with nothing ahead" from a `sample` walk's end to TRACK_DONE.  Config 2: tracer -1.5 % (Tr walks), -9 % (`sample` walks).
 template <bool MULTI, bool COLOR, bool EMIT, bool COUNT, bool ELDS, bool A24, bool SPLIT = false, int HS = 256, int HCAP = VPT_HIST_CAP, bool TRX = false>
 VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst& K, int kind, bool record_hist,
                     float* hist, uint32_t& n_hist, Walk& w, Rng& rng, uint32_t& draws, WalkCounts& c,
@@ -274,6 +279,7 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
     // operations is unchanged.
     int leaf = 0;
     int st = LOC_EMPTY;
+    bool clear_exit = false;
     const OccTop occ_top = {s_occ[0], s_occ[1], s_occ[2]};
 #ifdef VPT_PROFILE_SECTIONS
     const unsigned long long tp0_ = __builtin_readcyclecounter();
@@ -287,6 +293,19 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
                 if (st == LOC_LEAF) w.geo = true;
                 else if (st == LOC_EMPTY && w.geo) st = LOC_OUTSIDE;          // left the box of non-empty leaves for good: nothing ahead can change trw
             }
+#if VPT_SAMPLE_CONVEX_EXIT
+            if (TRX && is_sample && st == LOC_EMPTY && w.t > 0.0f) {
+                // A DELTA-TRACKING walk that has taken a tracking step (t > 0: it has been inside a leaf) and stands in an empty node will not interact any more
+                // (same convexity).  What the reference still does with it: pushes to the root's far side, then get_closest_object from THAT position (:1806) -- the
+                // box is behind it, so only the sphere can answer.  Where the ray's LINE misses the sphere by a margin a thousand times the rounding of the
+                // discriminant, the answer is "nothing" from any point of it, every later outer iteration is a no-op, and the path ends with the L, beta, alpha,
+                // depth and direction it has now: the pushes and both get_closest_object calls are skipped (WALK_DONE_CLEAR).  Anything less clear-cut pushes on.
+                const f3 o = w.pos - ld3(P.sph_center);
+                const float qa = dot(w.dir, w.dir), qb = 2.0f * dot(w.dir, o), oo = dot(o, o);
+                const float disc = qb * qb - 4.0f * qa * (oo - P.sph_radius * P.sph_radius);
+                if (disc < -1e-3f * (qb * qb + 4.0f * qa * oo)) { st = LOC_OUTSIDE; clear_exit = true; }
+            }
+#endif
             if (st == LOC_EMPTY) {
                 // empty node: push to its far side, at least 0.1 (:1613-1616)
                 float t_min, t_max;
@@ -310,7 +329,7 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
     if (!COUNT) c.n_skips += (uint32_t)(__builtin_readcyclecounter() - tp0_);      // cycles of the skip loop (perf study)
 #endif
     if (st == LOC_EMPTY) return WALK_GOES_ON;    // still crossing empty nodes: next pass
-    if (st == LOC_OUTSIDE) return WALK_DONE;
+    if (st == LOC_OUTSIDE) return (TRX && clear_exit) ? WALK_DONE_CLEAR : WALK_DONE;
     if (COUNT) {
         const unsigned long long m = __ballot(1);
         if (__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&P.counters->sched[7], (unsigned long long)__popcll(m));
