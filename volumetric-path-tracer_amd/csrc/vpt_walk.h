@@ -303,7 +303,22 @@ VPT_D int walk_step(const TraceParams& P, const uint32_t* s_occ, const WalkConst
                 const f3 o = w.pos - ld3(P.sph_center);
                 const float qa = dot(w.dir, w.dir), qb = 2.0f * dot(w.dir, o), oo = dot(o, o);
                 const float disc = qb * qb - 4.0f * qa * (oo - P.sph_radius * P.sph_radius);
-                if (disc < -1e-3f * (qb * qb + 4.0f * qa * oo)) { st = LOC_OUTSIDE; clear_exit = true; }
+                if (disc < -1e-3f * (qb * qb + 4.0f * qa * oo)) {
+                    // ... and sphere::intersect's OTHER way of answering: `B == 0` is a hit at distance 0 whatever the discriminant (find_discr, geometry.h:52-57).  B =
+                    // 2 dir . (pos - centre) grows by 2 A per unit of path, so it can round to zero only next to the point of closest approach to the centre.  The
+                    // position get_closest_object would start from lies where the ray leaves the root box, at most 0.1 (the pushes' minimum) + rounding beyond it: the
+                    // rule cannot fire there when B is already positive by a margin here (closest approach behind), or still negative by a margin one unit past the
+                    // root's far side (closest approach well ahead).  Anything in between pushes on.
+                    const float bs = 2.0f * (fabsf(w.dir.x * o.x) + fabsf(w.dir.y * o.y) + fabsf(w.dir.z * o.z));
+                    bool b_clear = qb > 1e-3f * bs;
+                    if (!b_clear) {
+                        float t_in, t_out;
+                        box_intersect(K.root_lo, K.root_hi, w.pos, w.inv, t_in, t_out);
+                        const float reach = 2.0f * qa * (t_out + 1.0f);
+                        b_clear = qb + reach < -1e-3f * (bs + reach);
+                    }
+                    if (b_clear) { st = LOC_OUTSIDE; clear_exit = true; }
+                }
             }
 #endif
             if (st == LOC_EMPTY) {
