@@ -133,6 +133,13 @@ struct DCamera {           // vpt_camera, same field order
 
 // words of vpt_ctx::d_work_counter: [0] the tracer's dequeue cursor, [4] second queue's tail, [8] raygen's queue tail, [32 + 32 c] claim counter c (128 bytes apart)
 #define VPT_WORK_COUNTER_WORDS (32 + 32 * 32)
+// QUEUE-ORDERED compact ray records (round 6; 0 = rounds 5's slot-indexed ones, the A/B switch): a compact record stands where its sample stands in its raygen block's
+// queue -- block b owns records [b x 64 x ROWS, ...) of `rays32`, in enqueue order -- and holds {position reached | (t_hit, depth, t_box), packed word} + {direction, slot}:
+// the tracer re-generates the Philox block from the counter in the word (one block per refilled lane) instead of reading it, reads no head, and the records of a refill
+// are one contiguous run instead of three scattered 16-byte loads per ray.  The queue entry is the record's place.  Config 2 tracer -6 %, config 3 -3.6 %, config 4 -1.6 %.
+#ifndef VPT_QREC
+#define VPT_QREC 1
+#endif
 struct Counters {
     unsigned long long samples;
     unsigned long long density_lookups;
@@ -208,7 +215,7 @@ struct TraceParams {
     // reads 48 instead of 64.  The compact records live in their OWN dense array (`rays32`, 32-byte stride): written into the first half of the 64-byte record slots
     // they cost raygen +10-17 % (half-filled lines: profiles/r05_compact_rays.txt); records[] keeps the 64-byte path records of the paths the dome cannot serve.
     int compact_rays;
-    float4* rays32;                  // [iter_count][n_pixels][2]
+    float4* rays32;                  // VPT_QREC: [raygen block][place in the block's queue][2] over the image padded to 64 x 64 tiles; else [iter_count][n_pixels][2]
     uint32_t* work_counter;          // [0] next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h); [32 + 32 c]: the interleaved claim counters (VPT_CLAIM_COUNTERS)
     uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
     uint32_t* queue_tail;            // raygen's append cursor

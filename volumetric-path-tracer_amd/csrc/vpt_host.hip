@@ -1429,11 +1429,13 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     // compact 32-byte ray records (vpt_device.h): the origin must be the camera's for every sample (closed lens) and the direction in a head
     P.compact_rays = (compact && cam->lens_radius == 0.0f && !ctx->no_compact_rays && !ctx->use_pool) ? 1 : 0;
     if (P.compact_rays) {
-        if (ctx->rays32_capacity < ctx->records_capacity) {
+        // (sized over the image padded to raygen's 64 x 64 tiles: with queue-ordered records -- VPT_QREC -- every raygen block writes into its own run of 64 x ROWS records)
+        const size_t rays_need = std::max<size_t>(ctx->records_capacity, (ctx->records_capacity / per_iter) * (size_t)((W + 63u) / 64u * 64u) * (size_t)((H + 63u) / 64u * 64u));
+        if (ctx->rays32_capacity < rays_need) {
             { const int rq = quiesce_all(ctx, stream); if (rq != VPT_OK) return rq; }
             (void)hipFree(ctx->d_rays32); ctx->d_rays32 = nullptr; ctx->rays32_capacity = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->d_rays32, ctx->records_capacity * 2u * sizeof(float4)));
-            ctx->rays32_capacity = ctx->records_capacity;
+            HIPCHK(ctx, hipMalloc(&ctx->d_rays32, rays_need * 2u * sizeof(float4)));
+            ctx->rays32_capacity = rays_need;
         }
         P.rays32 = ctx->d_rays32;
     }

@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
         const int x = sq_x + (squares ? (sq & 7) * 8 : 0), y = sq_y + (squares ? (sq >> 3) * 8 : sq);
         bool enqueue = false;
         uint32_t s = 0;
+#if VPT_QREC
+        bool store_q = false;
+        float4 qrec0 = make_float4(0, 0, 0, 0), qrec1 = qrec0;
+#endif
         bool live = x < (int)P.width && y < (int)P.height;
         if (live && ((never_bits >> pass) & 1u)) {
             // no ray of this pixel can start a walk and the tail has its samples' values (ResolveParams::never_traced): nothing to emit
@@ -324,14 +328,24 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
             } else if (P.heads) {
                 // compact stream: a sample that starts no walk is fully described by its 16-byte head {dir0, depth} --
                 // plus its origin when the lens is open (lens_radius == 0: org0 is the camera origin for every sample)
+                // (with queue-ordered records the tracer no longer reads a traced sample's direction from its head -- but the head's w = -1 still tells sky_fix_kernel's
+                // pass over the pixels without a patch, and the non-resolving tails, that the sample is the tracer's: it stays)
                 st_stream(P.heads + s, make_float4(dir0.x, dir0.y, dir0.z, traced ? -1.0f : (rendered ? depth : -2.0f)));
                 if (P.head_org && !traced) st_stream(P.head_org + s, make_float4(org0.x, org0.y, org0.z, 0.0f));
                 if (traced && P.compact_rays) {
                     // 32 bytes (TraceParams::compact_rays): the origin is the camera's, the direction is in the head, the counter follows from the iteration
                     const uint32_t word = ((uint32_t)obj | adv) | (rng.idx << 14) | ((rng.c0 - iteration * 1024u) << 17);
+#if VPT_QREC
+                    // QUEUE-ORDERED records (round 6, vpt_device.h VPT_QREC): the record goes where the sample stands in its block's queue (below, once that place is known) and carries
+                    // {direction, slot} instead of the Philox block -- the tracer re-generates the block from the counter, reads no head, and a refill's records are one contiguous run
+                    qrec0 = make_float4(r0.w, r3.z, r3.w, __uint_as_float(word));
+                    qrec1 = make_float4(dir0.x, dir0.y, dir0.z, __uint_as_float(s));
+                    store_q = true;
+#else
                     float4* d32 = P.rays32 + 2u * (size_t)s;
                     st_stream(d32, make_float4(r0.w, r3.z, r3.w, __uint_as_float(word)));
                     st_stream(d32 + 1, r2);
+#endif
                 } else if (traced) { st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3); }
             } else {
                 st_stream(dst, r0); st_stream(dst + 1, r1); st_stream(dst + 2, r2); st_stream(dst + 3, r3);
@@ -343,7 +357,22 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));      // LDS atomic
             base = __shfl(base, leader);
+#if VPT_QREC
+            if (enqueue) {
+                const uint32_t lidx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (store_q) {
+                    const uint32_t qpos = blockIdx.x * (64u * (uint32_t)VPT_RAYGEN_ROWS) + lidx;      // this block's own run of the (padded) record array
+                    float4* d32 = P.rays32 + 2u * (size_t)qpos;
+                    st_stream(d32, qrec0);
+                    st_stream(d32 + 1, qrec1);
+                    s_q[lidx] = qpos;
+                } else {
+                    s_q[lidx] = s;
+                }
+            }
+#else
             if (enqueue) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = s;
+#endif
         }
     }
     __syncthreads();
@@ -481,27 +510,27 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 const uint32_t e0 = __shfl(qi0, src_lane), e1 = __shfl(qi1, src_lane), e2 = __shfl(qi2, src_lane), e3 = __shfl(qi3, src_lane);
 #ifdef VPT_PROFILE_SECTIONS
                 float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+                uint32_t pk_ = 0, pp_ = 0;
 #endif
                 if (phase == PH_IDLE) {
                     if (rank < take) {
                         const uint32_t word = rel >> 6;
-                        const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
+                        const uint32_t entry = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
                         uint32_t new_kiter, new_pixel;
-                        split_slot(P, slot, new_kiter, new_pixel);
 #ifdef VPT_PROFILE_SECTIONS
                         // (study builds: the wave waits for its records HERE, outside the divergent block, and times the wait apart from the unpacking)
-                        load_ray_record(P, slot, P.iter_begin + new_kiter * P.iter_stride, q0, q1, q2, q3);
+                        load_ray_record(P, entry, new_kiter, new_pixel, q0, q1, q2, q3);
+                        pk_ = new_kiter; pp_ = new_pixel;
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 VPT_TICK(tr2);
                 if (phase == PH_IDLE) {
                     if (rank < take) {
-                        uint32_t new_kiter, new_pixel;
-                        split_slot(P, rel >> 6 == 0u ? e0 : (rel >> 6 == 1u ? e1 : (rel >> 6 == 2u ? e2 : e3)), new_kiter, new_pixel);
+                        const uint32_t new_kiter = pk_, new_pixel = pp_;
 #else
                         float4 q0, q1, q2, q3;
-                        load_ray_record(P, slot, P.iter_begin + new_kiter * P.iter_stride, q0, q1, q2, q3);
+                        load_ray_record(P, entry, new_kiter, new_pixel, q0, q1, q2, q3);
 #endif
                         kiter = new_kiter;
                         pixel = new_pixel;

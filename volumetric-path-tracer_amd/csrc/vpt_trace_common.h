@@ -163,19 +163,40 @@ VPT_D ColdConst load_cold_const() {
 // -- loaded as such, or REBUILT from a compact 32-byte record + the sample's head + the camera origin (TraceParams::compact_rays): the same values, so
 // everything behind this function is one code path.  Launch constants come through the laundered kernel-argument pointer (scalar loads at the refill,
 // nothing carried through the loop).
-VPT_D void load_ray_record(const TraceParams& P, uint32_t slot, uint32_t iteration, float4& q0, float4& q1, float4& q2, float4& q3) {
+VPT_D void split_slot(const TraceParams& P, uint32_t slot, uint32_t& kiter, uint32_t& pixel);
+// `entry` is the queue entry: the sample's slot (kiter * n_pixels + pixel) -- or, with queue-ordered compact records (VPT_QREC), the record's own place, the slot then
+// travels in the record.  Returns the sample's kiter / pixel with the record.
+VPT_D void load_ray_record(const TraceParams& P, uint32_t entry, uint32_t& kiter, uint32_t& pixel, float4& q0, float4& q1, float4& q2, float4& q3) {
     KargPtr k = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     if (k->compact_rays) {
-        const float4* src = k->rays32 + 2u * (size_t)slot;
-        const float4 c0 = ld_stream(src), c1 = ld_stream(src + 1), h = ld_stream(k->heads + slot);
+#if VPT_QREC
+        const float4* src = k->rays32 + 2u * (size_t)entry;
+        const float4 c0 = ld_stream(src), c1 = ld_stream(src + 1);
+        split_slot(P, __float_as_uint(c1.w), kiter, pixel);
+        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+        const uint32_t word = __float_as_uint(c0.w);
+        const uint32_t counter = iteration * 1024u + (word >> 17);
+        uint32_t b0, b1, b2, b3;
+        philox_block(counter, pixel, b0, b1, b2, b3);                        // (the block raygen stood in when get_ray's draws were done: re-generated, not carried)
+        q0 = make_float4(k->cam.origin[0] + 0.0f, k->cam.origin[1] + 0.0f, k->cam.origin[2] + 0.0f, c0.x);
+        q1 = make_float4(c1.x, c1.y, c1.z, __uint_as_float(word & 0x3fffu));
+        q2 = make_float4(__uint_as_float(b0), __uint_as_float(b1), __uint_as_float(b2), __uint_as_float(b3));
+        q3 = make_float4(__uint_as_float(counter), __uint_as_float((word >> 14) & 7u), c0.y, c0.z);
+#else
+        split_slot(P, entry, kiter, pixel);
+        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+        const float4* src = k->rays32 + 2u * (size_t)entry;
+        const float4 c0 = ld_stream(src), c1 = ld_stream(src + 1), h = ld_stream(k->heads + entry);
         const uint32_t word = __float_as_uint(c0.w);
         q0 = make_float4(k->cam.origin[0] + 0.0f, k->cam.origin[1] + 0.0f, k->cam.origin[2] + 0.0f, c0.x);      // (raygen's `origin + offset` with the closed lens' offset of +0)
         q1 = make_float4(h.x, h.y, h.z, __uint_as_float(word & 0x3fffu));
         q2 = c1;
         q3 = make_float4(__uint_as_float(iteration * 1024u + (word >> 17)), __uint_as_float((word >> 14) & 7u), c0.y, c0.z);
+#endif
     } else {
-        const float4* src = reinterpret_cast<const float4*>(k->records + slot);
+        split_slot(P, entry, kiter, pixel);
+        const float4* src = reinterpret_cast<const float4*>(k->records + entry);
         q0 = ld_stream(src); q1 = ld_stream(src + 1); q2 = ld_stream(src + 2); q3 = ld_stream(src + 3);
     }
 }

@@ -278,11 +278,10 @@ __global__ __launch_bounds__(256, SKYLUT ? VPT_VOL_SKY_WAVES_PER_EU : VPT_VOL_WA
                 if (phase == VH_IDLE) {
                     if (rank < avail) {
                         const uint32_t word = rel >> 6;
-                        const uint32_t slot = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
-                        split_slot(P, slot, kiter, pixel);
-                        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
+                        const uint32_t entry = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
                         float4 q0, q1, q2, q3;
-                        load_ray_record(P, slot, iteration, q0, q1, q2, q3);
+                        load_ray_record(P, entry, kiter, pixel, q0, q1, q2, q3);
+                        const uint32_t iteration = P.iter_begin + kiter * P.iter_stride;
                         const f3 o0 = mk3(q0.x, q0.y, q0.z), d0 = mk3(q1.x, q1.y, q1.z);
                         org0 = o0;
                         dir0 = d0;
