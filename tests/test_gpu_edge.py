@@ -547,6 +547,49 @@ def test_compact_ray_records_change_nothing(pkg, monkeypatch, kind):
                 assert getattr(sa, c) == getattr(sb, c), c
 
 
+@pytest.mark.parametrize("kind", ["dragon sun+sky", "dragon sun only", "fireball sun+sky", "instances closed lens"])
+def test_queue_of_pieces_changes_nothing(pkg, monkeypatch, kind):
+    """With the compact records in queue order the direct tracer's queue holds PIECES -- {first record, count} of consecutive records, cut by raygen into sizes that shrink
+    towards the end of the launch -- instead of one entry per ray (csrc/vpt_device.h: TraceParams::piece_max; a claim is one piece).  Which wave traces which ray is all
+    that moves.  Against VPT_PIECE_MAX=0 (a queue of entries) and against other piece sizes: every buffer and every count identical, counting and timed builds, chunked
+    batches, frames, a launch of many iterations (pieces of several sizes)."""
+    if kind == "instances closed lens":
+        sd = pkg.scene.instanced_scene(256, 144, n=32, grid=3, aperture=0.0, sky=True)
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+    else:
+        sd = _frame_scene(pkg, kind)
+
+    def run(counting, batch_iters):
+        if batch_iters:
+            monkeypatch.setenv("VPT_BATCH_ITERS", str(batch_iters))
+        else:
+            monkeypatch.delenv("VPT_BATCH_ITERS", raising=False)
+        hb = pkg.scene.HipBinding(sd, device=0)
+        hb.ctx.set_counting(counting)
+        hb.render(7 if batch_iters else 40)
+        hb.render_frame()
+        hb.render(2)
+        hb.sync()
+        st = hb.ctx.stats()
+        out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+        hb.ctx.close()
+        return out, st
+    cases = [(True, 3), (False, 3), (False, 0)]
+    res = {c: run(*c) for c in cases}
+    assert res[cases[0]][1].queued_rays > 0
+    for sw, val in (("VPT_PIECE_MAX", "0"), ("VPT_PIECE_MAX", "64"), ("VPT_PIECE_DIV", "1")):
+        monkeypatch.setenv(sw, val)
+        for c in cases:
+            a, sa = res[c]
+            b, sb = run(*c)
+            assert np.isfinite(a["accum"]).all() and a["accum"].max() > 0
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg="%s=%s: %s %s" % (sw, val, k, c))
+            for cn in ("samples", "queued_rays") + (("density_lookups", "color_lookups", "emission_lookups", "tracking_steps", "skip_steps") if c[0] else ()):
+                assert getattr(sa, cn) == getattr(sb, cn), (sw, val, cn)
+        monkeypatch.delenv(sw)
+
+
 @pytest.mark.parametrize("kind", ["instances open lens", "dragon open lens", "dragon open lens, sphere in view", "dragon open lens, render off at 3"])
 def test_resolved_samples_behind_an_open_lens_change_nothing(pkg, monkeypatch, kind):
     """RESOLVED SAMPLES behind an OPEN lens (round 5): every sample starts somewhere on the lens disc, and the dome that serves its environment term is the one of

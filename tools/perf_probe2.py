@@ -51,6 +51,7 @@ if sum(op[8:12]):
     if sum(co[0:4]):
         print("  refill split (of all cycles): idle test %.1f%%, claim (atomic + queue entries, waited for) %.1f%%, wait for the records %.1f%%, unpack %.1f%% | refills %d with %.1f lanes each, %d claims; cycles per refill: wait %.0f unpack %.0f, per claim %.0f"
               % (100.0 * co[0] / tot, 100.0 * co[1] / tot, 100.0 * co[2] / tot, 100.0 * co[3] / tot, co[4], co[5] / max(1, co[4]), co[6], co[2] / max(1, co[4]), co[3] / max(1, co[4]), co[1] / max(1, co[6])))
+        print("  (idle test: with what the last pass left in flight; of a claim, its atomic alone: %.0f cycles)" % (co[7] / max(1, co[6])))
 hb.ctx.set_counting(True)
 hb.render(a.count_spp, iteration=0); hb.sync()
 print("(schedule figures: a counted render of %d iterations)" % a.count_spp)

@@ -125,6 +125,9 @@ struct vpt_ctx {
     size_t td_capacity = 0;
     uint32_t* d_queue2 = nullptr;          // record slots for sky_fix_kernel (TraceParams::queue2), same capacity, allocated with d_td
     uint32_t* d_nopatch = nullptr;         // [0]: count, [1..]: pixels without a usable sky patch (ResolveParams::nopatch_list), with d_sky_patch
+    uint32_t piece_max = 512;              // VPT_PIECE_MAX: records per piece of the tracer's queue at most (vpt_device.h: queue of pieces); 0: a queue of entries
+    bool last_queue_pieces = false;        // the last launch's queue held pieces (get_stats: where its ray count stands)
+    uint32_t piece_waves_div = 32;         // VPT_PIECE_DIV: a piece is at most (samples left in the launch) / (waves of the tracer x this)
     bool no_compact_rays = false;          // VPT_NO_COMPACT_RAYS: 64-byte ray records behind a closed lens too (tests: same bits either way)
     bool no_lens_lean = false;             // VPT_NO_LENS_LEAN: behind an open lens the samples keep their records and the tail adds the environment (tests, A/B)
     bool no_lean_tail = false;             // VPT_NO_LEAN_TAIL: finished paths keep their 64-byte records and the tail adds the environment (A/B, tests)

@@ -53,6 +53,8 @@ VPT_D uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(
 VPT_D void st_stream(float4* p, float4 v) { vpt_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<vpt_v4f*>(p)); }
 VPT_D void st_stream(float2* p, float2 v) { vpt_v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<vpt_v2f*>(p)); }
 VPT_D void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+VPT_D uint2 ld_stream(const uint2* p) { const float2 v = ld_stream(reinterpret_cast<const float2*>(p)); return make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); }
+VPT_D void st_stream(uint2* p, uint2 v) { st_stream(reinterpret_cast<float2*>(p), make_float2(__uint_as_float(v.x), __uint_as_float(v.y))); }
 #else
 VPT_D float4 ld_stream(const float4* p) { return *p; }
 VPT_D float2 ld_stream(const float2* p) { return *p; }
@@ -60,6 +62,8 @@ VPT_D uint32_t ld_stream(const uint32_t* p) { return *p; }
 VPT_D void st_stream(float4* p, float4 v) { *p = v; }
 VPT_D void st_stream(float2* p, float2 v) { *p = v; }
 VPT_D void st_stream(uint32_t* p, uint32_t v) { *p = v; }
+VPT_D uint2 ld_stream(const uint2* p) { return *p; }
+VPT_D void st_stream(uint2* p, uint2 v) { *p = v; }
 #endif
 
 struct DVolume {
@@ -206,6 +210,11 @@ struct TraceParams {
     uint32_t regen_min;              // refill when at least this many lanes of a wave are idle
     uint32_t trans_min;              // run the transition states when at least this many lanes wait for them
     uint32_t chunk;                  // queue entries a wave claims per global atomic: VPT_CHUNK, half of it for launches of a few iterations
+    // QUEUE OF PIECES (round 6; with queue-ordered records, piece_max != 0): the queue holds {first record, count} pairs instead of one word per ray -- the records of a raygen
+    // block are consecutive, so a run of them needs no list.  A claim is then ONE piece: no dependent load of 256 entries, no entries kept in registers, and its size is free:
+    // a block cuts its run into even pieces of at most clamp(samples of this and the later blocks / piece_div, piece_min, piece_max) records -- large pieces while the
+    // launch has plenty of work left, small ones towards its end (raygen's blocks append in launch order), so that the last pieces finish together.  `chunk` is 1 then.
+    uint32_t piece_min, piece_max, piece_div;
     uint32_t raygen_small_iters;     // launches of fewer iterations run raygen over 16-row tiles (four times the blocks)
     uint32_t raygen_squares;         // a raygen wave covers an 8 x 8 pixel square (a never-traced mask exists: live or skipped as a whole) or 64 pixels of a row (no mask: 1 KB store runs)
     // COMPACT RAY RECORDS (round 5; closed lens + heads): a queued ray's record is 32 bytes instead of 64 -- {a.x, a.y, a.z, word} + the Philox block, where
@@ -217,8 +226,8 @@ struct TraceParams {
     int compact_rays;
     float4* rays32;                  // VPT_QREC: [raygen block][place in the block's queue][2] over the image padded to 64 x 64 tiles; else [iter_count][n_pixels][2]
     uint32_t* work_counter;          // [0] next queue entry the tracer hands out (claim_chunk, vpt_trace_common.h); [32 + 32 c]: the interleaved claim counters (VPT_CLAIM_COUNTERS)
-    uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted)
-    uint32_t* queue_tail;            // raygen's append cursor
+    uint32_t* queue;                 // [n_pixels*iter_count] record slots of the rays to trace (compacted); piece_max != 0: [pieces][2] = {first record, count}
+    uint32_t* queue_tail;            // raygen's append cursor (entries, or pieces; then [1] counts the rays)
     const uint32_t* queue_count;     // == queue_tail, read by the tracer
     Record* records;                 // [iter_count][n_pixels]
     float4* heads;                   // [iter_count][n_pixels] 16-byte sample heads, or NULL (see ResolveParams)

@@ -217,6 +217,8 @@ int vpt_create(int device, vpt_ctx** out_ctx) {
     ctx->no_sky_dome = std::getenv("VPT_NO_SKY_DOME") != nullptr;
     ctx->no_lean_tail = std::getenv("VPT_NO_LEAN_TAIL") != nullptr;
     ctx->no_compact_rays = std::getenv("VPT_NO_COMPACT_RAYS") != nullptr;
+    if (const char* e = std::getenv("VPT_PIECE_MAX")) { const int v = std::atoi(e); if (v >= 0 && v <= 4096) ctx->piece_max = (uint32_t)v; }       // 0: a queue of entries, as before
+    if (const char* e = std::getenv("VPT_PIECE_DIV")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) ctx->piece_waves_div = (uint32_t)v; }
     ctx->no_lens_lean = std::getenv("VPT_NO_LENS_LEAN") != nullptr;
     ctx->no_fast_div = std::getenv("VPT_NO_FAST_DIV") != nullptr;
     ctx->no_leaf_cull = std::getenv("VPT_NO_LEAF_CULL") != nullptr;
@@ -778,9 +780,9 @@ int vpt_get_stats(vpt_ctx* ctx, vpt_render_stats* out) {
     }
     out->samples = ctx->last_samples;
     {
-        uint32_t wc[9] = {0};
+        uint32_t wc[10] = {0};
         HIPCHK(ctx, hipMemcpy(wc, ctx->d_work_counter, sizeof(wc), hipMemcpyDeviceToHost));
-        out->queued_rays = wc[8];
+        out->queued_rays = ctx->last_queue_pieces ? wc[9] : wc[8];       // (a queue of pieces counts its rays beside its pieces)
     }
     if (ctx->counting) {
         Counters c;
@@ -1475,6 +1477,24 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
     const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->use_pool ? 3 : (kp->integrator != 0 ? trace_vol_blocks_per_cu(kp->environment_type == 0) : trace_blocks_per_cu()));
     const int max_blocks = ctx->num_cus * blocks_per_cu;
 
+    // what a claim of the tracer is: `chunk` queue entries -- or, where the compact records stand in queue order and the direct tracer runs, one PIECE of them (vpt_device.h)
+    auto set_claim = [&](unsigned long long total) {
+        P.chunk = ctx->chunk_entries ? ctx->chunk_entries : (total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK);
+        P.piece_min = P.piece_max = 0u;
+        P.piece_div = 1u;
+#if VPT_QREC
+        if (P.compact_rays && kp->integrator == 0 && ctx->piece_max != 0u) {
+            P.piece_min = P.chunk;
+            P.piece_max = std::max(ctx->piece_max, P.chunk);
+            // pieces shrink once fewer than 32 of the current size are left per wave of the tracer, counted in SAMPLES (a quarter to all of them are rays).  Config 2, tracer per 64
+            // iterations: entries 3.12 ms; pieces of at most 256 / 384 / 512 / 768 / 1024 / 2048 records 3.08 / 3.04 / 3.02 / 3.03 / 3.08 / 3.20 ms (larger pieces spread the rays in
+            // flight over more tiles); shrinking below 8 / 32 pieces per wave 3.03 / 3.02 (profiles/r06_pieces.txt)
+            P.piece_div = (uint32_t)max_blocks * 4u * ctx->piece_waves_div;
+            P.chunk = 1u;
+        }
+#endif
+        ctx->last_queue_pieces = P.piece_max != 0u;
+    };
     // raygen's queue -> the persistent tracer of this scene (direct / vol_integrator instantiation)
     auto launch_tracer = [&](unsigned long long total, int blocks) -> int {
         // the root-only point location is for instantiations that ignore the leaf index (MULTI = false): the direct tracer
@@ -1526,7 +1546,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             const unsigned long long total = (unsigned long long)n_pixels * n;
             int blocks = (int)std::min<unsigned long long>((total + 255) / 256, (unsigned long long)max_blocks);
             if (blocks < 1) blocks = 1;
-            P.chunk = ctx->chunk_entries ? ctx->chunk_entries : (total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK);
+            set_claim(total);
             int e0, e1, e2, e3;
             if ((rc = get_events(ctx, &e0, &e1)) != 0 || (rc = get_events(ctx, &e2, &e3)) != 0) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->ev_pool[e0], stream));
@@ -1599,7 +1619,7 @@ int vpt_render_batch(vpt_ctx* ctx, const vpt_camera* cam, const vpt_light_list* 
             ev[i] = a;
             ev[i + 1] = b;
         }
-        P.chunk = ctx->chunk_entries ? ctx->chunk_entries : (total < 6000ull * 4ull * (unsigned long long)max_blocks ? (uint32_t)VPT_CHUNK / 2u : (uint32_t)VPT_CHUNK);
+        set_claim(total);
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[0]], stream));
         HIPCHK(ctx, launch_raygen(P, stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_pool[ev[1]], stream));

@@ -378,10 +378,30 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
     __syncthreads();
     const uint32_t n = s_n;
     const uint32_t tid = threadIdx.y * 64u + threadIdx.x;
+#if VPT_QREC
+    if (P.piece_max != 0u) {
+        // QUEUE OF PIECES (vpt_device.h): this block's records are [run, run + n) of rays32 -- appended as even pieces of whole waves' worth, sized by how much of the launch is left
+        if (n) {
+            const uint32_t left = (gridDim.x - blockIdx.x) * (64u * (uint32_t)VPT_RAYGEN_ROWS);
+            uint32_t size = min(max(left / P.piece_div, P.piece_min), P.piece_max);
+            uint32_t np = (n + size - 1u) / size;
+            size = ((n + np - 1u) / np + 63u) & ~63u;
+            np = (n + size - 1u) / size;
+            if (tid == 0) { s_base = atomicAdd(P.queue_tail, np); atomicAdd(P.queue_tail + 1, n); }       // (+ 1: the rays, for vpt_render_stats::queued_rays)
+            __syncthreads();
+            if (tid < np) {
+                const uint32_t first = tid * size;
+                st_stream(reinterpret_cast<uint2*>(P.queue) + s_base + tid, make_uint2(blockIdx.x * (64u * (uint32_t)VPT_RAYGEN_ROWS) + first, min(size, n - first)));
+            }
+        }
+    } else
+#endif
+    {
     if (tid == 0 && n) s_base = atomicAdd(P.queue_tail, n);
     __syncthreads();
     const uint32_t gbase = s_base;
     for (uint32_t i = tid; i < n; i += 256u) st_stream(P.queue + gbase + i, s_q[i]);
+    }
     if (COUNT && n_final) atomicAdd(&P.counters->samples, (unsigned long long)n_final);
     if (COUNT && n_empty_skips) atomicAdd(&P.counters->skip_steps, (unsigned long long)n_empty_skips);
 }
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
 #endif
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;       // transitions, split (PROF builds)
     unsigned long long tskip = 0;                                         // skip loop inside the walk step (PROF builds)
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, nr0 = 0, nr1 = 0, nr2 = 0;   // refill, split: idle test, claim, record wait, unpack; refills, lanes refilled, claims
+    unsigned long long tr0 = 0, tr1 = 0, tr1a = 0, tr2 = 0, tr3 = 0, nr0 = 0, nr1 = 0, nr2 = 0;   // refill, split: idle test, claim, record wait, unpack; refills, lanes refilled, claims
     unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
 #define VPT_TICK(acc) do { if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tstamp; tstamp = now_; } } while (0)
     for (;;) {
@@ -472,17 +492,28 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
         if (idle != 0ull) {
             const unsigned long long active = __ballot(1);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }       // (study builds: what the last pass left in flight is charged to the idle test, not to the claim)
             VPT_TICK(tr0);
             if (chunk_next == chunk_end && more && (n_idle >= regen_min || idle == active)) {
                 if (PROF) nr2++;
                 claim_chunk<MULTI ? 1 : VPT_CLAIM_COUNTERS>(P, total, lane, __ffsll((long long)active) - 1, chunk_next, chunk_end, more);
+                if (PROF) { const unsigned long long now_ = __builtin_readcyclecounter(); tr1a += now_ - tstamp; }       // the atomic alone (tr1 keeps the whole claim)
                 // the chunk's queue entries are fetched once, here (4 per lane), so that a refill pays one
                 // memory latency (the ray record) instead of two dependent ones
+                if (P.piece_max != 0u) {
+                    // a queue of PIECES (vpt_device.h): the claim is a piece's number, the piece a run of consecutive records
+                    if (chunk_next != chunk_end) {
+                        const uint2 pc = ld_stream(reinterpret_cast<const uint2*>(P.queue) + chunk_next);
+                        chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.x);
+                        chunk_end = chunk_next + (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.y);
+                    }
+                } else {
                 chunk_base = chunk_next;
                 qi0 = chunk_base + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + (uint32_t)lane) : 0u;
                 qi1 = chunk_base + 64u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 64u + (uint32_t)lane) : 0u;
                 qi2 = chunk_base + 128u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 128u + (uint32_t)lane) : 0u;
                 qi3 = chunk_base + 192u + (uint32_t)lane < chunk_end ? ld_stream(P.queue + chunk_base + 192u + (uint32_t)lane) : 0u;
+                }
             }
             if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }       // (study builds: charge the claim's latencies to the claim)
             VPT_TICK(tr1);
@@ -490,7 +521,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
             if (avail == 0u && !more && idle == active) {
                 if (PROF && lane == 0) {
                     atomicAdd(&P.prof->coh[0], tr0); atomicAdd(&P.prof->coh[1], tr1); atomicAdd(&P.prof->coh[2], tr2); atomicAdd(&P.prof->coh[3], tr3);
-                    atomicAdd(&P.prof->coh[4], nr0); atomicAdd(&P.prof->coh[5], nr1); atomicAdd(&P.prof->coh[6], nr2);
+                    atomicAdd(&P.prof->coh[4], nr0); atomicAdd(&P.prof->coh[5], nr1); atomicAdd(&P.prof->coh[6], nr2); atomicAdd(&P.prof->coh[7], tr1a);
                     atomicAdd(&P.prof->cycles[0], tc0 + tr0 + tr1 + tr2 + tr3); atomicAdd(&P.prof->cycles[1], tc1);
                     atomicAdd(&P.prof->cycles[2], tc2); atomicAdd(&P.prof->cycles[3], tc3 + ts0 + ts1 + ts2 + ts3 + ts4);
                     atomicAdd(&P.prof->sched[0], ts0); atomicAdd(&P.prof->sched[1], ts1); atomicAdd(&P.prof->sched[2], ts2);
@@ -505,9 +536,11 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 chunk_next += take;
                 // entry e of the chunk sits in word (e >> 6) of lane (e & 63); all lanes take part in the exchange
                 const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const bool pieces = P.piece_max != 0u;
                 const uint32_t rel = first + rank - chunk_base;
                 const int src_lane = (int)(rel & 63u);
-                const uint32_t e0 = __shfl(qi0, src_lane), e1 = __shfl(qi1, src_lane), e2 = __shfl(qi2, src_lane), e3 = __shfl(qi3, src_lane);
+                uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                if (!pieces) { e0 = __shfl(qi0, src_lane); e1 = __shfl(qi1, src_lane); e2 = __shfl(qi2, src_lane); e3 = __shfl(qi3, src_lane); }
 #ifdef VPT_PROFILE_SECTIONS
                 float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
                 uint32_t pk_ = 0, pp_ = 0;
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(256, VPT_TRACE_WAVES_PER_EU) void trace_kernel(cons
                 if (phase == PH_IDLE) {
                     if (rank < take) {
                         const uint32_t word = rel >> 6;
-                        const uint32_t entry = word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3));
+                        const uint32_t entry = pieces ? first + rank : (word == 0u ? e0 : (word == 1u ? e1 : (word == 2u ? e2 : e3)));
                         uint32_t new_kiter, new_pixel;
 #ifdef VPT_PROFILE_SECTIONS
                         // (study builds: the wave waits for its records HERE, outside the divergent block, and times the wait apart from the unpacking)
