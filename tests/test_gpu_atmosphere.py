@@ -445,6 +445,62 @@ def test_never_traced_pixels_change_nothing(pkg, sky, monkeypatch, view):
     assert sa.samples == w * h * 4
 
 
+@pytest.mark.parametrize("scene", ["dragon", "fireball", "instances"])
+def test_never_traced_masks_on_random_views(pkg, sky, monkeypatch, scene):
+    """The two tests around this one compare hand-picked views; this one sweeps SEEDED RANDOM cameras -- near and far, from below the horizon to the zenith, narrow and
+    wide fields of view, looking at the volume or past it, with and without the reference sphere in view, odd image extents -- over three scenes (one grid with empty
+    octree nodes, one without, an instanced one).  For every view: the timed render with both masks (root-box bounds + leaf tiles) against VPT_NO_PIXEL_CULL=1 (raygen
+    emits every sample), every buffer bit-identical and the same rays queued.  The masks hold "by test": this is the widest net the suite casts."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    lib = pkg.load_library()
+    lib.vpt_test_count_never_traced.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    rs = np.random.RandomState({"dragon": 11, "fireball": 12, "instances": 13}[scene])
+    skipped_views = traced_views = 0
+    for view in range(10):
+        w, h = int(rs.choice([320, 333, 256])), int(rs.choice([180, 187, 144]))
+        if scene == "dragon":
+            sd = pkg.scene.dragon_scene(w, h, "c2")
+        elif scene == "fireball":
+            sd = pkg.scene.fireball_scene(w, h, n=48, sky=True)
+        else:
+            sd = pkg.scene.instanced_scene(w, h, n=32, grid=3, aperture=0.0, sky=True)
+        o = sd.camera.origin
+        dist = float(np.sqrt(o.x * o.x + o.y * o.y + o.z * o.z)) * float(rs.uniform(0.35, 2.5))
+        az, el = float(rs.uniform(0.0, 2.0 * np.pi)), float(rs.uniform(-0.15, 1.45))
+        eye = (dist * np.cos(el) * np.cos(az), dist * np.sin(el) + float(rs.uniform(0.0, 2.0)), dist * np.cos(el) * np.sin(az))
+        look = tuple(float(v) for v in rs.uniform(-1.0, 1.0, 3) * (dist * 0.3 if view % 3 == 2 else 1.0))       # every third view looks well past the volume
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(*eye), Float3(*look), Float3(0, 1, 0), float(rs.uniform(18.0, 85.0)), w / h, 0.0)
+        if view % 4 == 1:                                  # the reference sphere somewhere between the camera and the volume
+            t = float(rs.uniform(0.3, 0.7))
+            sd.sphere.center = Float3(eye[0] * t + float(rs.uniform(-1, 1)), eye[1] * t + float(rs.uniform(-1, 1)), eye[2] * t + float(rs.uniform(-1, 1)))
+            sd.sphere.radius = float(rs.uniform(0.3, 1.5))
+        pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+
+        def run():
+            hb = pkg.scene.HipBinding(sd, device=0)
+            hb.render(3); hb.sync()
+            n = C.c_ulonglong(0)
+            assert lib.vpt_test_count_never_traced(hb.ctx.h, C.byref(n)) == 0
+            out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "depth", "raw", "display")}
+            st = hb.ctx.stats()
+            hb.ctx.close()
+            return out, st, n.value
+        a, sa, na = run()
+        monkeypatch.setenv("VPT_NO_PIXEL_CULL", "1")
+        b, sb, nb = run()
+        monkeypatch.delenv("VPT_NO_PIXEL_CULL")
+        assert nb == 0
+        for buf in a:
+            np.testing.assert_array_equal(a[buf], b[buf], err_msg="%s view %d: %s" % (scene, view, buf))
+        assert sa.queued_rays == sb.queued_rays, (scene, view)
+        assert np.isfinite(a["accum"]).all()
+        skipped_views += na > 0
+        traced_views += sa.queued_rays > 0
+        print("%s view %d (%d x %d): %d of %d pixels never traced, %d rays queued" % (scene, view, w, h, na, w * h, sa.queued_rays))
+    assert skipped_views >= 5 and traced_views >= 5, (skipped_views, traced_views)            # the sweep really exercises the masks, on views that see the volume
+
+
 @pytest.mark.parametrize("view", ["default", "1080p", "horizon in view", "sphere in view", "inside the box"])
 def test_leaf_level_never_traced_tiles_change_nothing(pkg, sky, monkeypatch, view):
     """The never-traced mask refined per 8x8-pixel tile by the screen bounds of the NON-EMPTY octree leaves (ResolveParams::cull_tiles): a ray that only
