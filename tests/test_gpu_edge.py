@@ -220,6 +220,70 @@ def test_convex_exit_changes_nothing(pkg, scene):
     assert sa.queued_rays == sb.queued_rays
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_convex_exit_on_random_views(pkg, seed):
+    """test_convex_exit_changes_nothing on SEEDED RANDOM set-ups instead of hand-picked ones: camera anywhere around (and sometimes inside) the dragon's box, the
+    reference sphere anywhere from touching the box to far away -- and small enough, half of the time, that exits graze it: the robust "clears the sphere" test and the
+    `B == 0` rule decide --, the sun anywhere above the horizon, ray_depth 1-4, volume_depth 1-3, thin and dense media, the volume rotated about y in a third of the cases.
+    Timed (exits taken) against counting (every push walked, as the reference does): every buffer bit-identical, the same rays queued."""
+    import ctypes as C
+    from vpt_amd.abi import Float3
+    lib = pkg.load_library()
+    rs = np.random.RandomState(100 + seed)
+    exits_possible = 0
+    for case in range(8):
+        w, h = int(rs.choice([192, 160, 131])), int(rs.choice([108, 90, 77]))
+        sd = pkg.scene.dragon_scene(w, h, "c1" if case % 4 == 3 else "sun")
+        if case % 4 == 3:
+            sd.kp.sun_mult = 1.0                            # point lights AND the sun: twelve Tr walks per scatter
+        vdb = sd.volumes[0][0]
+        if case % 3 == 1:
+            ang = float(rs.uniform(-1.2, 1.2))
+            rot = np.array([[np.cos(ang), 0, np.sin(ang), 0], [0, 1, 0, 0], [-np.sin(ang), 0, np.cos(ang), 0], [0, 0, 0, 1]], np.float32)
+            m = np.array([[vdb.xform[r][c] for c in range(4)] for r in range(4)], np.float32) @ rot
+            for r in range(4):
+                for c in range(4):
+                    vdb.xform[r][c] = float(m[r, c])
+        lo, hi = Float3(), Float3()
+        lib.vpt_gpu_vdb_bounds(C.byref(vdb), C.byref(lo), C.byref(hi))
+        ctr = np.array([(lo.x + hi.x) * 0.5, (lo.y + hi.y) * 0.5, (lo.z + hi.z) * 0.5])
+        half = np.array([hi.x - lo.x, hi.y - lo.y, hi.z - lo.z]) * 0.5
+        size = float(np.linalg.norm(half))
+        d = rs.normal(size=3); d /= np.linalg.norm(d); d[1] = abs(d[1]) * 0.7
+        eye = ctr + d * size * float(rs.uniform(0.2 if case == 5 else 1.3, 5.0))
+        look = ctr + rs.uniform(-0.6, 0.6, 3) * half
+        lib.vpt_camera_update(C.byref(sd.camera), Float3(*[float(v) for v in eye]), Float3(*[float(v) for v in look]), Float3(0, 1, 0), float(rs.uniform(20.0, 70.0)), w / h, 0.0)
+        sdir = rs.normal(size=3); sdir /= np.linalg.norm(sdir)
+        sd.sphere.radius = float(rs.uniform(0.15, 0.6) if case % 2 else rs.uniform(0.8, 3.0))
+        sdist = float(np.max(half)) + sd.sphere.radius * float(rs.uniform(0.8, 1.3) if case % 2 == 0 else rs.uniform(1.0, 4.0))     # from overlapping the box's edge to well away
+        sc = ctr + sdir * sdist
+        sd.sphere.center = Float3(float(sc[0]), float(sc[1]), float(sc[2]))
+        sd.kp.azimuth = float(rs.uniform(0.0, 360.0))
+        sd.kp.elevation = float(rs.uniform(2.0, 88.0))
+        sd.kp.ray_depth = int(rs.randint(1, 5))
+        sd.kp.volume_depth = int(rs.randint(1, 4))
+        sd.kp.density_mult = float(sd.kp.density_mult) * float(rs.choice([0.25, 1.0, 3.0]))
+
+        def run(counting):
+            hb = pkg.scene.HipBinding(sd, device=0)
+            hb.ctx.set_counting(counting)
+            hb.render(4)
+            hb.sync()
+            out = {b: getattr(hb, b).cpu().numpy().copy() for b in ("accum", "cost", "depth", "raw", "display", "blue_noise")}
+            st = hb.ctx.stats()
+            hb.ctx.close()
+            return out, st
+        a, sa = run(False)
+        b, sb = run(True)
+        assert np.isfinite(a["accum"]).all()
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg="seed %d case %d: %s" % (seed, case, k))
+        assert sa.queued_rays == sb.queued_rays
+        exits_possible += sb.skip_steps > 0 and sb.tracking_steps > 0
+        print("seed %d case %d: %d rays, %d steps, %d skips" % (seed, case, sb.queued_rays, sb.tracking_steps, sb.skip_steps))
+    assert exits_possible >= 6, exits_possible
+
+
 def _skip_if_stale(lib):
     """a study library left over from an earlier state of the sources (it is git-ignored and built by hand) may lack entry points the Python host binds"""
     import ctypes
