@@ -113,6 +113,38 @@ def test_image_parity_dragon(pkg, ob_mod, config, spp):
     assert st.skip_steps == ob.stats.skip_steps
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_setups_vs_oracle(pkg, ob_mod, seed):
+    """The parity tests above and in test_gpu_edge.py use hand-built scenes; this one draws them: SEEDED RANDOM camera (around and sometimes inside the dragon's box), reference
+    sphere (from overlapping the box's edge to far away, small and large; above the ground: a view point inside the planet is outside the sky model's domain), sun direction, ray_depth 1-4, volume_depth 1-3, density_mult x 0.25 / 1 / 3, phase g, the volume
+    rotated about y in a third of the cases, point lights in a quarter, the procedural sky in a quarter, odd image extents.  Timed HIP render (every shortcut on) against
+    the oracle: depth BIT-identical (a function of the walk decisions alone), accum within north_star's 1e-3 (2e-6 without the sky's value-only tables); counting render:
+    look-up / step / skip counts equal to the oracle's."""
+    from random_setups import dragon_setup
+    rs = np.random.RandomState(500 + seed)
+    for case in range(8):
+        sd, w, h, sky, desc = dragon_setup(pkg, rs, case)
+        spp = 3
+        ob = ob_mod.OracleBinding(sd)
+        ob.render(spp, nthreads=os.cpu_count() or 1)
+        for counting in (False, True):
+            hb = pkg.scene.HipBinding(sd, device=0)
+            hb.ctx.set_counting(counting)
+            hb.render(spp)
+            hb.sync()
+            got, dgot = hb.accum.cpu().numpy(), hb.depth.cpu().numpy()
+            st = hb.ctx.stats()
+            hb.ctx.close()
+            assert np.isfinite(got).all()
+            np.testing.assert_array_equal(dgot, ob.depth, err_msg="seed %d case %d (counting %s): depth" % (seed, case, counting))
+            e = rel_l2(got, ob.accum)
+            assert e <= (REL_L2_TOL if sky else REL_L2_TIGHT), (seed, case, counting, e)
+            if counting:
+                assert st.samples == ob.stats.samples == w * h * spp
+                assert (st.density_lookups, st.tracking_steps, st.skip_steps) == (ob.stats.density_lookups, ob.stats.tracking_steps, ob.stats.skip_steps), (seed, case)
+        print("seed %d case %d: %d x %d, rel L2 %.2e, %d steps, %d skips" % (seed, case, w, h, e, ob.stats.tracking_steps, ob.stats.skip_steps))
+
+
 def test_per_pixel_values_match_single_sample(pkg, ob_mod):
     """One iteration, pixel by pixel: accum after iteration 0 is the sample value itself."""
     sd, hb, ob = _pair(pkg, ob_mod, 96, 64, "c1", tweak=lambda s: setattr(s.kp, "sun_mult", 1.0))
