@@ -51,3 +51,39 @@ def dragon_setup(pkg, rs, case, sizes=((128, 113, 96), (72, 67, 54))):
     desc = "%d x %d eye %s look %s fov %.1f sun az %.1f el %.1f sphere c %s r %.2f ray_depth %d volume_depth %d" % (
         w, h, np.round(eye, 2), np.round(look, 2), fov, sd.kp.azimuth, sd.kp.elevation, np.round(sc, 2), sd.sphere.radius, sd.kp.ray_depth, sd.kp.volume_depth)
     return sd, w, h, sky, desc
+
+
+def random_view(pkg, rs, sd, w, h, aperture=0.0, inside=False, above_ground=False):
+    """A seeded random camera around (inside=True: within) the union of the scene's volume bounds, a random sun, loop depths, density and phase g; the reference sphere near
+    the volumes half of the time (above_ground: kept above y = 0, see dragon_setup).  -> description"""
+    from vpt_amd.abi import Float3
+    lib = pkg.load_library()
+    lo_u, hi_u = np.full(3, np.inf), np.full(3, -np.inf)
+    for vol in sd.volumes:
+        lo, hi = Float3(), Float3()
+        lib.vpt_gpu_vdb_bounds(C.byref(vol[0]), C.byref(lo), C.byref(hi))
+        lo_u = np.minimum(lo_u, [lo.x, lo.y, lo.z]); hi_u = np.maximum(hi_u, [hi.x, hi.y, hi.z])
+    ctr, half = (lo_u + hi_u) * 0.5, (hi_u - lo_u) * 0.5
+    size = float(np.linalg.norm(half))
+    d = rs.normal(size=3); d /= np.linalg.norm(d); d[1] = abs(d[1]) * 0.7
+    eye = ctr + d * size * float(rs.uniform(0.1, 0.5) if inside else rs.uniform(1.2, 3.5))
+    if above_ground:
+        eye[1] = max(eye[1], 1.0)
+    look = ctr + rs.uniform(-0.5, 0.5, 3) * half
+    fov = float(rs.uniform(20.0, 65.0))
+    lib.vpt_camera_update(C.byref(sd.camera), Float3(*[float(v) for v in eye]), Float3(*[float(v) for v in look]), Float3(0, 1, 0), fov, w / h, float(aperture))
+    if rs.uniform() < 0.5:
+        sdir = rs.normal(size=3); sdir /= np.linalg.norm(sdir)
+        sd.sphere.radius = float(rs.uniform(0.05, 0.3) * size)
+        sc = ctr + sdir * (float(np.max(half)) + sd.sphere.radius * float(rs.uniform(0.9, 2.5)))
+        if above_ground:
+            sc[1] = max(sc[1], sd.sphere.radius + 0.5)
+        sd.sphere.center = Float3(float(sc[0]), float(sc[1]), float(sc[2]))
+    sd.kp.azimuth = float(rs.uniform(0.0, 360.0))
+    sd.kp.elevation = float(rs.uniform(2.0, 88.0))
+    sd.kp.ray_depth = int(rs.randint(1, 4))
+    sd.kp.volume_depth = int(rs.randint(1, 4))
+    sd.kp.density_mult = float(sd.kp.density_mult) * float(rs.choice([0.5, 1.0, 2.0]))
+    sd.kp.phase_g1 = float(rs.uniform(-0.3, 0.85))
+    return "%d x %d eye %s look %s fov %.1f aperture %.2f sun az %.1f el %.1f ray_depth %d volume_depth %d" % (
+        w, h, np.round(eye, 2), np.round(look, 2), fov, aperture, sd.kp.azimuth, sd.kp.elevation, sd.kp.ray_depth, sd.kp.volume_depth)

@@ -145,6 +145,52 @@ def test_random_setups_vs_oracle(pkg, ob_mod, seed):
         print("seed %d case %d: %d x %d, rel L2 %.2e, %d steps, %d skips" % (seed, case, w, h, e, ob.stats.tracking_steps, ob.stats.skip_steps))
 
 
+@pytest.mark.parametrize("kind", ["fireball", "fireball sky", "instances", "instances open lens", "cloud vol_integrator"])
+def test_random_views_of_the_other_scenes_vs_oracle(pkg, ob_mod, kind):
+    """test_random_setups_vs_oracle for the other tracer instantiations: the emission march (fireball; sun only and with the procedural sky), instanced coloured volumes (the
+    generic walk with per-leaf instance lists and the colour look-ups; closed lens and open lens: every sample has its own origin), the vol_integrator over a cloud with an HDRI
+    (the second tracer kernel).  Four seeded random views each -- one from inside the volumes -- with random sun, loop depths, density, phase g and the sphere near the volumes
+    half of the time.  Depth bit-identical, look-up / step / skip counts equal, accum within north_star's 1e-3 (2e-6 where no value-only sky code is involved)."""
+    from random_setups import random_view
+    rs = np.random.RandomState({"fireball": 21, "fireball sky": 22, "instances": 23, "instances open lens": 24, "cloud vol_integrator": 25}[kind])
+    for view in range(4):
+        w, h = int(rs.choice([112, 96, 83])), int(rs.choice([63, 54, 47]))
+        sky = False
+        aperture = 0.0
+        if kind.startswith("fireball"):
+            sky = kind.endswith("sky")
+            sd = pkg.scene.fireball_scene(w, h, n=40, sky=sky)
+        elif kind.startswith("instances"):
+            aperture = float(rs.uniform(0.5, 3.0)) if kind.endswith("open lens") else 0.0
+            sd = pkg.scene.instanced_scene(w, h, n=24, grid=3, aperture=aperture, sky=False)
+        else:
+            sky = True
+            sd = pkg.scene.cloud_scene(w, h, shape=(40, 36, 48), env=(96, 48), integrator=1)
+        if sky:
+            pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+        desc = random_view(pkg, rs, sd, w, h, aperture=aperture, inside=view == 3, above_ground=sky)
+        spp = 2
+        ob = ob_mod.OracleBinding(sd)
+        ob.render(spp, nthreads=os.cpu_count() or 1)
+        for counting in (False, True):
+            hb = pkg.scene.HipBinding(sd, device=0)
+            hb.ctx.set_counting(counting)
+            hb.render(spp)
+            hb.sync()
+            got, dgot = hb.accum.cpu().numpy(), hb.depth.cpu().numpy()
+            st = hb.ctx.stats()
+            hb.ctx.close()
+            assert np.isfinite(got).all()
+            np.testing.assert_array_equal(dgot, ob.depth, err_msg="%s view %d (counting %s): depth | %s" % (kind, view, counting, desc))
+            e = rel_l2(got, ob.accum)
+            assert e <= (REL_L2_TOL if sky else REL_L2_TIGHT), (kind, view, counting, e, desc)
+            if counting:
+                assert st.samples == ob.stats.samples == w * h * spp
+                assert (st.density_lookups, st.color_lookups, st.emission_lookups, st.tracking_steps, st.skip_steps) == \
+                       (ob.stats.density_lookups, ob.stats.color_lookups, ob.stats.emission_lookups, ob.stats.tracking_steps, ob.stats.skip_steps), (kind, view, desc)
+        print("%s view %d: rel L2 %.2e, %d steps, %d look-ups | %s" % (kind, view, e, ob.stats.tracking_steps, ob.stats.density_lookups, desc))
+
+
 def test_per_pixel_values_match_single_sample(pkg, ob_mod):
     """One iteration, pixel by pixel: accum after iteration 0 is the sample value itself."""
     sd, hb, ob = _pair(pkg, ob_mod, 96, 64, "c1", tweak=lambda s: setattr(s.kp, "sun_mult", 1.0))
