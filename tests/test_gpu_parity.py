@@ -145,6 +145,57 @@ def test_random_setups_vs_oracle(pkg, ob_mod, seed):
         print("seed %d case %d: %d x %d, rel L2 %.2e, %d steps, %d skips" % (seed, case, w, h, e, ob.stats.tracking_steps, ob.stats.skip_steps))
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_kernel_params_vs_oracle(pkg, ob_mod, seed):
+    """The Kernel_params fields the set-ups above leave at their defaults, drawn at random on the dragon (sun or point lights + sun, both integrators): albedo / extinction
+    per channel, tr_depth, energy_inject, the sun's colour and multiplier, exposure, a first iteration other than 0 and an iteration stride (striping), max_interactions inside
+    the batch (the iterations past it are not rendered: WHITE), image extents that are not multiples of the 8 x 8 / 64 x 64 tiles.  Depth bit-identical, counts equal,
+    accum within 2e-6 (1e-3 for the vol_integrator cases: their tail is the procedural sky); the blue-noise state advances as the oracle's."""
+    from vpt_amd.abi import Float3
+    from random_setups import random_view
+    rs = np.random.RandomState(900 + seed)
+    for case in range(8):
+        w, h = int(rs.choice([101, 127, 64, 90])), int(rs.choice([59, 71, 36]))
+        sd = pkg.scene.dragon_scene(w, h, "c1" if case % 2 else "sun")
+        if case % 2:
+            sd.kp.sun_mult = float(rs.uniform(0.0, 2.0))
+        vol = case % 4 == 2
+        if vol:
+            sd.kp.integrator = 1                                    # (its tail is always the procedural sky, render_kernel.cu:1752: the tables must be bound)
+            pkg.atmosphere.attach_default_atmosphere(sd, device=0)
+        desc = random_view(pkg, rs, sd, w, h, above_ground=vol)
+        a = rs.uniform(0.2, 1.0, 3); e = rs.uniform(0.3, 1.0, 3)
+        sd.kp.albedo = Float3(float(a[0]), float(a[1]), float(a[2]))
+        sd.kp.extinction = Float3(float(e[0]), float(e[1]), float(e[2]))
+        sd.kp.tr_depth = float(rs.choice([0.5, 1.0, 2.0]))
+        sd.kp.energy_inject = float(rs.choice([0.0, 0.5, 3.0]))
+        c = rs.uniform(0.2, 1.0, 3)
+        sd.kp.sun_color = Float3(float(c[0]), float(c[1]), float(c[2]))
+        sd.kp.exposure_scale = float(rs.uniform(0.3, 3.0))
+        spp, it0, stride = int(rs.randint(2, 5)), int(rs.randint(0, 40)), int(rs.choice([1, 1, 2, 5]))
+        if case == 5:
+            sd.kp.max_interactions = it0 + stride                   # the batch's first iteration renders, the later ones are past the limit
+        ob = ob_mod.OracleBinding(sd)
+        ob.render(spp, iter_stride=stride, iteration=it0, nthreads=os.cpu_count() or 1)
+        for counting in (False, True):
+            hb = pkg.scene.HipBinding(sd, device=0)
+            hb.ctx.set_counting(counting)
+            hb.render(spp, iteration=it0, iter_stride=stride)
+            hb.sync()
+            got, dgot, bn = hb.accum.cpu().numpy(), hb.depth.cpu().numpy(), hb.blue_noise.cpu().numpy()
+            st = hb.ctx.stats()
+            hb.ctx.close()
+            assert np.isfinite(got).all()
+            np.testing.assert_array_equal(dgot, ob.depth, err_msg="seed %d case %d (counting %s): depth | %s" % (seed, case, counting, desc))
+            np.testing.assert_array_equal(bn, ob.blue_noise)
+            e2 = rel_l2(got, ob.accum)
+            assert e2 <= (REL_L2_TOL if vol else REL_L2_TIGHT), (seed, case, counting, e2, desc)
+            if counting:
+                assert st.samples == ob.stats.samples
+                assert (st.density_lookups, st.tracking_steps, st.skip_steps) == (ob.stats.density_lookups, ob.stats.tracking_steps, ob.stats.skip_steps), (seed, case, desc)
+        print("seed %d case %d: integrator %d, %d iterations from %d stride %d, rel L2 %.2e, %d steps | %s" % (seed, case, sd.kp.integrator, spp, it0, stride, e2, ob.stats.tracking_steps, desc))
+
+
 @pytest.mark.parametrize("kind", ["fireball", "fireball sky", "instances", "instances open lens", "cloud vol_integrator"])
 def test_random_views_of_the_other_scenes_vs_oracle(pkg, ob_mod, kind):
     """test_random_setups_vs_oracle for the other tracer instantiations: the emission march (fireball; sun only and with the procedural sky), instanced coloured volumes (the
