@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256, LENSRES ? VPT_RAYGEN_LENS_WAVES : VPT_RAYGEN_W
                         accepted = a1 ? 2u * j + 1u : (a2 ? 2u * j + 2u : 0u);
                         placed = a1;                                          // K odd: the `time` draw is word 2 of this very block
                     }
+#if VPT_QREC && !defined(VPT_RAYGEN_ALL_BLOCKS)
+                    // QUEUE-ORDERED records carry the stream's POSITION, not its block (the tracer re-generates the block from the counter): a lane accepted at a block's
+                    // second attempt only steps its counter -- one more block is generated only while a lane is still UNDECIDED (both attempts rejected: 4.6 % of the lanes
+                    // per block, not the 21 % that also end on an even attempt).  Raygen -3 % on config 2 (profiles/r06_raygen.txt).  (-DVPT_RAYGEN_ALL_BLOCKS: as before, the A/B.)
+                    if (P.compact_rays && accepted != 0u && !placed) { cb += 1u; placed = true; }
+#endif
                     if (!__any(!placed)) break;
                     if (!placed) {
                         cb += 1u;
